@@ -1,0 +1,255 @@
+/*
+ * bioik_hip.h — C-ABI boundary of the MI355X-native bio2_memetic IK solver.
+ *
+ * This header is the drop-in boundary described in DESIGN.md §2.  It replaces, for the hot path
+ * only, the pair of calls
+ *
+ *     ik->initialize(problem);   ik->solve();           (reference src/kinematics_plugin.cpp:566-578)
+ *
+ * i.e. `bio_ik::IKParallel::initialize/solve/getSolution/getSuccess/getSolutionFitness`
+ * (reference src/ik_parallel.h:141-145, 193-276), and everything those calls execute:
+ * `IKEvolution2<'q'>::initialize/step` (src/ik_evolution_2.cpp:111-230, 328-646), `RobotFK`
+ * (src/forward_kinematics.h:65-1234), `Problem::computeGoalFitness/checkSolutionActiveVariables`
+ * (src/problem.cpp:244-341) and the built-in `Goal::evaluate`s (include/bio_ik/goal_types.h).
+ *
+ * Only plain C types cross this boundary: no C++ classes, no torch types, no HIP types (streams and
+ * device pointers travel as `void*`).  The reference-side adapter that marshals
+ * `moveit::core::RobotModel` / `bio_ik::Goal` objects into these PODs is shown in INTEGRATION.md and
+ * implemented (against stand-in MoveIt headers) in bio_ik_amd/cpp/.
+ *
+ * Conventions
+ *   - a frame is 7 doubles: px py pz qx qy qz qw  (Hamilton quaternion, reference
+ *     include/bio_ik/frame.h:51-56 stores the same 7 numbers + 1 pad)
+ *   - every function returns BIOIK_OK (0) or a negative status; it never aborts or throws.
+ *     `bioik_last_error()` returns a thread-local human-readable message for the last failure.
+ *   - handles are opaque and must be destroyed by the matching *_destroy.
+ */
+#ifndef BIOIK_HIP_H
+#define BIOIK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BIOIK_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum {
+    BIOIK_OK = 0,
+    BIOIK_ERR_INVALID_ARGUMENT = -1, /* malformed descriptor (reference: ERROR(...) -> std::runtime_error, src/utils.h:122-129) */
+    BIOIK_ERR_UNSUPPORTED = -2,      /* joint/goal type that has no device implementation */
+    BIOIK_ERR_NO_DEVICE = -3,        /* no HIP device / extension not usable: the product path never falls back to CPU */
+    BIOIK_ERR_HIP = -4,              /* a HIP runtime call failed; message in bioik_last_error() */
+    BIOIK_ERR_NOT_FOUND = -5         /* link/variable not part of the group (reference src/problem.cpp:125,141) */
+};
+
+/* ---- joint types: moveit::core::JointModel::JointType as used by
+ *      RobotJointEvaluator::getJointFrame (reference src/forward_kinematics.h:78-139) ---------- */
+enum {
+    BIOIK_JOINT_FIXED = 0,
+    BIOIK_JOINT_REVOLUTE = 1,  /* also URDF "continuous" (unbounded revolute) */
+    BIOIK_JOINT_PRISMATIC = 2,
+    BIOIK_JOINT_FLOATING = 3,  /* 7 variables x y z qx qy qz qw; oracle only (device: BIOIK_ERR_UNSUPPORTED) */
+    BIOIK_JOINT_PLANAR = 4     /* 3 variables x y theta;          oracle only (device: BIOIK_ERR_UNSUPPORTED) */
+};
+
+/* ---- goal opcodes: one per closed-form class of reference include/bio_ik/goal_types.h.
+ *      `n_params` doubles per query, laid out as listed.  Vectors that the reference normalises
+ *      in its setters/constructors (quaternions, directions) must arrive normalised. ------------ */
+enum {
+    BIOIK_GOAL_POSITION = 0,             /* goal_types.h:80-97    params: pos[3]                                  */
+    BIOIK_GOAL_ORIENTATION = 1,          /* goal_types.h:99-124   params: quat[4]                                 */
+    BIOIK_GOAL_POSE = 2,                 /* goal_types.h:126-181  params: pos[3] quat[4] rotation_scale           */
+    BIOIK_GOAL_LOOK_AT = 3,              /* goal_types.h:183-212  params: axis[3] target[3]                       */
+    BIOIK_GOAL_MAX_DISTANCE = 4,         /* goal_types.h:214-241  params: target[3] distance                      */
+    BIOIK_GOAL_MIN_DISTANCE = 5,         /* goal_types.h:243-270  params: target[3] distance                      */
+    BIOIK_GOAL_LINE = 6,                 /* goal_types.h:272-298  params: position[3] direction[3]                */
+    BIOIK_GOAL_PLANE = 7,                /* goal_types.h:300-328  params: position[3] normal[3]                   */
+    BIOIK_GOAL_AVOID_JOINT_LIMITS = 8,   /* goal_types.h:379-402  params: -                                       */
+    BIOIK_GOAL_CENTER_JOINTS = 9,        /* goal_types.h:404-426  params: -                                       */
+    BIOIK_GOAL_REGULARIZATION = 10,      /* goal_types.h:428-445  params: -                                       */
+    BIOIK_GOAL_MINIMAL_DISPLACEMENT = 11,/* goal_types.h:447-466  params: -                                       */
+    BIOIK_GOAL_JOINT_VARIABLE = 12,      /* goal_types.h:468-499  params: position                                */
+    BIOIK_GOAL_SIDE = 13,                /* goal_types.h:585-614  params: axis[3] direction[3]                    */
+    BIOIK_GOAL_DIRECTION = 14,           /* goal_types.h:616-644  params: axis[3] direction[3]                    */
+    BIOIK_GOAL_CONE = 15,                /* goal_types.h:646-712  params: position[3] position_weight axis[3] direction[3] angle */
+    BIOIK_GOAL_TYPE_COUNT = 16
+    /* TouchGoal (FCL), JointFunctionGoal / LinkFunctionGoal (std::function), BalanceGoal (URDF inertials)
+     * have no device opcode in this round: DESIGN.md §7. */
+};
+
+/* number of per-query parameter doubles of a goal opcode, or -1 for an unknown opcode */
+int bioik_goal_param_count(int goal_type);
+
+/* ---- solver modes: IKFactory names of reference src/ik_evolution_2.cpp:652-654 -------------- */
+enum {
+    BIOIK_MODE_BIO2 = 0,            /* "bio2":           16 generations per step, no memetic phase      */
+    BIOIK_MODE_BIO2_MEMETIC = 1,    /* "bio2_memetic":   8 generations + quadratic ('q') line search    */
+    BIOIK_MODE_BIO2_MEMETIC_L = 2   /* "bio2_memetic_l": 8 generations + linear ('l') line search       */
+};
+
+/* how a child's phenotype (tip frames) is obtained inside the evolution loop */
+enum {
+    BIOIK_FK_LINEAR = 0, /* the reference's first-order extrapolation RobotFK_Mutator::computeApproximateMutations
+                            (src/forward_kinematics.h:1172-1233) around the species' elite                       */
+    BIOIK_FK_EXACT = 1   /* exact chain walk per individual, RobotFK_Fast_Base::applyConfiguration semantics
+                            (src/forward_kinematics.h:331-354) — the north-star GPU path                         */
+};
+
+/* ---- flattened robot model = what RobotJointEvaluator/RobotFK_Fast_Base/RobotInfo read from
+ *      moveit::core::RobotModel (reference src/forward_kinematics.h:192-213, 230-246, 268-329;
+ *      include/bio_ik/robot_info.h:70-106).  One entry per link; entry i also describes the link's
+ *      parent joint (MoveIt: every link has exactly one parent joint). --------------------------- */
+typedef struct bioik_model_desc {
+    uint32_t struct_size;               /* sizeof(bioik_model_desc), for ABI evolution */
+    uint32_t n_links;
+    uint32_t n_variables;
+    uint32_t reserved;
+    const int32_t* link_parent;          /* [n_links] parent link index, -1 for the root link; parent < child */
+    const double* link_origin;           /* [n_links*7] LinkModel::getJointOriginTransform()            */
+    const int32_t* joint_type;           /* [n_links] BIOIK_JOINT_*                                      */
+    const double* joint_axis;            /* [n_links*3] Revolute/PrismaticJointModel::getAxis()          */
+    const int32_t* joint_first_variable; /* [n_links] JointModel::getFirstVariableIndex(), -1 if none   */
+    const int32_t* joint_mimic;          /* [n_links] link index whose joint this joint mimics, -1      */
+    const double* joint_mimic_factor;    /* [n_links] getMimicFactor()                                   */
+    const double* joint_mimic_offset;    /* [n_links] getMimicOffset()                                   */
+    const double* var_min;               /* [n_variables] VariableBounds::min_position_                  */
+    const double* var_max;               /* [n_variables] VariableBounds::max_position_                  */
+    const uint8_t* var_bounded;          /* [n_variables] VariableBounds::position_bounded_              */
+    const double* var_max_velocity;      /* [n_variables] VariableBounds::max_velocity_                  */
+} bioik_model_desc;
+
+/* ---- one goal of the problem template (structure shared by every query of a batch; the numeric
+ *      parameters are per query).  Mirrors what Goal::describe() puts into GoalContext
+ *      (reference include/bio_ik/goal.h:87-90, 113-117) plus the goal's class. ------------------ */
+typedef struct bioik_goal_desc {
+    int32_t type;      /* BIOIK_GOAL_*                                                     */
+    int32_t link;      /* link index for LinkGoalBase-derived goals, -1 otherwise          */
+    int32_t variable;  /* variable index for BIOIK_GOAL_JOINT_VARIABLE, -1 otherwise       */
+    int32_t secondary; /* Goal::isSecondary()                                              */
+    double weight;     /* Goal::getWeight()                                                */
+} bioik_goal_desc;
+
+/* ---- problem template = the arguments of Problem::initialize (reference src/problem.cpp:72-228)
+ *      that do not change from query to query. -------------------------------------------------- */
+typedef struct bioik_problem_desc {
+    uint32_t struct_size;
+    uint32_t n_group_joints;
+    const int32_t* group_joints; /* link indices of JointModelGroup::getActiveJointModels(), in that order */
+    uint32_t n_goals;
+    uint32_t n_fixed_joints;
+    const bioik_goal_desc* goals;
+    const int32_t* fixed_joints; /* link indices of BioIKKinematicsQueryOptions::fixed_joints (goal.h:124) */
+} bioik_problem_desc;
+
+/* ---- solver parameters = IKParams (reference src/utils.h:64-85) restricted to bio2*, plus the
+ *      additive GPU keys of DESIGN.md §5. -------------------------------------------------------- */
+typedef struct bioik_solve_params {
+    uint32_t struct_size;
+    int32_t mode;            /* BIOIK_MODE_*; yaml "mode" (kinematics_plugin.cpp:252)                    */
+    int32_t fk_mode;         /* BIOIK_FK_*;  new key "gpu_fk"                                            */
+    int32_t population;      /* children per species per generation (reference hard-codes 16,
+                                ik_evolution_2.cpp:138); new key "gpu_population"                        */
+    int32_t islands;         /* independent islands per query (reference concurrency()==4 identical
+                                clones, ik_evolution_2.cpp:649 + utils.h:423); new key "gpu_islands"     */
+    int32_t max_steps;       /* budget in IKEvolution2::step() calls per island; replaces the wall-clock
+                                timeout of ik_parallel.h:160 by a deterministic budget                   */
+    uint64_t random_seed;    /* yaml "random_seed" (kinematics_plugin.cpp:256)                           */
+    double dpos, drot, dtwist; /* yaml keys (kinematics_plugin.cpp:259-261); <0 or >=FLT_MAX disables   */
+    int32_t no_wipeout;      /* debugging aid: disable species wipe-outs                                 */
+    int32_t reserved;
+} bioik_solve_params;
+
+/* defaults: bio2_memetic, exact FK, population 128, 1 island, 64 steps, seed 0, dpos=drot=off, dtwist=1e-5 */
+void bioik_default_solve_params(bioik_solve_params* p);
+
+typedef struct bioik_model bioik_model;
+typedef struct bioik_problem bioik_problem;
+
+const char* bioik_last_error(void);
+int bioik_abi_version(void);
+/* number of usable HIP devices (0 when none); never fails */
+int bioik_device_count(void);
+
+/* replaces RobotFK/RobotInfo construction from a RobotModel (ik_base.h:144-151) */
+int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out);
+void bioik_model_destroy(bioik_model* m);
+
+/* replaces Problem::initialize + IKBase::initialize(problem) -> RobotFK::initialize(tips)
+ * (problem.cpp:72-228, ik_base.h:154-161, forward_kinematics.h:253-330, 566-599) */
+int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bioik_problem** out);
+void bioik_problem_destroy(bioik_problem* p);
+
+/* introspection of what Problem::initialize derived */
+int bioik_problem_active_variable_count(const bioik_problem* p);          /* Problem::active_variables.size()  */
+int bioik_problem_active_variables(const bioik_problem* p, int32_t* out); /* robot variable index per gene      */
+int bioik_problem_tip_count(const bioik_problem* p);                      /* Problem::tip_link_indices.size()   */
+int bioik_problem_tip_links(const bioik_problem* p, int32_t* out);
+int bioik_problem_param_count(const bioik_problem* p);                    /* doubles per query in goal_params   */
+int bioik_problem_variable_count(const bioik_problem* p);                 /* robot variables V                  */
+
+/*
+ * The batched solve: replaces IKParallel::solve() for n independent queries
+ * (reference src/ik_parallel.h:193-270, per query).
+ *   seeds        [n][V]  Problem::initial_guess (kinematics_plugin.cpp:466-485, 507): full variable vectors
+ *   goal_params  [n][P]  per-query goal parameters, goals in template order (P = bioik_problem_param_count)
+ *   solutions    [n][V]  IKParallel::getSolution(): full variable vector (inactive variables = seed)
+ *   fitness      [n]     IKParallel::getSolutionFitness(): primary fitness of the exact-FK pose
+ *   success      [n]     IKParallel::getSuccess(): Problem::checkSolutionActiveVariables on the exact-FK pose
+ *   steps        [n]     number of step() calls executed by the winning island (new: device counter)
+ * Host-pointer variant: copies in, solves, copies out, synchronises.
+ */
+int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds,
+                      const double* goal_params, double* solutions, double* fitness, int32_t* success,
+                      int32_t* steps);
+
+/* Device-pointer variant: all arrays already resident in HBM on the problem's device; enqueues on
+ * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising. */
+int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds,
+                             const double* d_goal_params, double* d_solutions, double* d_fitness,
+                             int32_t* d_success, int32_t* d_steps, void* hip_stream);
+
+/* ---- function-level entry points (device-resident math exposed one function at a time so that
+ *      each kernel can be parity-checked against the matching reference function) -------------- */
+
+/* RobotFK_Fast_Base::applyConfiguration + getTipFrames (forward_kinematics.h:331-356) for n genotypes.
+ *   seed [V] supplies the inactive variables; genes [n][D]; tip_frames [n][T][7].  Host pointers. */
+int bioik_eval_fk(bioik_problem* p, size_t n, const double* seed, const double* genes, double* tip_frames);
+
+/* Problem::computeGoalFitness over goals / secondary_goals (problem.cpp:244-257) with the phenotype from
+ * exact FK (fk_mode = BIOIK_FK_EXACT) or from the linear extrapolation around `base_genes`
+ * (fk_mode = BIOIK_FK_LINEAR; base_genes [D]).  One query's seed [V] and goal_params [P]; genes [n][D];
+ * primary [n], secondary [n].  Host pointers. */
+int bioik_eval_fitness(bioik_problem* p, int fk_mode, size_t n, const double* seed, const double* goal_params,
+                       const double* base_genes, const double* genes, double* primary, double* secondary);
+
+/* RobotFK_Mutator::initializeMutationApproximator (forward_kinematics.h:802-930): the per-(tip,gene) delta
+ * frames around base_genes.  deltas [T][D][7] (dpx dpy dpz dqx dqy dqz dqw), tip_frames [T][7]. Host pointers. */
+int bioik_eval_approximator(bioik_problem* p, const double* seed, const double* base_genes, double* tip_frames,
+                            double* deltas);
+
+/* IKEvolution2::reproduce (ik_evolution_2.cpp:242-326) with the counter-based RNG of DESIGN.md §4:
+ * parents [2][2][D] (parent, {genes,gradients}, gene); out children_genes / children_gradients [population][D].
+ * rng_key/species/generation select the random stream. Host pointers. */
+int bioik_eval_reproduce(bioik_problem* p, int population, uint32_t rng_key, int species, uint32_t generation,
+                         const double* parents, double* children_genes, double* children_gradients);
+
+/* Problem::checkSolutionActiveVariables (problem.cpp:259-341) on the exact-FK pose of n genotypes. */
+int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seed,
+                     const double* goal_params, const double* genes, int32_t* ok);
+
+/* streamed (unfused) generation: n_units (query,species) populations resident in HBM, layout
+ * genes [n_units][D][population] (individual index fastest — coalesced), fitness [n_units][population].
+ * One launch evaluates exact-FK fitness of every individual.  Used for the HBM-streamed measurement of
+ * DESIGN.md §6; device pointers, enqueued on hip_stream. */
+int bioik_stream_fitness_device(bioik_problem* p, size_t n_units, int population, const double* d_seeds,
+                                const double* d_goal_params, const double* d_genes, double* d_fitness,
+                                void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOIK_HIP_H */

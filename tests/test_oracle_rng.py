@@ -1,0 +1,39 @@
+"""Counter-based RNG: Random123 known-answer vectors and distribution sanity."""
+import numpy as np
+
+from oracle import orc
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32-10 and philox2x32-10
+    assert orc.philox4x32([0, 0], [0, 0, 0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32([0xffffffff] * 2, [0xffffffff] * 4) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32([0xa4093822, 0x299f31d0], [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert orc.philox2x32(0, 0, 0) == (0xff1dae59, 0x6cd10df2)
+    assert orc.philox2x32(0xffffffff, 0xffffffff, 0xffffffff) == (0x2c3f628b, 0xab4fd7ad)
+    assert orc.philox2x32(0x13198a2e, 0x243f6a88, 0x85a308d3) == (0xdd7ce038, 0xf62a4c12)
+
+
+def test_counter_gauss_and_uniform_definition():
+    # integer-only post-processing, reproduced here with Python integers
+    for key, c0, c1 in [(1, 2, 3), (0xdeadbeef, (77 << 8) | 5, (1234 << 4) | 8), (42, 0, 0)]:
+        x0, x1 = orc.philox2x32(key, c0, c1)
+        k = bin(x0).count("1") - 16
+        t = ((x1 & 0xffff) + (x1 >> 16)) / 65536.0 - 1.0
+        assert orc.counter_gauss(key, c0, c1) == (k + t) * 0.3499271061118826
+        assert orc.counter_uniform(key, c0, c1) == (((x0 << 32) | x1) >> 11) * 2.0 ** -53
+
+
+def test_counter_gauss_moments():
+    z = np.array([orc.counter_gauss(7, (c << 8) | g, 5 << 4) for c in range(2000) for g in range(10)])
+    assert abs(z.mean()) < 0.03
+    assert abs(z.var() - 1.0) < 0.03
+    assert abs(np.mean(z ** 3)) < 0.1
+    assert abs(np.mean(z ** 4) - 3.0) < 0.25
+    u = np.array([orc.counter_uniform(9, c, 3) for c in range(20000)])
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005 and u.min() >= 0 and u.max() < 1
+    # neighbouring children / genes are uncorrelated
+    zz = z.reshape(2000, 10)
+    assert abs(np.corrcoef(zz[:, 0], zz[:, 1])[0, 1]) < 0.08
+    assert abs(np.corrcoef(zz[:-1, 0], zz[1:, 0])[0, 1]) < 0.08
