@@ -1,0 +1,381 @@
+// bioik_compile.cpp — host half of the drop-in boundary.
+//
+// HostModel restates what the reference reads from moveit::core::RobotModel (src/forward_kinematics.h:192-213,
+// include/bio_ik/robot_info.h:70-106); HostProblem restates Problem::initialize (src/problem.cpp:72-228) and the
+// link schedule of RobotFK_Fast_Base::initialize (src/forward_kinematics.h:253-330), then compiles both into the
+// flat joint program (DevProblem) the gfx950 kernels walk: fixed links are folded into per-joint constant frames,
+// branch frames get LDS slots, goals are grouped by the tip they read.
+#include "bioik_compile.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+
+namespace bioik {
+
+static Frame identity() { return Frame{{0, 0, 0}, {0, 0, 0, 1}}; }
+static void qrot(const double* q, const double* v, double* r) {
+    double tx = q[1] * v[2] - q[2] * v[1], ty = q[2] * v[0] - q[0] * v[2], tz = q[0] * v[1] - q[1] * v[0];
+    double rx = q[3] * tx + q[1] * tz - q[2] * ty, ry = q[3] * ty + q[2] * tx - q[0] * tz, rz = q[3] * tz + q[0] * ty - q[1] * tx;
+    r[0] = rx + rx + v[0];
+    r[1] = ry + ry + v[1];
+    r[2] = rz + rz + v[2];
+}
+static void qmul(const double* p, const double* q, double* r) {
+    double x = (p[3] * q[0] + p[0] * q[3]) + (p[1] * q[2] - p[2] * q[1]);
+    double y = (p[3] * q[1] - p[0] * q[2]) + (p[1] * q[3] + p[2] * q[0]);
+    double z = (p[3] * q[2] + p[0] * q[1]) - (p[1] * q[0] - p[2] * q[3]);
+    double w = (p[3] * q[3] - p[0] * q[0]) - (p[1] * q[1] + p[2] * q[2]);
+    r[0] = x, r[1] = y, r[2] = z, r[3] = w;
+}
+static Frame concat(const Frame& a, const Frame& b) {
+    Frame r;
+    double d[3];
+    qrot(a.q, b.p, d);
+    for (int i = 0; i < 3; i++) r.p[i] = a.p[i] + d[i];
+    qmul(a.q, b.q, r.q);
+    return r;
+}
+static bool is_identity(const Frame& f) { return f.p[0] == 0 && f.p[1] == 0 && f.p[2] == 0 && f.q[0] == 0 && f.q[1] == 0 && f.q[2] == 0 && f.q[3] == 1; }
+
+int goal_param_count(int type) {
+    switch (type) {
+        case BIOIK_GOAL_POSITION: return 3;
+        case BIOIK_GOAL_ORIENTATION: return 4;
+        case BIOIK_GOAL_POSE: return 8;
+        case BIOIK_GOAL_LOOK_AT: return 6;
+        case BIOIK_GOAL_MAX_DISTANCE: return 4;
+        case BIOIK_GOAL_MIN_DISTANCE: return 4;
+        case BIOIK_GOAL_LINE: return 6;
+        case BIOIK_GOAL_PLANE: return 6;
+        case BIOIK_GOAL_AVOID_JOINT_LIMITS: return 0;
+        case BIOIK_GOAL_CENTER_JOINTS: return 0;
+        case BIOIK_GOAL_REGULARIZATION: return 0;
+        case BIOIK_GOAL_MINIMAL_DISPLACEMENT: return 0;
+        case BIOIK_GOAL_JOINT_VARIABLE: return 1;
+        case BIOIK_GOAL_SIDE: return 6;
+        case BIOIK_GOAL_DIRECTION: return 6;
+        case BIOIK_GOAL_CONE: return 11;
+    }
+    return -1;
+}
+
+static int joint_var_count(int type) {
+    switch (type) {
+        case BIOIK_JOINT_FIXED: return 0;
+        case BIOIK_JOINT_REVOLUTE: return 1;
+        case BIOIK_JOINT_PRISMATIC: return 1;
+        case BIOIK_JOINT_FLOATING: return 7;
+        case BIOIK_JOINT_PLANAR: return 3;
+    }
+    throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown joint type");
+}
+
+HostModel::HostModel(const bioik_model_desc& d) {
+    if (d.struct_size != sizeof(bioik_model_desc)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_model_desc: struct_size mismatch");
+    if (d.n_links == 0) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "model has no links");
+    if (!d.link_parent || !d.link_origin || !d.joint_type || !d.joint_axis || !d.joint_first_variable)
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_model_desc: null link array");
+    if (d.n_variables > 0 && (!d.var_min || !d.var_max || !d.var_bounded || !d.var_max_velocity))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_model_desc: null variable array");
+    links.resize(d.n_links);
+    std::vector<int> var_joint(d.n_variables, -1);
+    for (uint32_t i = 0; i < d.n_links; i++) {
+        Link& l = links[i];
+        l.parent = d.link_parent[i];
+        if (l.parent >= (int)i || l.parent < -1) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "links must be ordered parent before child");
+        for (int c = 0; c < 3; c++) l.origin.p[c] = d.link_origin[7 * i + c];
+        for (int c = 0; c < 4; c++) l.origin.q[c] = d.link_origin[7 * i + 3 + c];
+        l.type = d.joint_type[i];
+        for (int c = 0; c < 3; c++) l.axis[c] = d.joint_axis[3 * i + c];
+        l.first_var = d.joint_first_variable[i];
+        l.var_count = joint_var_count(l.type);
+        l.mimic = d.joint_mimic ? d.joint_mimic[i] : -1;
+        if (l.var_count > 0) {
+            if (l.first_var < 0 || l.first_var + l.var_count > (int)d.n_variables) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "joint variable index out of range");
+            for (int v = 0; v < l.var_count; v++) var_joint[l.first_var + v] = (int)i;
+        }
+    }
+    // RobotInfo (robot_info.h:70-106)
+    vars.resize(d.n_variables);
+    for (uint32_t v = 0; v < d.n_variables; v++) {
+        Var info;
+        bool bounded = d.var_bounded[v] != 0;
+        int j = var_joint[v];
+        if (j >= 0 && links[j].type == BIOIK_JOINT_REVOLUTE)
+            if (d.var_max[v] - d.var_min[v] >= 2 * M_PI * 0.9999) bounded = false;  // :82-84
+        info.vmin = d.var_min[v];
+        info.vmax = d.var_max[v];
+        info.clip_min = bounded ? info.vmin : -DBL_MAX;
+        info.clip_max = bounded ? info.vmax : +DBL_MAX;
+        info.span = info.vmax - info.vmin;
+        if (!(info.span >= 0 && info.span < FLT_MAX)) info.span = 1;  // :94
+        double mv = d.var_max_velocity[v];
+        info.max_velocity_rcp = mv > 0.0 ? 1.0 / mv : 0.0;
+        info.joint = j;
+        vars[v] = info;
+    }
+}
+
+HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : model(m) {
+    if (d.struct_size != sizeof(bioik_problem_desc)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_problem_desc: struct_size mismatch");
+    const int nl = (int)m->links.size(), nv = (int)m->vars.size();
+    std::memset(&dev, 0, sizeof(dev));
+
+    // ---- Problem::initialize, problem.cpp:72-228 ----
+    std::vector<char> group_variable(nv, 0), fixed_joint(nl, 0);
+    std::vector<int> group_joints(d.group_joints, d.group_joints + d.n_group_joints);
+    for (int j : group_joints) {
+        if (j < 0 || j >= nl) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "group joint out of range");
+        for (int v = 0; v < m->links[j].var_count; v++) group_variable[m->links[j].first_var + v] = 1;
+    }
+    for (uint32_t i = 0; i < d.n_fixed_joints; i++) {
+        int j = d.fixed_joints[i];
+        if (j < 0 || j >= nl) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "fixed joint out of range");
+        fixed_joint[j] = 1;
+    }
+    std::vector<long> link_tip(nl, -1);
+    auto add_tip_link = [&](int link) -> int {  // problem.cpp:57-65
+        if (link_tip[link] < 0) {
+            link_tip[link] = (long)tip_links.size();
+            tip_links.push_back(link);
+        }
+        return (int)link_tip[link];
+    };
+    auto add_active_variable = [&](int ivar) -> long {  // problem.cpp:103-126
+        int joint = m->vars[ivar].joint;
+        if (joint >= 0 && fixed_joint[joint]) return (long)-1 - (long)ivar;
+        for (size_t i = 0; i < active_variables.size(); i++)
+            if (active_variables[i] == ivar) return (long)i;
+        if (group_variable[ivar]) {
+            active_variables.push_back(ivar);
+            return (long)active_variables.size() - 1;
+        }
+        throw Error(BIOIK_ERR_NOT_FOUND, "joint variable not found");
+    };
+    struct G {
+        int type, tip;
+        long var;
+        double weight;
+        int secondary, param_off;
+    };
+    std::vector<G> goals;
+    for (uint32_t gi = 0; gi < d.n_goals; gi++) {
+        const bioik_goal_desc& g = d.goals[gi];
+        int np = goal_param_count(g.type);
+        if (np < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "goal type has no device implementation");
+        G info{g.type, -1, LONG_MIN, g.weight, g.secondary != 0, param_count};
+        if (g.link >= 0) {
+            if (g.link >= nl) throw Error(BIOIK_ERR_NOT_FOUND, "link not found");
+            info.tip = add_tip_link(g.link);
+        }
+        if (g.variable >= 0) {
+            if (g.variable >= nv) throw Error(BIOIK_ERR_NOT_FOUND, "joint variable not found");
+            info.var = add_active_variable(g.variable);
+        }
+        param_count += np;
+        goals.push_back(info);
+    }
+    {  // active variables of the active subtree, problem.cpp:191-204
+        std::vector<char> usage(nl, 0);
+        for (int tip : tip_links)
+            for (int l = tip; l >= 0; l = m->links[l].parent) usage[l] = 1;
+        for (int j = 0; j < nl; j++)
+            if (fixed_joint[j]) usage[j] = 0;
+        for (int j : group_joints)
+            if (usage[j] && m->links[j].mimic < 0)
+                for (int v = 0; v < m->links[j].var_count; v++) add_active_variable(m->links[j].first_var + v);
+    }
+    const int D = (int)active_variables.size();
+    std::vector<double> vw(D);  // problem.cpp:206-225
+    {
+        double s = 0;
+        for (int v : active_variables) s += m->vars[v].max_velocity_rcp;
+        for (int i = 0; i < D; i++) vw[i] = s > 0 ? m->vars[active_variables[i]].max_velocity_rcp / s : 1.0 / D;
+    }
+
+    // ---- link schedule (forward_kinematics.h:268-282) folded into the joint program ----
+    std::vector<int> schedule;
+    std::vector<char> scheduled(nl, 0);
+    for (int tip : tip_links) {
+        std::vector<int> chain;
+        for (int l = tip; l >= 0; l = m->links[l].parent) chain.push_back(l);
+        std::reverse(chain.begin(), chain.end());
+        for (int l : chain)
+            if (!scheduled[l]) scheduled[l] = 1, schedule.push_back(l);
+    }
+    std::vector<int> gene_of_var(nv, -1);
+    for (int i = 0; i < D; i++) gene_of_var[active_variables[i]] = i;
+    std::vector<int> src_of(nl, -1), op_of_link(nl, -1);
+    std::vector<Frame> c_of(nl, identity());
+    std::vector<DevOp> ops;
+    for (int l : schedule) {
+        const HostModel::Link& L = m->links[l];
+        if (L.mimic >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "mimic joints have no device implementation in this version");
+        int base_src = L.parent >= 0 ? src_of[L.parent] : -1;
+        Frame base_c = L.parent >= 0 ? c_of[L.parent] : identity();
+        Frame C = concat(base_c, L.origin);
+        if (L.type == BIOIK_JOINT_FIXED) {
+            src_of[l] = base_src;
+            c_of[l] = C;
+            continue;
+        }
+        if (L.type != BIOIK_JOINT_REVOLUTE && L.type != BIOIK_JOINT_PRISMATIC)
+            throw Error(BIOIK_ERR_UNSUPPORTED, "floating / planar joints have no device implementation in this version");
+        DevOp op;
+        std::memset(&op, 0, sizeof(op));
+        op.type = L.type == BIOIK_JOINT_REVOLUTE ? BIOIK_OP_REVOLUTE : BIOIK_OP_PRISMATIC;
+        op.var = L.first_var;
+        op.gene = gene_of_var[L.first_var];
+        op.src = base_src;
+        op.load_slot = op.save_slot = -1;
+        for (int c = 0; c < 3; c++) op.cpos[c] = C.p[c], op.axis[c] = L.axis[c];
+        for (int c = 0; c < 4; c++) op.ca[c] = C.q[c];
+        if (op.type == BIOIK_OP_REVOLUTE) {
+            double aq[4] = {L.axis[0], L.axis[1], L.axis[2], 0.0};
+            qmul(C.q, aq, op.cb);
+        } else {
+            qrot(C.q, L.axis, op.cb);
+            op.cb[3] = 0.0;
+        }
+        int k = (int)ops.size();
+        ops.push_back(op);
+        src_of[l] = k;
+        op_of_link[l] = k;
+        c_of[l] = identity();
+    }
+    const int n_chain = (int)ops.size();
+    for (int i = 0; i < D; i++) {  // active variables that move no scheduled link (goal variables off the chains)
+        int v = active_variables[i];
+        int j = m->vars[v].joint;
+        if (j >= 0 && op_of_link[j] >= 0) continue;
+        if (j >= 0 && (m->links[j].type != BIOIK_JOINT_REVOLUTE && m->links[j].type != BIOIK_JOINT_PRISMATIC))
+            throw Error(BIOIK_ERR_UNSUPPORTED, "floating / planar joints have no device implementation in this version");
+        DevOp op;
+        std::memset(&op, 0, sizeof(op));
+        op.type = BIOIK_OP_NONE;
+        op.var = v;
+        op.gene = i;
+        op.src = op.load_slot = op.save_slot = -1;
+        ops.push_back(op);
+    }
+    if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 32 moving joints on the goal chains");
+    if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 8 tip links");
+    for (size_t k = 0; k < ops.size(); k++) {
+        DevOp& op = ops[k];
+        const HostModel::Var& vi = m->vars[op.var];
+        op.clip_min = vi.clip_min, op.clip_max = vi.clip_max, op.span = vi.span, op.vmin = vi.vmin, op.vmax = vi.vmax;
+        op.unbounded = vi.clip_max == DBL_MAX;
+        op.vw = op.gene >= 0 ? vw[op.gene] : 0.0;
+        if (op.gene >= 0) dev.op_of_gene[op.gene] = (int)k;
+    }
+    // branch frames: an op whose parent frame is not the running frame fetches it from an LDS slot
+    int n_slots = 0;
+    for (int k = 0; k < n_chain; k++) {
+        int s = ops[k].src;
+        if (s >= 0 && s != k - 1) {
+            if (ops[s].save_slot < 0) ops[s].save_slot = n_slots++;
+            ops[k].load_slot = ops[s].save_slot;
+        }
+    }
+    // tips, ordered by the op that completes them
+    struct TipTmp {
+        int pub, src;
+        Frame e;
+    };
+    std::vector<TipTmp> tt;
+    for (size_t t = 0; t < tip_links.size(); t++) tt.push_back(TipTmp{(int)t, src_of[tip_links[t]], c_of[tip_links[t]]});
+    std::stable_sort(tt.begin(), tt.end(), [](const TipTmp& a, const TipTmp& b) { return a.src < b.src; });
+    const int T = (int)tt.size();
+    for (int k = 0; k < (int)ops.size(); k++) ops[k].tip_first = 0, ops[k].tip_count = 0;
+    for (int t = 0; t < T; t++) {
+        DevTip& dt = dev.tips[t];
+        dt.src = tt[t].src;
+        dt.has_e = !is_identity(tt[t].e);
+        for (int c = 0; c < 3; c++) dt.e[c] = tt[t].e.p[c];
+        for (int c = 0; c < 4; c++) dt.e[3 + c] = tt[t].e.q[c];
+        dt.out_index = tt[t].pub;
+        dev.tip_of_out[tt[t].pub] = t;
+        uint32_t mask = 0;
+        for (int l = tip_links[tt[t].pub]; l >= 0; l = m->links[l].parent)
+            if (op_of_link[l] >= 0) mask |= 1u << op_of_link[l];
+        dt.dep_mask = mask;
+        if (dt.src < 0) {
+            dev.n_root_tips++;
+        } else {
+            DevOp& op = ops[dt.src];
+            if (op.tip_count == 0) op.tip_first = t;
+            op.tip_count++;
+        }
+    }
+    // goals: primary link goals grouped by device tip, then gene-only primary goals; secondary goals in order
+    auto to_dev = [&](const G& g) {
+        DevGoal o;
+        std::memset(&o, 0, sizeof(o));
+        o.weight_sq = g.weight * g.weight;
+        o.type = g.type;
+        o.tip = g.tip >= 0 ? dev.tip_of_out[g.tip] : -1;
+        o.var_op = -1, o.var_seed = -1;
+        if (g.var != LONG_MIN) {
+            if (g.var >= 0) o.var_op = dev.op_of_gene[g.var];
+            else o.var_seed = (int)(-1 - g.var);
+        }
+        o.param_off = g.param_off;
+        return o;
+    };
+    int np = 0, ns = 0;
+    for (int t = 0; t < T; t++) {
+        dev.tips[t].goal_first = np;
+        for (const G& g : goals)
+            if (!g.secondary && g.tip >= 0 && dev.tip_of_out[g.tip] == t) {
+                if (np >= BIOIK_MAX_GOALS) throw Error(BIOIK_ERR_UNSUPPORTED, "too many goals");
+                dev.primary[np++] = to_dev(g);
+            }
+        dev.tips[t].goal_count = np - dev.tips[t].goal_first;
+    }
+    dev.n_link_primary = np;
+    for (const G& g : goals) {
+        if (g.secondary) {
+            if (ns >= BIOIK_MAX_GOALS) throw Error(BIOIK_ERR_UNSUPPORTED, "too many goals");
+            dev.secondary[ns++] = to_dev(g);
+        } else if (g.tip < 0) {
+            if (np >= BIOIK_MAX_GOALS) throw Error(BIOIK_ERR_UNSUPPORTED, "too many goals");
+            dev.primary[np++] = to_dev(g);
+        }
+    }
+    dev.n_primary = np;
+    dev.n_secondary = ns;
+    dev.n_ops = (int)ops.size();
+    dev.n_chain_ops = n_chain;
+    dev.D = D;
+    dev.T = T;
+    dev.V = nv;
+    dev.P = param_count;
+    dev.n_slots = n_slots;
+    for (size_t k = 0; k < ops.size(); k++) dev.ops[k] = ops[k];
+}
+
+DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query) {
+    if (p.struct_size != sizeof(bioik_solve_params)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_params: struct_size mismatch");
+    DevSolveParams o;
+    std::memset(&o, 0, sizeof(o));
+    auto thr = [](double v) { return (v < 0.0 || v >= FLT_MAX || !std::isfinite(v)) ? DBL_MAX : v; };  // problem.cpp:90-95
+    o.dpos = thr(p.dpos), o.drot = thr(p.drot), o.dtwist = thr(p.dtwist);
+    o.random_seed = p.random_seed;
+    o.first_query = first_query;
+    if (p.mode != BIOIK_MODE_BIO2 && p.mode != BIOIK_MODE_BIO2_MEMETIC && p.mode != BIOIK_MODE_BIO2_MEMETIC_L)
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown solver mode");
+    o.memetic = p.mode == BIOIK_MODE_BIO2 ? 0 : (p.mode == BIOIK_MODE_BIO2_MEMETIC_L ? 'l' : 'q');
+    if (p.fk_mode != BIOIK_FK_LINEAR && p.fk_mode != BIOIK_FK_EXACT) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown fk_mode");
+    o.fk_mode = p.fk_mode;
+    o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
+    o.islands = p.islands > 0 ? p.islands : 1;
+    o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
+    o.no_wipeout = p.no_wipeout;
+    o.generations = o.memetic ? 8 : 16;  // ik_evolution_2.cpp:349-351
+    return o;
+}
+
+}  // namespace bioik

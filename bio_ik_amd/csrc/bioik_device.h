@@ -1,0 +1,604 @@
+// bioik_device.h — per-lane device functions of the MI355X bio2_memetic solver: rigid-transform algebra, the
+// counter-based RNG, goal costs, the joint-program chain walk (exact FK), the linearised phenotype model and
+// reproduction.  Every function is what ONE lane does for ONE individual; the kernels in bioik_kernels.h decide
+// which individual a lane holds.  Written against bioik_platform.h only.
+//
+// Behavioural reference (what is computed, not how): TAMS-Group/bio_ik
+//   include/bio_ik/frame.h:108-187, 231-238       quat_mul_vec, quat_mul_quat, concat, normalizeFast
+//   src/forward_kinematics.h:78-139, 331-354       joint frames, exact FK over the link schedule
+//   src/forward_kinematics.h:600-730, 802-930      analytic Jacobian, mutation approximator tables
+//   src/forward_kinematics.h:1009-1058, 1175-1233  linearised phenotypes
+//   include/bio_ik/goal_types.h:80-712             closed-form goal costs
+//   src/problem.cpp:244-341                        computeGoalFitness, checkSolutionActiveVariables
+//   src/ik_evolution_2.cpp:242-326                 reproduce
+#pragma once
+#include "bioik_platform.h"
+
+#if defined(BIOIK_HOSTSIM)
+#define BIOIK_FP_STRICT
+#else
+#define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
+#endif
+
+// goal opcodes / modes: numeric values of include/bioik_hip.h (kept in sync by a static_assert in bioik_hip.hip)
+enum {
+    G_POSITION = 0, G_ORIENTATION = 1, G_POSE = 2, G_LOOK_AT = 3, G_MAX_DISTANCE = 4, G_MIN_DISTANCE = 5, G_LINE = 6,
+    G_PLANE = 7, G_AVOID_JOINT_LIMITS = 8, G_CENTER_JOINTS = 9, G_REGULARIZATION = 10, G_MINIMAL_DISPLACEMENT = 11,
+    G_JOINT_VARIABLE = 12, G_SIDE = 13, G_DIRECTION = 14, G_CONE = 15
+};
+enum { FK_LINEAR = 0, FK_EXACT = 1 };
+
+struct V3 {
+    double x, y, z;
+};
+struct Q4 {
+    double x, y, z, w;
+};
+struct F7 {
+    V3 p;
+    Q4 q;
+};
+
+BIOIK_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+BIOIK_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+BIOIK_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+BIOIK_DEV V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
+BIOIK_DEV double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+BIOIK_DEV V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+BIOIK_DEV double len2(V3 a) { return dot3(a, a); }
+BIOIK_DEV double dist2(V3 a, V3 b) { return len2(b - a); }
+BIOIK_DEV V3 normalized3(V3 a) {
+    double l = sqrt(len2(a));
+    return V3{a.x / l, a.y / l, a.z / l};
+}
+BIOIK_DEV double qdot(Q4 a, Q4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+BIOIK_DEV Q4 qinv(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
+BIOIK_DEV double clamped_acos(double x) { return acos(fmin(1.0, fmax(-1.0, x))); }
+BIOIK_DEV F7 f7_identity() { return F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 1.0}}; }
+
+// rotate v by unit quaternion q (frame.h:108-149; its identity/zero short-cuts are arithmetic no-ops)
+BIOIK_DEV V3 qrot(Q4 q, V3 v) {
+    double tx = q.y * v.z - q.z * v.y;
+    double ty = q.z * v.x - q.x * v.z;
+    double tz = q.x * v.y - q.y * v.x;
+    double rx = q.w * tx + q.y * tz - q.z * ty;
+    double ry = q.w * ty + q.z * tx - q.x * tz;
+    double rz = q.w * tz + q.x * ty - q.y * tx;
+    return V3{rx + rx + v.x, ry + ry + v.y, rz + rz + v.z};
+}
+// Hamilton product (frame.h:151-172)
+BIOIK_DEV Q4 qmul(Q4 p, Q4 q) {
+    return Q4{(p.w * q.x + p.x * q.w) + (p.y * q.z - p.z * q.y), (p.w * q.y - p.x * q.z) + (p.y * q.w + p.z * q.x),
+              (p.w * q.z + p.x * q.y) - (p.y * q.x - p.z * q.w), (p.w * q.w - p.x * q.x) - (p.y * q.y + p.z * q.z)};
+}
+BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p), qmul(a.q, b.q)}; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox2x32-10 (Salmon et al., SC'11; Random123 constants) with integer-only
+// post-processing, so that the device and the CPU oracle (oracle/orc_rng.h) produce bit-identical doubles.
+// ---------------------------------------------------------------------------------------------------------
+enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4 };
+#define RNG_SLOT_RATE 255u
+
+BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        if (r > 0) key += 0x9E3779B9u;
+        uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0;
+        uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+    }
+    o0 = c0;
+    o1 = c1;
+}
+BIOIK_DEV uint32_t rng_ctr0(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
+BIOIK_DEV uint32_t rng_ctr1(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
+// ~N(0,1): Binomial(32,1/2) lattice + triangular jitter
+BIOIK_DEV double rng_gauss(uint32_t x0, uint32_t x1) {
+    int k = p_popc(x0) - 16;
+    uint32_t s = (x1 & 0xffffu) + (x1 >> 16);
+    double t = (double)s * (1.0 / 65536.0) - 1.0;
+    return ((double)k + t) * 0.3499271061118826;
+}
+BIOIK_DEV double rng_uniform(uint32_t x0, uint32_t x1) {
+    uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+}
+BIOIK_DEV uint32_t rng_query_key(uint64_t seed, uint64_t query, uint32_t island) {
+    uint32_t o0, o1;
+    philox2x32_10((uint32_t)seed, (uint32_t)query, (uint32_t)(seed >> 32) ^ (island * 0x9E3779B9u) ^ (uint32_t)(query >> 32), o0, o1);
+    return o0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-query context: seed (Problem::initial_guess) and goal parameters, staged in LDS by the kernels
+// ---------------------------------------------------------------------------------------------------------
+struct QueryCtx {
+    const double* seed;  // [V]
+    const double* par;   // [P]
+};
+
+BIOIK_DEV F7 f7_load(const double* p) { return F7{{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}}; }
+BIOIK_DEV void f7_store(double* p, const F7& f) {
+    p[0] = f.p.x;
+    p[1] = f.p.y;
+    p[2] = f.p.z;
+    p[3] = f.q.x;
+    p[4] = f.q.y;
+    p[5] = f.q.z;
+    p[6] = f.q.w;
+}
+
+// One value per op of the joint program ("genotype in op order"), held in LDS.  A lane's own individual is a column
+// of the [op][lane] array (p = base + lane, s = nthreads: consecutive lanes hit consecutive banks); a vector shared
+// by the whole workgroup (an elite, a line-search point) is read with s = 1 (same address in every lane: broadcast).
+struct XV {
+    const double* p;
+    int s;
+    BIOIK_DEV double operator()(int k) const { return p[(size_t)k * s]; }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// goal costs (goal_types.h); joint-set goals walk the active ops.
+// ---------------------------------------------------------------------------------------------------------
+BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
+    const int n_ops = pb->n_ops;
+    switch (type) {
+        case G_POSITION:  // goal_types.h:96
+            return dist2(fb.p, v3(P[0], P[1], P[2]));
+        case G_ORIENTATION: {  // :115-124
+            double dx = P[0] - fb.q.x, dy = P[1] - fb.q.y, dz = P[2] - fb.q.z, dw = P[3] - fb.q.w;
+            double sx = P[0] + fb.q.x, sy = P[1] + fb.q.y, sz = P[2] + fb.q.z, sw = P[3] + fb.q.w;
+            return fmin(dx * dx + dy * dy + dz * dz + dw * dw, sx * sx + sy * sy + sz * sz + sw * sw);
+        }
+        case G_POSE: {  // :149-180
+            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
+            double dx = P[3] - fb.q.x, dy = P[4] - fb.q.y, dz = P[5] - fb.q.z, dw = P[6] - fb.q.w;
+            double sx = P[3] + fb.q.x, sy = P[4] + fb.q.y, sz = P[5] + fb.q.z, sw = P[6] + fb.q.w;
+            double rs = P[7];
+            e += fmin(dx * dx + dy * dy + dz * dz + dw * dw, sx * sx + sy * sy + sz * sz + sw * sw) * (rs * rs);
+            return e;
+        }
+        case G_LOOK_AT: {  // :204-211
+            V3 axis = qrot(fb.q, v3(P[0], P[1], P[2]));
+            V3 target = v3(P[3], P[4], P[5]);
+            return dist2(normalized3(target - fb.p), normalized3(axis));
+        }
+        case G_MAX_DISTANCE: {  // :235-240
+            double d = fmax(0.0, sqrt(dist2(fb.p, v3(P[0], P[1], P[2]))) - P[3]);
+            return d * d;
+        }
+        case G_MIN_DISTANCE: {  // :264-269
+            double d = fmax(0.0, P[3] - sqrt(dist2(fb.p, v3(P[0], P[1], P[2]))));
+            return d * d;
+        }
+        case G_LINE: {  // :293-297
+            V3 position = v3(P[0], P[1], P[2]), direction = v3(P[3], P[4], P[5]);
+            return dist2(position, fb.p - direction * dot3(direction, fb.p - position));
+        }
+        case G_PLANE: {  // :321-327
+            V3 position = v3(P[0], P[1], P[2]), normal = v3(P[3], P[4], P[5]);
+            double sd = dot3(fb.p - position, normal);
+            return sd * sd;
+        }
+        case G_AVOID_JOINT_LIMITS: {  // :387-401
+            double sum = 0.0;
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
+                    double d = x(k) - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
+                    d = fmax(0.0, fabs(d) * 2.0 - pb->ops[k].span * 0.5);
+                    d *= pb->ops[k].vw;
+                    sum += d * d;
+                }
+            return sum;
+        }
+        case G_CENTER_JOINTS: {  // :412-425
+            double sum = 0.0;
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
+                    double d = x(k) - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
+                    d *= pb->ops[k].vw;
+                    sum += d * d;
+                }
+            return sum;
+        }
+        case G_REGULARIZATION: {  // :435-444
+            double sum = 0.0;
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0) {
+                    double d = x(k) - qc.seed[pb->ops[k].var];
+                    sum += d * d;
+                }
+            return sum;
+        }
+        case G_MINIMAL_DISPLACEMENT: {  // :455-465
+            double sum = 0.0;
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0) {
+                    double d = x(k) - qc.seed[pb->ops[k].var];
+                    d *= pb->ops[k].vw;
+                    sum += d * d;
+                }
+            return sum;
+        }
+        case G_JOINT_VARIABLE: {  // :494-498 + goal.h:70-77
+            double v = var_op >= 0 ? x(var_op) : qc.seed[var_seed];
+            double d = P[0] - v;
+            return d * d;
+        }
+        case G_SIDE: {  // :606-613
+            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
+            double f = fmax(0.0, dot3(v, v3(P[3], P[4], P[5])));
+            return f * f;
+        }
+        case G_DIRECTION: {  // :637-643
+            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
+            return dist2(v, v3(P[3], P[4], P[5]));
+        }
+        case G_CONE: {  // :700-711
+            V3 v = qrot(fb.q, v3(P[4], P[5], P[6]));
+            V3 dir = v3(P[7], P[8], P[9]);
+            double ang = clamped_acos(dot3(v, dir) / sqrt(len2(v) * len2(dir)));
+            double d = fmax(0.0, ang - P[10]);
+            double w = P[3];
+            return d * d + w * w * len2(v3(P[0], P[1], P[2]) - fb.p);
+        }
+    }
+    return 0.0;
+}
+
+// Σ weight² · e over the primary link goals of one tip (problem.cpp:244-257, grouped by tip)
+BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XV& x, const QueryCtx& qc) {
+    double sum = 0.0;
+    const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
+    for (int g = g0; g < g1; g++)
+        sum += goal_eval(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, f, x, qc) *
+               pb->primary[g].weight_sq;
+    return sum;
+}
+// primary goals that read no link
+BIOIK_DEV double nonlink_primary(ProbPtr pb, const XV& x, const QueryCtx& qc) {
+    double sum = 0.0;
+    const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    for (int g = pb->n_link_primary; g < pb->n_primary; g++)
+        sum += goal_eval(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, zero, x, qc) *
+               pb->primary[g].weight_sq;
+    return sum;
+}
+// secondary goals see genes only; link goals marked secondary read null frames (ik_base.h:163)
+BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) {
+    double sum = 0.0;
+    const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    for (int g = 0; g < pb->n_secondary; g++)
+        sum += goal_eval(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
+               pb->secondary[g].weight_sq;
+    return sum;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact FK: every lane walks the joint program with the values of ITS individual (forward_kinematics.h:331-354)
+//   slots      LDS, [slot][7][nthreads]: parked branch frames of this lane
+//   frames_out LDS or null, [op][7]: when set, lane 0 of the workgroup publishes every joint's global frame
+//              (the per-joint frame chain the analytic Jacobian reads)
+//   tip_fn(t, frame): called with device tip index t as soon as the tip's frame is complete
+// The loop trip count and every constant are wave-uniform: control flow is scalar, constants arrive in SGPRs.
+// ---------------------------------------------------------------------------------------------------------
+template <class TipFn>
+BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn) {
+    const int tid = p_tid(), nth = p_nthreads();
+    const int n_chain = pb->n_chain_ops;
+    F7 f = f7_identity();
+    for (int t = 0; t < pb->n_root_tips; t++) {
+        if (pb->tips[t].has_e) {
+            double e[7];
+            for (int c = 0; c < 7; c++) e[c] = pb->tips[t].e[c];
+            tip_fn(t, f7_load(e));
+        } else {
+            tip_fn(t, f);
+        }
+    }
+    for (int k = 0; k < n_chain; k++) {
+        const int ls = pb->ops[k].load_slot;
+        if (ls >= 0) {
+            const double* s = slots + (size_t)ls * 7 * nth + tid;
+            f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
+        } else if (k > 0 && pb->ops[k].src < 0) {
+            f = f7_identity();
+        }
+        const double xv = x(k);
+        const V3 cp = v3(pb->ops[k].cpos[0], pb->ops[k].cpos[1], pb->ops[k].cpos[2]);
+        const Q4 ca = Q4{pb->ops[k].ca[0], pb->ops[k].ca[1], pb->ops[k].ca[2], pb->ops[k].ca[3]};
+        if (pb->ops[k].type == BIOIK_OP_REVOLUTE) {
+            double s, c;
+            p_sincos(xv * 0.5, &s, &c);
+            Q4 lq = Q4{c * ca.x + s * pb->ops[k].cb[0], c * ca.y + s * pb->ops[k].cb[1], c * ca.z + s * pb->ops[k].cb[2], c * ca.w + s * pb->ops[k].cb[3]};
+            f.p = f.p + qrot(f.q, cp);
+            f.q = qmul(f.q, lq);
+        } else {
+            V3 lp = v3(cp.x + xv * pb->ops[k].cb[0], cp.y + xv * pb->ops[k].cb[1], cp.z + xv * pb->ops[k].cb[2]);
+            f.p = f.p + qrot(f.q, lp);
+            f.q = qmul(f.q, ca);
+        }
+        const int ss = pb->ops[k].save_slot;
+        if (ss >= 0) {
+            double* s = slots + (size_t)ss * 7 * nth + tid;
+            s[0] = f.p.x;
+            s[(size_t)nth] = f.p.y;
+            s[(size_t)2 * nth] = f.p.z;
+            s[(size_t)3 * nth] = f.q.x;
+            s[(size_t)4 * nth] = f.q.y;
+            s[(size_t)5 * nth] = f.q.z;
+            s[(size_t)6 * nth] = f.q.w;
+        }
+        if (frames_out && tid == 0) f7_store(frames_out + k * 7, f);
+        const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+        for (int t = t0; t < t1; t++) {
+            if (pb->tips[t].has_e) {
+                double e[7];
+                for (int c = 0; c < 7; c++) e[c] = pb->tips[t].e[c];
+                tip_fn(t, f7_concat(f, f7_load(e)));
+            } else {
+                tip_fn(t, f);
+            }
+        }
+    }
+}
+
+// primary fitness on the exact-FK phenotype (ik_base.h:203-207 semantics, per individual)
+BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, double* slots) {
+    double sum = 0.0;
+    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); });
+    sum += nonlink_primary(pb, x, qc);
+    return sum;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// linearised phenotype model (RobotFK_Mutator): tables in LDS
+//   tipbase [T][7] tip frames at the base configuration, delta [T][n_ops][7] per-(tip,op) first-order frames,
+//   base [n_ops] op values at the base configuration
+// ---------------------------------------------------------------------------------------------------------
+struct LinModel {
+    const double* tipbase;
+    const double* delta;
+    const double* base;
+};
+
+// forward_kinematics.h:1186-1231 (no renormalisation of the quaternion)
+BIOIK_DEV F7 linear_tip(ProbPtr pb, int t, const XV& x, const LinModel& lm) {
+    const int n_ops = pb->n_ops;
+    const double* tb = lm.tipbase + t * 7;
+    double px = tb[0], py = tb[1], pz = tb[2], rx = tb[3], ry = tb[4], rz = tb[5], rw = tb[6];
+    for (int k = 0; k < n_ops; k++)
+        if (pb->ops[k].gene >= 0) {
+            const double* d = lm.delta + ((size_t)t * n_ops + k) * 7;
+            double dv = x(k) - lm.base[k];
+            px += d[0] * dv;
+            py += d[1] * dv;
+            pz += d[2] * dv;
+            rx += d[3] * dv;
+            ry += d[4] * dv;
+            rz += d[5] * dv;
+            rw += d[6] * dv;
+        }
+    return F7{{px, py, pz}, {rx, ry, rz, rw}};
+}
+
+BIOIK_DEV double eval_linear_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, const LinModel& lm) {
+    double sum = 0.0;
+    const int T = pb->T;
+    for (int t = 0; t < T; t++) sum += tip_goals(pb, t, linear_tip(pb, t, x, lm), x, qc);
+    sum += nonlink_primary(pb, x, qc);
+    return sum;
+}
+
+// One (tip, op) entry of the approximator tables from the published joint frames:
+// tip-local Jacobian column (forward_kinematics.h:639-693) -> world delta frame (:827-852).
+BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames, const double* tips, double* out7) {
+    bool dep = ((pb->tips[t].dep_mask >> k) & 1u) != 0 && pb->ops[k].gene >= 0 && k < pb->n_chain_ops;
+    if (!dep) {
+        for (int c = 0; c < 7; c++) out7[c] = 0.0;
+        return;
+    }
+    F7 lf = f7_load(frames + k * 7);
+    F7 tf = f7_load(tips + t * 7);
+    V3 axis = v3(pb->ops[k].axis[0], pb->ops[k].axis[1], pb->ops[k].axis[2]);
+    // tf2 Quaternion product inverse(link.rot) * tip.rot, then inverse
+    Q4 a = qinv(lf.q), b = tf.q;
+    Q4 q = Q4{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+              a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+    q = qinv(q);
+    V3 rot = qrot(q, axis);
+    V3 vel, om;
+    if (pb->ops[k].type == BIOIK_OP_REVOLUTE) {
+        V3 d = qrot(qinv(tf.q), lf.p - tf.p);
+        vel = cross3(d, rot);
+        om = rot;
+    } else {
+        vel = rot;
+        om = v3(0.0, 0.0, 0.0);
+    }
+    V3 dp = qrot(tf.q, vel);
+    Q4 dq = qmul(tf.q, Q4{om.x * 0.5, om.y * 0.5, om.z * 0.5, 1.0});
+    out7[0] = dp.x;
+    out7[1] = dp.y;
+    out7[2] = dp.z;
+    out7[3] = dq.x - tf.q.x;
+    out7[4] = dq.y - tf.q.y;
+    out7[5] = dq.z - tf.q.z;
+    out7[6] = dq.w - tf.q.w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reproduction of ONE child (ik_evolution_2.cpp:263-300) with the counter RNG; bit-exact against the oracle.
+//   p0g / p0d / p1d: LDS, op-indexed genes of parent 0 and momentum ("gradients") of parents 0 and 1
+//   xo / go (stride xs / gs): where the child's genes / momentum go; go may be null
+// ---------------------------------------------------------------------------------------------------------
+BIOIK_DEV void reproduce_child(ProbPtr pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
+                               double* xo, int xs, double* go, int gs) {
+    BIOIK_FP_STRICT
+    const int n_ops = pb->n_ops;
+    uint32_t r0, r1;
+    philox2x32_10(key, rng_ctr0(child_index, RNG_SLOT_RATE), ctr1, r0, r1);
+    double mutation_rate = (double)(1u << (r0 & 15u)) * (1.0 / (double)(1 << 23));
+    double fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
+    double gradient_factor = (double)(child_index % 3u);
+    for (int k = 0; k < n_ops; k++) {
+        if (pb->ops[k].gene >= 0) {
+            philox2x32_10(key, rng_ctr0(child_index, (uint32_t)pb->ops[k].gene), ctr1, r0, r1);
+            double r = rng_gauss(r0, r1);
+            double f = mutation_rate * pb->ops[k].span;
+            double parent_gene = p0g[k];
+            double gene = parent_gene;
+            gene += r * f;
+            double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
+            double g = parent_gradient * gradient_factor;
+            gene += g;
+            gene = fmin(fmax(gene, pb->ops[k].clip_min), pb->ops[k].clip_max);
+            xo[(size_t)k * xs] = gene;
+            if (go) go[(size_t)k * gs] = parent_gradient * (1.0 - 0.3) + (gene - parent_gene) * 0.3;
+        } else {
+            xo[(size_t)k * xs] = p0g[k];  // inactive op: the seed's value, carried by every elite
+            if (go) go[(size_t)k * gs] = 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// success test of one tip / of the gene-only primary goals (problem.cpp:259-341)
+// ---------------------------------------------------------------------------------------------------------
+BIOIK_DEV void rot_from_quat(Q4 q, double* R) {  // KDL::Rotation::Quaternion
+    double x = q.x, y = q.y, z = q.z, w = q.w;
+    double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    R[0] = w2 + x2 - y2 - z2;
+    R[1] = 2 * x * y - 2 * w * z;
+    R[2] = 2 * x * z + 2 * w * y;
+    R[3] = 2 * x * y + 2 * w * z;
+    R[4] = w2 - x2 + y2 - z2;
+    R[5] = 2 * y * z - 2 * w * x;
+    R[6] = 2 * x * z - 2 * w * y;
+    R[7] = 2 * y * z + 2 * w * x;
+    R[8] = w2 - x2 - y2 + z2;
+}
+BIOIK_DEV V3 kdl_get_rot(const double* d) {  // KDL::Rotation::GetRot
+    const double epsilon = 1e-6, epsilon2 = 1e-5;
+    if ((fabs(d[1] - d[3]) < epsilon) && (fabs(d[2] - d[6]) < epsilon) && (fabs(d[5] - d[7]) < epsilon)) {
+        if ((fabs(d[1] + d[3]) < epsilon2) && (fabs(d[2] + d[6]) < epsilon2) && (fabs(d[5] + d[7]) < epsilon2) && (fabs(d[0] + d[4] + d[8] - 3) < epsilon2))
+            return v3(0.0, 0.0, 0.0);
+        double angle = BIOIK_PI;
+        double xx = (d[0] + 1) / 2, yy = (d[4] + 1) / 2, zz = (d[8] + 1) / 2;
+        double xy = (d[1] + d[3]) / 4, xz = (d[2] + d[6]) / 4, yz = (d[5] + d[7]) / 4;
+        double x, y, z;
+        if ((xx > yy) && (xx > zz)) {
+            x = sqrt(xx);
+            y = xy / x;
+            z = xz / x;
+        } else if (yy > zz) {
+            y = sqrt(yy);
+            x = xy / y;
+            z = yz / y;
+        } else {
+            z = sqrt(zz);
+            x = xz / z;
+            y = yz / z;
+        }
+        return v3(x * angle, y * angle, z * angle);
+    }
+    double f = (d[0] + d[4] + d[8] - 1) / 2;
+    double x = (d[7] - d[5]), y = (d[2] - d[6]), z = (d[3] - d[1]);
+    double n = sqrt(x * x + y * y + z * z);
+    double angle = atan2(n / 2, f);
+    return v3(x / n * angle, y / n * angle, z / n * angle);
+}
+// Twist(Ma^-1 * diff(pa,pb), Ma^-1 * diff(Ma,Mb)) of problem.cpp:281/300/321
+BIOIK_DEV void pose_twist(const F7& fa, const F7& fb, double* t6) {
+    double A[9], B[9], R[9];
+    rot_from_quat(fa.q, A);
+    rot_from_quat(fb.q, B);
+    double dx = fb.p.x - fa.p.x, dy = fb.p.y - fa.p.y, dz = fb.p.z - fa.p.z;
+    t6[0] = A[0] * dx + A[3] * dy + A[6] * dz;
+    t6[1] = A[1] * dx + A[4] * dy + A[7] * dz;
+    t6[2] = A[2] * dx + A[5] * dy + A[8] * dz;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = A[0 * 3 + i] * B[0 * 3 + j] + A[1 * 3 + i] * B[1 * 3 + j] + A[2 * 3 + i] * B[2 * 3 + j];
+    V3 rv = kdl_get_rot(R);
+    V3 w = v3(A[0] * rv.x + A[1] * rv.y + A[2] * rv.z, A[3] * rv.x + A[4] * rv.y + A[5] * rv.z, A[6] * rv.x + A[7] * rv.y + A[8] * rv.z);
+    t6[3] = A[0] * w.x + A[3] * w.y + A[6] * w.z;
+    t6[4] = A[1] * w.x + A[4] * w.y + A[7] * w.z;
+    t6[5] = A[2] * w.x + A[5] * w.y + A[8] * w.z;
+}
+BIOIK_DEV double angle_shortest_path(Q4 a, Q4 b) {  // tf2::Quaternion::angleShortestPath
+    double s = sqrt(qdot(a, a) * qdot(b, b));
+    double d = qdot(a, b);
+    if (d < 0) return clamped_acos(-d / s) * 2.0;
+    return clamped_acos(d / s) * 2.0;
+}
+
+BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const QueryCtx& qc, double dpos, double drot, double dtwist) {
+    const int type = pb->primary[g].type;
+    const double* P = qc.par + pb->primary[g].param_off;
+    bool ok = true;
+    if (type == G_POSITION) {
+        F7 fa = f7_identity();
+        fa.p = v3(P[0], P[1], P[2]);
+        if (dpos != BIOIK_DBL_MAX) ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 0; k < 3; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    } else if (type == G_ORIENTATION) {
+        F7 fa = f7_identity();
+        fa.q = Q4{P[0], P[1], P[2], P[3]};
+        if (drot != BIOIK_DBL_MAX) ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 3; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    } else if (type == G_POSE) {
+        F7 fa = F7{{P[0], P[1], P[2]}, {P[3], P[4], P[5], P[6]}};
+        if (dpos != BIOIK_DBL_MAX || drot != BIOIK_DBL_MAX) {
+            ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
+            ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
+        }
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 0; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    } else {
+        double dmax = fmin(BIOIK_DBL_MAX, fmin(dpos, dtwist));
+        double d = goal_eval(pb, type, pb->primary[g].var_op, pb->primary[g].var_seed, P, fb, x, qc) * pb->primary[g].weight_sq;
+        ok = ok && (d < dmax * dmax);
+    }
+    return ok;
+}
+
+// exact FK of one individual + primary fitness, optionally with Problem::checkSolutionActiveVariables
+// (ik_base.h:203-207, ik_parallel.h:173-181).  It serves the once-per-step call sites (initial fitness, species
+// ranking, wipe-out, success test).
+// (kept inline: ROCm 7.2's gfx950 backend rejects the generic-pointer aperture test it emits for LDS pointers that
+// cross a real call boundary — "V_CMP_NE_U32 0, $src_shared_base: Operand has incorrect register class")
+#define BIOIK_NOINLINE BIOIK_DEV
+struct FitCheck {
+    double fitness;
+    int ok;
+};
+BIOIK_NOINLINE FitCheck exact_fitness_check(ProbPtr pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check) {
+    bool good = true;
+    double sum = 0.0;
+    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
+        sum += tip_goals(pb, t, f, x, qc);
+        if (do_check) {
+            const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
+            for (int g = g0; g < g1; g++) good = check_goal(pb, g, f, x, qc, dpos, drot, dtwist) && good;
+        }
+    });
+    sum += nonlink_primary(pb, x, qc);
+    if (do_check) {
+        const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        for (int g = pb->n_link_primary; g < pb->n_primary; g++) good = check_goal(pb, g, zero, x, qc, dpos, drot, dtwist) && good;
+    }
+    return FitCheck{sum, good ? 1 : 0};
+}

@@ -1,0 +1,505 @@
+// bioik_hip.hip — the C-ABI of include/bioik_hip.h: __global__ entry points for gfx950 and the thin host shim
+// that owns device memory and launches them.  No torch, no C++ types across the boundary.
+//
+// The same file builds the test-only host simulator (tests/hostsim, -DBIOIK_HOSTSIM): there "device memory" is
+// host memory and a launch runs every workgroup as a gang of OS threads.  The product library is always built by
+// hipcc for gfx950 and refuses to do anything without a HIP device.
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bioik_compile.h"
+#include "bioik_kernels.h"
+
+static_assert((int)G_POSITION == (int)BIOIK_GOAL_POSITION && (int)G_POSE == (int)BIOIK_GOAL_POSE && (int)G_CONE == (int)BIOIK_GOAL_CONE &&
+                  (int)G_JOINT_VARIABLE == (int)BIOIK_GOAL_JOINT_VARIABLE && (int)G_MINIMAL_DISPLACEMENT == (int)BIOIK_GOAL_MINIMAL_DISPLACEMENT &&
+                  (int)G_AVOID_JOINT_LIMITS == (int)BIOIK_GOAL_AVOID_JOINT_LIMITS,
+              "goal opcodes out of sync with include/bioik_hip.h");
+static_assert((int)FK_LINEAR == (int)BIOIK_FK_LINEAR && (int)FK_EXACT == (int)BIOIK_FK_EXACT, "fk modes out of sync");
+
+using bioik::Error;
+
+static thread_local std::string g_err;
+
+// ------------------------------------------------------------------------------------------------------------
+// back end: memory + launch
+// ------------------------------------------------------------------------------------------------------------
+#if defined(BIOIK_HOSTSIM)
+namespace sim {
+thread_local Block* blk = nullptr;
+thread_local int tid = 0;
+}  // namespace sim
+typedef void* stream_t;
+static int be_device_count() { return 1; }
+static void be_set_device(int) {}
+static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+static void be_free(void* p) { std::free(p); }
+static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
+static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
+static void be_sync(stream_t) {}
+template <class Body>
+static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body body) {
+    std::vector<double> lds(lds_bytes / 8 + 2);
+    for (uint64_t b = 0; b < grid; b++) {
+        sim::Block blk;
+        blk.nthreads = block;
+        blk.block_id = (int)b;
+        blk.bar.reset(new std::barrier<>(block));
+        for (int w = 0; w < block / 64; w++) blk.wave_bar.emplace_back(new std::barrier<>(64));
+        blk.xchg.assign((size_t)block, 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < block; t++)
+            th.emplace_back([&, t]() {
+                sim::blk = &blk;
+                sim::tid = t;
+                body(b, lds.data());
+            });
+        for (auto& t : th) t.join();
+    }
+}
+#else
+typedef hipStream_t stream_t;
+#define HIP_CHECK(expr)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) throw Error(BIOIK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+static int be_device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+static void be_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
+static void* be_alloc(size_t bytes) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+    return p;
+}
+static void be_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+static void be_h2d(void* d, const void* h, size_t bytes, stream_t s) {
+    if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+}
+static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
+    if (bytes) HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
+}
+static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
+
+__global__ void __launch_bounds__(256) k_solve(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body(a, blockIdx.x, lds);
+}
+__global__ void k_select(SelectArgs a) { select_body(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ void __launch_bounds__(256) k_eval_fk(EvalArgs a) {
+    extern __shared__ double lds[];
+    eval_fk_body(a, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(256) k_eval_fitness(EvalArgs a) {
+    extern __shared__ double lds[];
+    eval_fitness_body(a, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(256) k_eval_approximator(EvalArgs a) {
+    extern __shared__ double lds[];
+    eval_approximator_body(a, lds);
+}
+__global__ void __launch_bounds__(256) k_eval_reproduce(EvalArgs a) {
+    extern __shared__ double lds[];
+    eval_reproduce_body(a, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(256) k_eval_check(EvalArgs a) {
+    extern __shared__ double lds[];
+    eval_check_body(a, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(256) k_stream_fitness(StreamArgs a) {
+    extern __shared__ double lds[];
+    stream_fitness_body(a, blockIdx.x, lds);
+}
+#endif
+
+// one launch macro for both back ends: BODYCALL is the kernel body as a function of (b_, l_) = (block index, LDS base)
+#if defined(BIOIK_HOSTSIM)
+#define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args) be_launch(grid, block, lds, stream, [&](uint64_t b_, double* l_) { BODYCALL; })
+#else
+#define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args)                                      \
+    do {                                                                                              \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)(grid)), dim3(block), lds, stream, args);           \
+        HIP_CHECK(hipGetLastError());                                                                 \
+    } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------------------
+struct bioik_model {
+    bioik::HostModel host;
+    int device;
+    bioik_model(const bioik_model_desc& d, int dev) : host(d), device(dev) {}
+};
+struct bioik_problem {
+    bioik_model* model;
+    bioik::HostProblem host;
+    DevProblem* d_pb = nullptr;
+    // grow-only device workspace for the island results of solve_batch_device
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    uint64_t first_query = 0;
+    std::mutex mtx;
+    bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
+    ProbPtr pb() const { return (ProbPtr)d_pb; }
+};
+
+static int fail(const Error& e) {
+    g_err = e.what();
+    return e.code;
+}
+static int fail(const std::exception& e) {
+    g_err = e.what();
+    return BIOIK_ERR_INVALID_ARGUMENT;
+}
+#define API_BEGIN try {
+#define API_END                      \
+    return BIOIK_OK;                 \
+    }                                \
+    catch (const Error& e) {         \
+        return fail(e);              \
+    }                                \
+    catch (const std::exception& e) { \
+        return fail(e);              \
+    }
+
+static int solve_threads(const DevSolveParams& sp, uint64_t units) {
+    int t = 64;
+    if (const char* e = std::getenv("BIOIK_SOLVE_THREADS")) {
+        t = std::atoi(e);
+    } else if (units < 1024) {
+        // few queries: spread one query's children over up to 4 wavefronts
+        while (t < sp.lambda && t < 256) t *= 2;
+    }
+    if (t < 64) t = 64;
+    t = (t + 63) / 64 * 64;
+    if (t > 256) t = 256;
+    return t;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) : p(be_alloc(bytes)) {}
+    ~DevBuf() { be_free(p); }
+    DevBuf(const DevBuf&) = delete;
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda) {
+    const DevProblem& d = p->host.dev;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0).total * 8;
+}
+
+static void launch_solve(bioik_problem* p, const DevSolveParams& sp, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
+                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream) {
+    if (n == 0) return;
+    const DevProblem& dp = p->host.dev;
+    if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
+    const uint64_t units = (uint64_t)n * sp.islands;
+    const int nth = solve_threads(sp, units);
+    const size_t lds = lds_bytes(p, nth, sp.lambda);
+    if (lds > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 64 KiB of LDS per workgroup");
+    SolveArgs a;
+    a.pb = p->pb();
+    a.sp = sp;
+    a.seeds = d_seeds;
+    a.params = d_params;
+    if (sp.islands == 1) {
+        a.solutions = d_solutions, a.fitness = d_fitness, a.success = d_success, a.steps = d_steps;
+    } else {
+        size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
+        size_t need = units * per + 64;
+        if (p->ws_bytes < need) {
+            be_free(p->ws);
+            p->ws = nullptr, p->ws_bytes = 0;
+            p->ws = be_alloc(need);
+            p->ws_bytes = need;
+        }
+        char* w = (char*)p->ws;
+        a.solutions = (double*)w, w += units * dp.V * 8;
+        a.fitness = (double*)w, w += units * 8;
+        a.success = (int32_t*)w, w += units * 4;
+        a.steps = (int32_t*)w;
+    }
+    LAUNCH(k_solve, solve_body(a, b_, l_), units, nth, lds, stream, a);
+    if (sp.islands > 1) {
+        SelectArgs s;
+        s.islands = sp.islands, s.V = dp.V, s.n = n;
+        s.isl_solutions = a.solutions, s.isl_fitness = a.fitness, s.isl_success = a.success, s.isl_steps = a.steps;
+        s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
+#if defined(BIOIK_HOSTSIM)
+        for (uint64_t q = 0; q < n; q++) select_body(s, q);
+#else
+        hipLaunchKernelGGL(k_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s);
+        HIP_CHECK(hipGetLastError());
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* bioik_last_error(void) { return g_err.c_str(); }
+int bioik_abi_version(void) { return BIOIK_ABI_VERSION; }
+int bioik_device_count(void) { return be_device_count(); }
+int bioik_goal_param_count(int goal_type) { return bioik::goal_param_count(goal_type); }
+
+void bioik_default_solve_params(bioik_solve_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(*p);
+    p->mode = BIOIK_MODE_BIO2_MEMETIC;
+    p->fk_mode = BIOIK_FK_EXACT;
+    p->population = 128;
+    p->islands = 1;
+    p->max_steps = 64;
+    p->random_seed = 0;
+    p->dpos = -1.0;
+    p->drot = -1.0;
+    p->dtwist = 1e-5;
+    p->no_wipeout = 0;
+}
+
+int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out) {
+    API_BEGIN
+    if (!desc || !out) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int n = be_device_count();
+    if (n <= 0) throw Error(BIOIK_ERR_NO_DEVICE, "no HIP device available: this solver has no CPU path");
+    if (device < 0 || device >= n) throw Error(BIOIK_ERR_NO_DEVICE, "HIP device index out of range");
+    *out = new bioik_model(*desc, device);
+    API_END
+}
+void bioik_model_destroy(bioik_model* m) { delete m; }
+
+int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bioik_problem** out) {
+    API_BEGIN
+    if (!model || !desc || !out) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    std::unique_ptr<bioik_problem> p(new bioik_problem(model, *desc));
+    be_set_device(model->device);
+    p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
+    be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
+    be_sync(0);
+    *out = p.release();
+    API_END
+}
+void bioik_problem_destroy(bioik_problem* p) {
+    if (!p) return;
+    be_free(p->d_pb);
+    be_free(p->ws);
+    delete p;
+}
+
+int bioik_problem_active_variable_count(const bioik_problem* p) { return p ? p->host.dev.D : BIOIK_ERR_INVALID_ARGUMENT; }
+int bioik_problem_active_variables(const bioik_problem* p, int32_t* out) {
+    if (!p || !out) return BIOIK_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < p->host.active_variables.size(); i++) out[i] = p->host.active_variables[i];
+    return BIOIK_OK;
+}
+int bioik_problem_tip_count(const bioik_problem* p) { return p ? p->host.dev.T : BIOIK_ERR_INVALID_ARGUMENT; }
+int bioik_problem_tip_links(const bioik_problem* p, int32_t* out) {
+    if (!p || !out) return BIOIK_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < p->host.tip_links.size(); i++) out[i] = p->host.tip_links[i];
+    return BIOIK_OK;
+}
+int bioik_problem_param_count(const bioik_problem* p) { return p ? p->host.dev.P : BIOIK_ERR_INVALID_ARGUMENT; }
+int bioik_problem_variable_count(const bioik_problem* p) { return p ? p->host.dev.V : BIOIK_ERR_INVALID_ARGUMENT; }
+int bioik_problem_set_first_query(bioik_problem* p, uint64_t first_query) {
+    if (!p) return BIOIK_ERR_INVALID_ARGUMENT;
+    p->first_query = first_query;
+    return BIOIK_OK;
+}
+
+int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds, const double* d_goal_params,
+                             double* d_solutions, double* d_fitness, int32_t* d_success, int32_t* d_steps, void* hip_stream) {
+    API_BEGIN
+    if (!p || !params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n && (!d_seeds || !d_solutions || !d_fitness || !d_success || !d_steps || (p->host.dev.P > 0 && !d_goal_params)))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
+    launch_solve(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream);
+    API_END
+}
+
+int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
+                      double* fitness, int32_t* success, int32_t* steps) {
+    API_BEGIN
+    if (!p || !params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n && (!seeds || !solutions || !fitness || !success || !steps || (p->host.dev.P > 0 && !goal_params)))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    if (n == 0) return BIOIK_OK;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const size_t V = p->host.dev.V, P = p->host.dev.P;
+    DevBuf ds(n * V * 8), dg(n * P * 8), dsol(n * V * 8), df(n * 8), dsu(n * 4), dst(n * 4);
+    be_h2d(ds.p, seeds, n * V * 8, 0);
+    be_h2d(dg.p, goal_params, n * P * 8, 0);
+    DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
+    launch_solve(p, sp, n, ds.as<double>(), dg.as<double>(), dsol.as<double>(), df.as<double>(), dsu.as<int32_t>(), dst.as<int32_t>(), 0);
+    be_d2h(solutions, dsol.p, n * V * 8, 0);
+    be_d2h(fitness, df.p, n * 8, 0);
+    be_d2h(success, dsu.p, n * 4, 0);
+    be_d2h(steps, dst.p, n * 4, 0);
+    be_sync(0);
+    API_END
+}
+
+// ---- function-level entry points -------------------------------------------------------------------------
+static EvalArgs eval_args(bioik_problem* p) {
+    EvalArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.pb = p->pb();
+    a.dpos = a.drot = a.dtwist = DBL_MAX;
+    return a;
+}
+
+int bioik_eval_fk(bioik_problem* p, size_t n, const double* seed, const double* genes, double* tip_frames) {
+    API_BEGIN
+    if (!p || !seed || (n && (!genes || !tip_frames))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return BIOIK_OK;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const size_t V = p->host.dev.V, D = p->host.dev.D, T = p->host.dev.T;
+    DevBuf dseed(V * 8), dgenes(n * D * 8), dout(n * T * 7 * 8);
+    be_h2d(dseed.p, seed, V * 8, 0);
+    be_h2d(dgenes.p, genes, n * D * 8, 0);
+    EvalArgs a = eval_args(p);
+    a.n = n, a.seed = dseed.as<double>(), a.genes = dgenes.as<double>(), a.out0 = dout.as<double>();
+    const int nth = 64;
+    LAUNCH(k_eval_fk, eval_fk_body(a, b_, l_), (n + nth - 1) / nth, nth, lds_bytes(p, nth, 0), 0, a);
+    be_d2h(tip_frames, dout.p, n * T * 7 * 8, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_eval_fitness(bioik_problem* p, int fk_mode, size_t n, const double* seed, const double* goal_params, const double* base_genes, const double* genes,
+                       double* primary, double* secondary) {
+    API_BEGIN
+    if (!p || !seed || (n && (!genes || !primary || !secondary))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (fk_mode != BIOIK_FK_LINEAR && fk_mode != BIOIK_FK_EXACT) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown fk_mode");
+    if (fk_mode == BIOIK_FK_LINEAR && !base_genes) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "base_genes required for the linear model");
+    if (p->host.dev.P > 0 && !goal_params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "goal_params required");
+    if (n == 0) return BIOIK_OK;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const size_t V = p->host.dev.V, D = p->host.dev.D, P = p->host.dev.P;
+    DevBuf dseed(V * 8), dpar(P * 8), dbase(D * 8), dgenes(n * D * 8), d0(n * 8), d1(n * 8);
+    be_h2d(dseed.p, seed, V * 8, 0);
+    be_h2d(dpar.p, goal_params, P * 8, 0);
+    if (base_genes) be_h2d(dbase.p, base_genes, D * 8, 0);
+    be_h2d(dgenes.p, genes, n * D * 8, 0);
+    EvalArgs a = eval_args(p);
+    a.n = n, a.seed = dseed.as<double>(), a.params = dpar.as<double>(), a.genes = dgenes.as<double>(), a.base = dbase.as<double>();
+    a.out0 = d0.as<double>(), a.out1 = d1.as<double>(), a.fk_mode = fk_mode;
+    const int nth = 64;
+    LAUNCH(k_eval_fitness, eval_fitness_body(a, b_, l_), (n + nth - 1) / nth, nth, lds_bytes(p, nth, 0), 0, a);
+    be_d2h(primary, d0.p, n * 8, 0);
+    be_d2h(secondary, d1.p, n * 8, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_eval_approximator(bioik_problem* p, const double* seed, const double* base_genes, double* tip_frames, double* deltas) {
+    API_BEGIN
+    if (!p || !seed || !base_genes || !tip_frames || !deltas) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const size_t V = p->host.dev.V, D = p->host.dev.D, T = p->host.dev.T;
+    DevBuf dseed(V * 8), dbase(D * 8), d0(T * 7 * 8), d1(T * D * 7 * 8);
+    be_h2d(dseed.p, seed, V * 8, 0);
+    be_h2d(dbase.p, base_genes, D * 8, 0);
+    EvalArgs a = eval_args(p);
+    a.n = 1, a.seed = dseed.as<double>(), a.base = dbase.as<double>(), a.out0 = d0.as<double>(), a.out1 = d1.as<double>();
+    const int nth = 64;
+    LAUNCH(k_eval_approximator, eval_approximator_body(a, l_), 1, nth, lds_bytes(p, nth, 0), 0, a);
+    be_d2h(tip_frames, d0.p, T * 7 * 8, 0);
+    be_d2h(deltas, d1.p, T * D * 7 * 8, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_eval_reproduce(bioik_problem* p, int population, uint32_t rng_key, int species, uint32_t generation, const double* parents, double* children_genes,
+                         double* children_gradients) {
+    API_BEGIN
+    if (!p || !parents || !children_genes || !children_gradients || population <= 0) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const size_t D = p->host.dev.D, n = (size_t)population;
+    DevBuf dpar(4 * D * 8), d0(n * D * 8), d1(n * D * 8);
+    be_h2d(dpar.p, parents, 4 * D * 8, 0);
+    EvalArgs a = eval_args(p);
+    a.n = n, a.genes = dpar.as<double>(), a.out0 = d0.as<double>(), a.out1 = d1.as<double>();
+    a.rng_key = rng_key;
+    a.rng_ctr1 = (generation << 4) | ((uint32_t)species << 3) | 0u;
+    const int nth = 64;
+    const size_t M = p->host.dev.n_ops > 0 ? p->host.dev.n_ops : 1;
+    LAUNCH(k_eval_reproduce, eval_reproduce_body(a, b_, l_), (n + nth - 1) / nth, nth, (4 * M + 2 * M * nth) * 8, 0, a);
+    be_d2h(children_genes, d0.p, n * D * 8, 0);
+    be_d2h(children_gradients, d1.p, n * D * 8, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seed, const double* goal_params, const double* genes,
+                     int32_t* ok) {
+    API_BEGIN
+    if (!p || !params || !seed || (n && (!genes || !ok))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->host.dev.P > 0 && !goal_params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "goal_params required");
+    if (n == 0) return BIOIK_OK;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    DevSolveParams sp = bioik::normalize_params(*params, 0);
+    const size_t V = p->host.dev.V, D = p->host.dev.D, P = p->host.dev.P;
+    DevBuf dseed(V * 8), dpar(P * 8), dgenes(n * D * 8), dok(n * 4);
+    be_h2d(dseed.p, seed, V * 8, 0);
+    be_h2d(dpar.p, goal_params, P * 8, 0);
+    be_h2d(dgenes.p, genes, n * D * 8, 0);
+    EvalArgs a = eval_args(p);
+    a.n = n, a.seed = dseed.as<double>(), a.params = dpar.as<double>(), a.genes = dgenes.as<double>(), a.outi = dok.as<int32_t>();
+    a.dpos = sp.dpos, a.drot = sp.drot, a.dtwist = sp.dtwist;
+    const int nth = 64;
+    LAUNCH(k_eval_check, eval_check_body(a, b_, l_), (n + nth - 1) / nth, nth, lds_bytes(p, nth, 0), 0, a);
+    be_d2h(ok, dok.p, n * 4, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_stream_fitness_device(bioik_problem* p, size_t n_units, int population, const double* d_seeds, const double* d_goal_params, const double* d_genes,
+                                double* d_fitness, void* hip_stream) {
+    API_BEGIN
+    if (!p || population <= 0) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n_units && (!d_seeds || !d_genes || !d_fitness || (p->host.dev.P > 0 && !d_goal_params))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    if (n_units == 0) return BIOIK_OK;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    be_set_device(p->model->device);
+    const int nth = population >= 256 ? 256 : (population + 63) / 64 * 64;
+    StreamArgs a;
+    a.pb = p->pb();
+    a.n_units = n_units;
+    a.population = population;
+    a.blocks_per_unit = (population + nth - 1) / nth;
+    a.seeds = d_seeds, a.params = d_goal_params, a.genes = d_genes, a.fitness = d_fitness;
+    uint64_t grid = (uint64_t)n_units * a.blocks_per_unit;
+    if (grid > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many units for one launch");
+    LAUNCH(k_stream_fitness, stream_fitness_body(a, b_, l_), grid, nth, lds_bytes(p, nth, 0), (stream_t)hip_stream, a);
+    API_END
+}
+
+}  // extern "C"

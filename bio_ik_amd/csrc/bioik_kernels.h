@@ -1,0 +1,591 @@
+// bioik_kernels.h — workgroup-level bodies of the gfx950 kernels.
+//
+// Mapping: one workgroup owns one (query, island).  Its lanes are the individuals of the current
+// generation: lane r reproduces child r (and r + nthreads, ...) from the two elites held in LDS into its own column
+// of the [op][lane] genotype array in LDS, walks the joint program for it (exact FK) or evaluates the linearised
+// model, and the elitist top-2 selection is a wave64 butterfly of (fitness, position) pairs (+ one LDS hop across
+// waves).  Winners are re-derived from the counter RNG instead of being stored.  The memetic phase spreads its D
+// finite differences and the two support points of the line search over lanes.  Everything of a query (seed, goal
+// parameters, elites, genotype columns, linear model, per-joint frame chain) lives in LDS; HBM sees the query once
+// on the way in and the result once on the way out.
+//
+// Reference behaviour restated here: src/ik_evolution_2.cpp:111-230 (initialize), :328-646 (step),
+// src/ik_parallel.h:148-190 (island loop, budget form), :220-269 (best island).
+#pragma once
+#include "bioik_device.h"
+
+#if defined(BIOIK_HOSTSIM)
+#define BIOIK_HD inline
+#else
+#define BIOIK_HD __host__ __device__ inline
+#endif
+
+struct LdsLayout {  // offsets in doubles
+    int seed, par, pop, sol, xn, gv, frames, tips, delta, base, grad, xcol, slots, red, sec, order, total;
+};
+BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary) {
+    LdsLayout L;
+    const int m = n_ops > 0 ? n_ops : 1;
+    int o = 0;
+    L.seed = o, o += V;
+    L.par = o, o += P > 0 ? P : 1;
+    L.pop = o, o += 2 * 2 * 2 * 2 * m;  // [species][buffer][individual][genes|momentum][op]
+    L.sol = o, o += m;
+    L.xn = o, o += m;
+    L.gv = o, o += m;
+    L.frames = o, o += m * 7;
+    L.tips = o, o += T * 7;
+    L.delta = o, o += T * m * 7;
+    L.base = o, o += m;
+    L.grad = o, o += m;
+    L.xcol = o, o += m * nthreads;  // genotype columns: [op][lane]
+    L.slots = o, o += n_slots * 7 * nthreads;
+    L.red = o, o += 2 * (nthreads / 64) + 2;
+    L.sec = o, o += has_secondary ? lambda : 0;
+    L.order = o, o += has_secondary ? (lambda + 1) / 2 : 0;
+    L.total = o;
+    return L;
+}
+
+struct Cand {
+    double f;
+    int pos;  // position in the reference's child_indices order (ties go to the lower position)
+    int id;   // 0/1 = parent, >=2 = evaluated child at sorted position id-2
+};
+BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f < of) || (f == of && pos < opos); }
+
+// all-lanes arg-min of (f,pos) over the workgroup: wave64 xor-butterfly, then one LDS hop across waves
+BIOIK_DEV void argmin_reduce(double& f, int& pos, double* s_red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double of = p_shfl_xor(f, m);
+        int op = p_shfl_xor(pos, m);
+        if (cand_better(of, op, f, pos)) f = of, pos = op;
+    }
+    const int nw = p_nthreads() >> 6;
+    if (nw > 1) {
+        const int tid = p_tid();
+        if ((tid & 63) == 0) {
+            s_red[2 * (tid >> 6)] = f;
+            s_red[2 * (tid >> 6) + 1] = (double)pos;
+        }
+        p_barrier();
+        for (int w = 0; w < nw; w++) {
+            double of = s_red[2 * w];
+            int op = (int)s_red[2 * w + 1];
+            if (cand_better(of, op, f, pos)) f = of, pos = op;
+        }
+        p_barrier();
+    }
+}
+
+// RobotFK::applyConfiguration + initializeMutationApproximator at the (workgroup-shared) individual x:
+// the joint frames are published to LDS by lane 0 (the per-joint frame chain), then lanes fan out over (tip, op).
+BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base) {
+    const int tid = p_tid(), nth = p_nthreads();
+    const int n_ops = pb->n_ops, T = pb->T;
+    fk_walk(pb, x, slots, s_frames, [&](int t, const F7& f) {
+        if (tid == 0) f7_store(s_tips + t * 7, f);
+    });
+    for (int k = tid; k < n_ops; k += nth) s_base[k] = x(k);
+    p_barrier();
+    for (int idx = tid; idx < T * n_ops; idx += nth) {
+        int t = idx / n_ops, k = idx - t * n_ops;
+        double o[7];
+        approximator_entry(pb, t, k, s_frames, s_tips, o);
+        double* d = s_delta + ((size_t)t * n_ops + k) * 7;
+        for (int c = 0; c < 7; c++) d[c] = o[c];
+    }
+    p_barrier();
+}
+
+struct SolveArgs {
+    ProbPtr pb;
+    DevSolveParams sp;
+    const double* seeds;    // [n][V]
+    const double* params;   // [n][P]
+    double* solutions;      // [n*islands][V]
+    double* fitness;        // [n*islands]   ranking fitness of ik_parallel.h:229-246
+    int32_t* success;       // [n*islands]
+    int32_t* steps;         // [n*islands]
+};
+
+struct SpeciesState {
+    double fit;       // Species::fitness (exact FK, primary)
+    double pf0, pf1;  // fitness of the two elites under the evaluation currently in use
+    int id;           // persistent id (RNG stream)
+    int slot;         // LDS slot of the species' elites
+    int cur;          // which of the two LDS buffers holds the elites
+    int improved;
+};
+
+BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
+    ProbPtr pb = a.pb;
+    const DevSolveParams& sp = a.sp;
+    const int tid = p_tid(), nth = p_nthreads(), lane = tid & 63;
+    const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
+    const int lambda = sp.lambda;
+    const bool has_sec = pb->n_secondary > 0;
+    const bool exact = sp.fk_mode == FK_EXACT;
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec);
+    double* s_seed = lds + L.seed;
+    double* s_par = lds + L.par;
+    double* s_pop = lds + L.pop;
+    double* s_sol = lds + L.sol;
+    double* s_xn = lds + L.xn;
+    double* s_gv = lds + L.gv;
+    double* s_frames = lds + L.frames;
+    double* s_tips = lds + L.tips;
+    double* s_delta = lds + L.delta;
+    double* s_base = lds + L.base;
+    double* s_grad = lds + L.grad;
+    double* s_slots = lds + L.slots;
+    double* s_red = lds + L.red;
+    double* s_sec = lds + L.sec;
+    int32_t* s_order = (int32_t*)(lds + L.order);
+    double* xcol = lds + L.xcol + tid;  // this lane's genotype column, stride nth
+    const XV xl{xcol, nth};
+    const int M = n_ops > 0 ? n_ops : 1;
+    const int SP = 2 * 2 * 2 * M;  // doubles per species in s_pop
+    const int BF = 4 * M;          // doubles per buffer: [ind0 genes][ind0 momentum][ind1 genes][ind1 momentum]
+
+    const uint64_t q = unit / (uint64_t)sp.islands;
+    const uint32_t island = (uint32_t)(unit % (uint64_t)sp.islands);
+    for (int i = tid; i < V; i += nth) s_seed[i] = a.seeds[q * V + i];
+    for (int i = tid; i < P; i += nth) s_par[i] = a.params[q * P + i];
+    p_barrier();
+    const QueryCtx qc{s_seed, s_par};
+    const LinModel lm{s_tips, s_delta, s_base};
+    const uint32_t key = rng_query_key(sp.random_seed, sp.first_query + q, island);
+
+    // ik_evolution_2.cpp:129-179: solution = seed, 2 species x 2 clones of the seed, zero momentum.
+    // Inactive ops carry the seed's value in every vector, so the chain walk never distinguishes them.
+    for (int k = tid; k < n_ops; k += nth) {
+        double v = s_seed[pb->ops[k].var];
+        for (int s = 0; s < 2; s++)
+            for (int i = 0; i < 2; i++) {
+                double* d = s_pop + s * SP + i * 2 * M;
+                d[k] = v, d[M + k] = 0.0;
+            }
+        s_sol[k] = v;
+    }
+    p_barrier();
+    double sol_fit = exact_fitness_check(pb, XV{s_sol, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
+    SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0};
+
+    int steps = 0;
+    bool success = false;
+    double final_fit = BIOIK_DBL_MAX;
+    for (int step = 0; step < sp.max_steps; step++) {
+        for (int rank = 0; rank < 2; rank++) {
+            SpeciesState S = rank == 0 ? A : B;
+            double* popS = s_pop + S.slot * SP;
+            if (!exact) {
+                // :341-346 linearise at the elite; both elites are re-scored under the new linear model
+                const double* cb = popS + S.cur * BF;
+                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base);
+                S.pf0 = eval_linear_primary(pb, XV{cb, 1}, qc, lm);
+                S.pf1 = eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm);
+            }
+            for (int gen = 0; gen < sp.generations; gen++) {
+                const double* cb = popS + S.cur * BF;
+                const double *p0g = cb, *p0d = cb + M, *p1d = cb + 3 * M;
+                const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
+                const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
+                int n_eval = lambda;
+                if (has_sec) {
+                    // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
+                    for (int c = tid; c < lambda; c += nth) {
+                        reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
+                        s_sec[c] = secondary_fitness(pb, xl, qc);
+                    }
+                    p_barrier();
+                    for (int c = tid; c < lambda; c += nth) {
+                        double my = s_sec[c];
+                        int r = 0;
+                        for (int j = 0; j < lambda; j++) {
+                            double o = s_sec[j];
+                            r += ((o < my) || (o == my && j < c)) ? 1 : 0;
+                        }
+                        s_order[r] = c;
+                    }
+                    p_barrier();
+                    uint32_t o0, o1;
+                    philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
+                    n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
+                }
+                // genotype -> phenotype -> fitness (:391-407): lane r scores the child at sorted position r
+                double b1f = P_INF, b2f = P_INF;
+                int b1p = 0x7fffffff, b2p = 0x7fffffff;
+                for (int r = tid; r < n_eval; r += nth) {
+                    int c = has_sec ? s_order[r] : r;
+                    reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
+                    double f = exact ? eval_exact_primary(pb, xl, qc, s_slots) : eval_linear_primary(pb, xl, qc, lm);
+                    int pos = r + 2;
+                    if (cand_better(f, pos, b1f, b1p)) {
+                        b2f = b1f, b2p = b1p;
+                        b1f = f, b1p = pos;
+                    } else if (cand_better(f, pos, b2f, b2p)) {
+                        b2f = f, b2p = pos;
+                    }
+                }
+                // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
+                double cf = b1f;
+                int cp = b1p;
+                argmin_reduce(cf, cp, s_red);
+                Cand first{S.pf0, 0, 0};
+                if (cand_better(S.pf1, 1, first.f, first.pos)) first = Cand{S.pf1, 1, 1};
+                if (cand_better(cf, cp, first.f, first.pos)) first = Cand{cf, cp, cp};
+                double c2f = (b1p == first.id) ? b2f : b1f;
+                int c2p = (b1p == first.id) ? b2p : b1p;
+                argmin_reduce(c2f, c2p, s_red);
+                Cand second{P_INF, 0x7fffffff, -1};
+                if (first.id != 0) second = Cand{S.pf0, first.pos, 0};  // parent 0 was swapped to the winner's position
+                if (first.id != 1 && (second.id < 0 || cand_better(S.pf1, 1, second.f, second.pos))) second = Cand{S.pf1, 1, 1};
+                if (second.id < 0 || cand_better(c2f, c2p, second.f, second.pos)) second = Cand{c2f, c2p, c2p};
+                // the winners become the elites; a winning child is re-derived from the RNG by lane 0, not fetched
+                double* nb = popS + (S.cur ^ 1) * BF;
+                for (int i = 0; i < 2; i++) {
+                    const int id = i == 0 ? first.id : second.id;
+                    double* dst = nb + i * 2 * M;
+                    if (id < 2) {
+                        const double* src = cb + id * 2 * M;
+                        for (int k = tid; k < 2 * M; k += nth) dst[k] = src[k];
+                    } else if (tid == 0) {
+                        int c = has_sec ? s_order[id - 2] : id - 2;
+                        reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, dst, 1, dst + M, 1);
+                    }
+                }
+                S.cur ^= 1;
+                S.pf0 = first.f;
+                S.pf1 = second.f;
+                p_barrier();
+            }
+
+            // memetic phase on the elite (:436-570)
+            if (sp.memetic) {
+                double* el = popS + S.cur * BF;  // the elite's genes, edited in place
+                const XV xe{el, 1};
+                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base);  // fresh linearisation at the elite
+                double dp = 0.0000001;
+                {
+                    uint32_t o0, o1;
+                    philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)S.id, RNG_MEMETIC_SIGN), o0, o1);
+                    if (rng_uniform(o0, o1) < 0.5) dp = -dp;
+                }
+                const int my_op = tid < D ? pb->op_of_gene[tid] : -1;  // lane i differentiates gene i
+                for (int it = 0; it < 8; it++) {
+                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
+                    double f2p = 0.0, fbp = 0.0;
+                    for (int t = 0; t < T; t++) {
+                        F7 f = linear_tip(pb, t, xe, lm);
+                        f2p += tip_goals(pb, t, f, xe, qc);
+                        if (my_op >= 0) {
+                            const double* d = s_delta + ((size_t)t * n_ops + my_op) * 7;  // computeApproximateMutation1
+                            F7 f3 = F7{{f.p.x + d[0] * dp, f.p.y + d[1] * dp, f.p.z + d[2] * dp},
+                                       {f.q.x + d[3] * dp, f.q.y + d[4] * dp, f.q.z + d[5] * dp, f.q.w + d[6] * dp}};
+                            fbp += tip_goals(pb, t, f3, xl, qc);
+                        }
+                    }
+                    f2p += nonlink_primary(pb, xe, qc);
+                    const double fa = f2p + secondary_fitness(pb, xe, qc);
+                    if (my_op >= 0) {
+                        fbp += nonlink_primary(pb, xl, qc);
+                        double fb = fbp + secondary_fitness(pb, xl, qc);
+                        s_grad[tid] = fb - fa;
+                    }
+                    p_barrier();
+                    double sum = dp * dp;  // :477-482
+                    for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
+                    const double fnorm = 1.0 / sum * dp;
+                    for (int k = tid; k < n_ops; k += nth) s_gv[k] = pb->ops[k].gene >= 0 ? s_grad[pb->ops[k].gene] * fnorm : 0.0;
+                    p_barrier();
+                    // support points x-g (even lanes) and x+g (odd lanes), :485-495
+                    const double sgn = (lane & 1) ? 1.0 : -1.0;
+                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * s_gv[k];
+                    double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
+                    const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
+                    double step_size;
+                    if (sp.memetic == 'q') {  // :498-539
+                        double v1 = f2 - f1, v2 = f3 - f2;
+                        double v = (v1 + v2) * 0.5, aa = v1 - v2;
+                        step_size = v / aa;
+                    } else {  // 'l' :545-568
+                        double cost_diff = (f3 - f1) * 0.5;
+                        step_size = -(f2 / cost_diff);
+                    }
+                    for (int k = tid; k < n_ops; k += nth)
+                        s_xn[k] = pb->ops[k].gene >= 0 ? fmin(fmax(el[k] + s_gv[k] * step_size, pb->ops[k].clip_min), pb->ops[k].clip_max) : el[k];
+                    p_barrier();
+                    const double f4p = eval_linear_primary(pb, XV{s_xn, 1}, qc, lm);
+                    if (!(f4p < f2p)) break;
+                    p_barrier();
+                    for (int k = tid; k < n_ops; k += nth) el[k] = s_xn[k];
+                    p_barrier();
+                }
+                p_barrier();
+            }
+            if (rank == 0) A = S; else B = S;
+        }
+
+        // species management (:604-645)
+        for (int rank = 0; rank < 2; rank++) {
+            SpeciesState S = rank == 0 ? A : B;
+            const double* cb = s_pop + S.slot * SP + S.cur * BF;
+            double fit = exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
+            S.improved = (fit != S.fit) ? 1 : 0;
+            S.fit = fit;
+            S.pf0 = fit;
+            if (rank == 0) A = S; else B = S;
+        }
+        if (B.fit < A.fit) {
+            SpeciesState tmp = A;
+            A = B;
+            B = tmp;
+        }
+        {
+            uint32_t o0, o1;
+            philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)B.id, RNG_WIPEOUT), o0, o1);
+            bool wipe = rng_uniform(o0, o1) < 0.1;
+            wipe = wipe || !B.improved;
+            if (sp.no_wipeout) wipe = false;
+            if (wipe) {
+                BIOIK_FP_STRICT
+                const uint32_t wc1 = rng_ctr1((uint32_t)step * 16u, (uint32_t)B.id, RNG_WIPEOUT_GENE);
+                double* cb = s_pop + B.slot * SP + B.cur * BF;
+                p_barrier();
+                for (int k = tid; k < n_ops; k += nth) {
+                    double v = cb[k];
+                    if (pb->ops[k].gene >= 0) {
+                        philox2x32_10(key, rng_ctr0(0, (uint32_t)pb->ops[k].gene), wc1, o0, o1);
+                        v = rng_uniform(o0, o1) * (pb->ops[k].vmax - pb->ops[k].vmin) + pb->ops[k].vmin;
+                    }
+                    cb[k] = v, cb[M + k] = 0.0;
+                    cb[2 * M + k] = v, cb[3 * M + k] = 0.0;
+                }
+                p_barrier();
+                if (exact) B.pf0 = B.pf1 = exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
+            }
+        }
+        steps++;
+        if (A.fit < sol_fit) {
+            const double* cb = s_pop + A.slot * SP + A.cur * BF;
+            p_barrier();
+            for (int k = tid; k < n_ops; k += nth) s_sol[k] = cb[k];
+            sol_fit = A.fit;
+            p_barrier();
+        }
+        // ik_parallel.h:173-181: exact FK of the solution, success test, fitness
+        FitCheck fc = exact_fitness_check(pb, XV{s_sol, 1}, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1);
+        final_fit = fc.fitness;
+        success = fc.ok != 0;
+        if (success) break;
+    }
+
+    // result of this island; ranking fitness of ik_parallel.h:229-246
+    double rank_fit = final_fit;
+    if (success && has_sec) rank_fit = final_fit + secondary_fitness(pb, XV{s_sol, 1}, qc);
+    double* out = a.solutions + unit * (uint64_t)V;
+    for (int i = tid; i < V; i += nth) out[i] = s_seed[i];
+    p_barrier();
+    if (steps > 0)
+        for (int k = tid; k < n_ops; k += nth)
+            if (pb->ops[k].gene >= 0) out[pb->ops[k].var] = s_sol[k];
+    if (tid == 0) {
+        a.fitness[unit] = rank_fit;
+        a.success[unit] = success ? 1 : 0;
+        a.steps[unit] = steps;
+    }
+}
+
+// best island per query (ik_parallel.h:220-269); one lane per query
+struct SelectArgs {
+    int islands, V;
+    uint64_t n;
+    const double* isl_solutions;
+    const double* isl_fitness;
+    const int32_t* isl_success;
+    const int32_t* isl_steps;
+    double* solutions;
+    double* fitness;
+    int32_t* success;
+    int32_t* steps;
+};
+BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
+    if (q >= a.n) return;
+    int best = 0;
+    double best_fit = BIOIK_DBL_MAX;
+    for (int i = 0; i < a.islands; i++) {
+        uint64_t u = q * (uint64_t)a.islands + i;
+        if (a.isl_success[u] && a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
+    }
+    if (best_fit == BIOIK_DBL_MAX) {
+        for (int i = 0; i < a.islands; i++) {
+            uint64_t u = q * (uint64_t)a.islands + i;
+            if (a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
+        }
+    }
+    uint64_t u = q * (uint64_t)a.islands + best;
+    for (int v = 0; v < a.V; v++) a.solutions[q * a.V + v] = a.isl_solutions[u * a.V + v];
+    a.fitness[q] = best_fit;
+    a.success[q] = a.isl_success[u];
+    a.steps[q] = a.isl_steps[u];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// function-level kernels: one lane per genotype, same device functions as the solver
+// ---------------------------------------------------------------------------------------------------------
+struct EvalArgs {
+    ProbPtr pb;
+    uint64_t n;             // genotypes (eval kernels) / population (reproduce)
+    const double* seed;     // [V]  one query
+    const double* params;   // [P]
+    const double* genes;    // [n][D] problem gene order
+    const double* base;     // [D] base genes of the linearisation (linear fitness / approximator)
+    double* out0;           // fk: tips [n][T][7]; fitness: primary [n]; approximator: tip frames [T][7]; reproduce: genes [n][D]
+    double* out1;           // fitness: secondary [n]; approximator: deltas [T][D][7]; reproduce: momentum [n][D]
+    int32_t* outi;          // check: ok [n]
+    double dpos, drot, dtwist;
+    uint32_t rng_key, rng_ctr1;
+    int32_t fk_mode;
+    int32_t pad;
+};
+
+BIOIK_DEV void load_query(const EvalArgs& a, double* s_seed, double* s_par) {
+    const int tid = p_tid(), nth = p_nthreads();
+    for (int i = tid; i < a.pb->V; i += nth) s_seed[i] = a.seed[i];
+    for (int i = tid; i < a.pb->P; i += nth) s_par[i] = a.params ? a.params[i] : 0.0;
+    p_barrier();
+}
+// op-ordered genotype from problem-ordered genes (or the seed when genes is null) into dst (stride ds)
+BIOIK_DEV void load_genotype(ProbPtr pb, const double* s_seed, const double* genes, double* dst, int ds) {
+    const int n_ops = pb->n_ops;
+    for (int k = 0; k < n_ops; k++) dst[(size_t)k * ds] = (pb->ops[k].gene >= 0 && genes) ? genes[pb->ops[k].gene] : s_seed[pb->ops[k].var];
+}
+
+// RobotFK_Fast_Base::applyConfiguration + getTipFrames for n genotypes
+BIOIK_DEV void eval_fk_body(const EvalArgs& a, uint64_t block, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads();
+    const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
+    load_query(a, lds + L.seed, lds + L.par);
+    uint64_t i = block * (uint64_t)nth + tid;
+    if (i >= a.n) return;
+    double* xcol = lds + L.xcol + tid;
+    load_genotype(pb, lds + L.seed, a.genes + i * pb->D, xcol, nth);
+    const int T = pb->T;
+    fk_walk(pb, XV{xcol, nth}, lds + L.slots, nullptr, [&](int t, const F7& f) { f7_store(a.out0 + (i * T + pb->tips[t].out_index) * 7, f); });
+}
+
+// Problem::computeGoalFitness on exact or linear phenotypes; every block of the linear variant rebuilds the tables itself
+BIOIK_DEV void eval_fitness_body(const EvalArgs& a, uint64_t block, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads();
+    const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
+    load_query(a, lds + L.seed, lds + L.par);
+    const QueryCtx qc{lds + L.seed, lds + L.par};
+    if (a.fk_mode == FK_LINEAR) {
+        if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.xn, 1);
+        p_barrier();
+        build_approximator(pb, XV{lds + L.xn, 1}, lds + L.slots, lds + L.frames, lds + L.tips, lds + L.delta, lds + L.base);
+    }
+    const LinModel lm{lds + L.tips, lds + L.delta, lds + L.base};
+    uint64_t i = block * (uint64_t)nth + tid;
+    if (i >= a.n) return;
+    double* xcol = lds + L.xcol + tid;
+    load_genotype(pb, lds + L.seed, a.genes + i * pb->D, xcol, nth);
+    const XV xl{xcol, nth};
+    a.out0[i] = a.fk_mode == FK_LINEAR ? eval_linear_primary(pb, xl, qc, lm) : eval_exact_primary(pb, xl, qc, lds + L.slots);
+    a.out1[i] = secondary_fitness(pb, xl, qc);
+}
+
+// RobotFK_Mutator::initializeMutationApproximator: tables in the public (tip, gene) order; 1 block
+BIOIK_DEV void eval_approximator_body(const EvalArgs& a, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads();
+    const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
+    load_query(a, lds + L.seed, lds + L.par);
+    if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.xn, 1);
+    p_barrier();
+    build_approximator(pb, XV{lds + L.xn, 1}, lds + L.slots, lds + L.frames, lds + L.tips, lds + L.delta, lds + L.base);
+    const int T = pb->T, D = pb->D, n_ops = pb->n_ops;
+    for (int idx = tid; idx < T * 7; idx += nth) {
+        int t = idx / 7, c = idx - t * 7;
+        a.out0[pb->tips[t].out_index * 7 + c] = lds[L.tips + idx];
+    }
+    for (int idx = tid; idx < T * D * 7; idx += nth) {
+        int t = idx / (D * 7), rem = idx - t * D * 7, g = rem / 7, c = rem - g * 7;
+        a.out1[((size_t)pb->tips[t].out_index * D + g) * 7 + c] = lds[L.delta + ((size_t)t * n_ops + pb->op_of_gene[g]) * 7 + c];
+    }
+}
+
+// IKEvolution2::reproduce for `n` children of one (species, generation)
+BIOIK_DEV void eval_reproduce_body(const EvalArgs& a, uint64_t block, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads(), D = pb->D, n_ops = pb->n_ops;
+    const int M = n_ops > 0 ? n_ops : 1;
+    double* s_par = lds;  // [2][2][M] parents, op-indexed: a.genes is [parent][genes|momentum][gene]
+    for (int idx = tid; idx < 4 * M; idx += nth) {
+        int k = idx % M, which = idx / M;
+        s_par[idx] = (k < n_ops && pb->ops[k].gene >= 0) ? a.genes[which * D + pb->ops[k].gene] : 0.0;
+    }
+    p_barrier();
+    uint64_t c = block * (uint64_t)nth + tid;
+    if (c >= a.n) return;
+    double* xcol = lds + 4 * M + tid;            // [M][nth]
+    double* gcol = lds + 4 * M + M * nth + tid;  // [M][nth]
+    reproduce_child(pb, a.rng_key, a.rng_ctr1, (uint32_t)c + 2u, s_par, s_par + M, s_par + 3 * M, xcol, nth, gcol, nth);
+    for (int k = 0; k < n_ops; k++)
+        if (pb->ops[k].gene >= 0) {
+            a.out0[c * D + pb->ops[k].gene] = xcol[(size_t)k * nth];
+            a.out1[c * D + pb->ops[k].gene] = gcol[(size_t)k * nth];
+        }
+}
+
+// Problem::checkSolutionActiveVariables on the exact-FK pose of n genotypes
+BIOIK_DEV void eval_check_body(const EvalArgs& a, uint64_t block, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads();
+    const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
+    load_query(a, lds + L.seed, lds + L.par);
+    const QueryCtx qc{lds + L.seed, lds + L.par};
+    uint64_t i = block * (uint64_t)nth + tid;
+    if (i >= a.n) return;
+    double* xcol = lds + L.xcol + tid;
+    load_genotype(pb, lds + L.seed, a.genes + i * pb->D, xcol, nth);
+    FitCheck fc = exact_fitness_check(pb, XV{xcol, nth}, qc, lds + L.slots, a.dpos, a.drot, a.dtwist, 1);
+    a.outi[i] = fc.ok;
+    if (a.out0) a.out0[i] = fc.fitness;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// streamed generation: the population genotype array is resident in HBM, genes [unit][D][population]
+// (individual index fastest: a wavefront's 64 loads of one gene are one contiguous 512-byte segment).
+// Block b serves `nthreads` individuals of unit b / blocks_per_unit.
+// ---------------------------------------------------------------------------------------------------------
+struct StreamArgs {
+    ProbPtr pb;
+    uint64_t n_units;
+    int32_t population, blocks_per_unit;
+    const double* seeds;   // [n_units][V]
+    const double* params;  // [n_units][P]
+    const double* genes;   // [n_units][D][population]
+    double* fitness;       // [n_units][population]
+};
+BIOIK_DEV void stream_fitness_body(const StreamArgs& a, uint64_t block, double* lds) {
+    ProbPtr pb = a.pb;
+    const int tid = p_tid(), nth = p_nthreads();
+    const int V = pb->V, P = pb->P, D = pb->D, n_ops = pb->n_ops;
+    const LdsLayout L = make_layout(n_ops, V, P, pb->T, pb->n_slots, nth, 0, 0);
+    const uint64_t unit = block / (uint64_t)a.blocks_per_unit;
+    const int ind = (int)(block % (uint64_t)a.blocks_per_unit) * nth + tid;
+    for (int i = tid; i < V; i += nth) lds[L.seed + i] = a.seeds[unit * V + i];
+    for (int i = tid; i < P; i += nth) lds[L.par + i] = a.params[unit * P + i];
+    p_barrier();
+    if (ind >= a.population) return;
+    const QueryCtx qc{lds + L.seed, lds + L.par};
+    const double* g = a.genes + unit * (uint64_t)D * a.population + ind;
+    double* xcol = lds + L.xcol + tid;
+    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = pb->ops[k].gene >= 0 ? g[(uint64_t)pb->ops[k].gene * a.population] : lds[L.seed + pb->ops[k].var];
+    a.fitness[unit * (uint64_t)a.population + ind] = eval_exact_primary(pb, XV{xcol, nth}, qc, lds + L.slots);
+}

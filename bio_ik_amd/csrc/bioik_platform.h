@@ -1,0 +1,85 @@
+// bioik_platform.h — the handful of execution-model primitives the kernels are written against.
+//
+// Product build (hipcc, gfx950): thin inline wrappers over the CDNA4 wave64 builtins.
+// BIOIK_HOSTSIM build (g++, tests/hostsim only): every lane of a workgroup is an OS thread and the cross-lane
+// primitives rendezvous on barriers, so the SAME kernel bodies can be stepped against the CPU oracle on a machine
+// without a GPU.  The simulator is test infrastructure; nothing in the product library is built with BIOIK_HOSTSIM.
+#pragma once
+#include <stdint.h>
+
+#include "bioik_types.h"
+
+#if defined(BIOIK_HOSTSIM)
+// ------------------------------------------------------------------------------------------------------------
+#include <barrier>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+#define BIOIK_DEV inline
+#define BIOIK_CONTRACT_OFF
+typedef const DevProblem* ProbPtr;
+
+namespace sim {
+struct Block {
+    int nthreads = 0;
+    int block_id = 0;
+    std::unique_ptr<std::barrier<>> bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<uint64_t> xchg;  // [waves][64]
+    char* lds = nullptr;
+};
+extern thread_local Block* blk;
+extern thread_local int tid;
+}  // namespace sim
+
+BIOIK_DEV int p_tid() { return sim::tid; }
+BIOIK_DEV int p_nthreads() { return sim::blk->nthreads; }
+BIOIK_DEV void p_barrier() { sim::blk->bar->arrive_and_wait(); }
+template <class T>
+BIOIK_DEV T p_shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "");
+    int w = sim::tid >> 6, l = sim::tid & 63;
+    uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(T));
+    uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
+    x[l] = bits;
+    sim::blk->wave_bar[w]->arrive_and_wait();
+    uint64_t r = x[src_lane & 63];
+    sim::blk->wave_bar[w]->arrive_and_wait();
+    T out;
+    std::memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <class T>
+BIOIK_DEV T p_shfl_xor(T v, int mask) { return p_shfl(v, (sim::tid & 63) ^ mask); }
+BIOIK_DEV int p_uniform(int v) { return v; }
+BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
+BIOIK_DEV void p_sincos(double x, double* s, double* c) {
+    *s = std::sin(x);
+    *c = std::cos(x);
+}
+#define P_INF (__builtin_inf())
+
+#else
+// ------------------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define BIOIK_DEV __device__ __forceinline__
+// uniform, read-only problem block: the constant address space makes every access a scalar (s_load) candidate
+typedef const DevProblem __attribute__((address_space(4))) * ProbPtr;
+
+BIOIK_DEV int p_tid() { return (int)threadIdx.x; }
+BIOIK_DEV int p_nthreads() { return (int)blockDim.x; }
+BIOIK_DEV void p_barrier() { __syncthreads(); }
+template <class T>
+BIOIK_DEV T p_shfl(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+template <class T>
+BIOIK_DEV T p_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
+BIOIK_DEV void p_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+#define P_INF (__builtin_inf())
+#endif
+
+#define BIOIK_DBL_MAX 1.7976931348623157e308
+#define BIOIK_PI 3.14159265358979323846

@@ -1,0 +1,93 @@
+// bioik_types.h — PODs shared by the host-side problem compiler and the gfx950 kernels.
+//
+// A problem template (robot model + goal structure, reference Problem::initialize, src/problem.cpp:72-228, plus
+// RobotFK::initialize, src/forward_kinematics.h:253-330) is compiled ONCE on the host into a `DevProblem`: a flat
+// "joint program" that every lane of every wavefront walks.  The block is read through uniform (scalar) loads, so
+// its numbers reach the FP64 VALU as SGPR operands and cost neither VGPRs nor LDS bandwidth.
+#pragma once
+#include <stdint.h>
+
+#define BIOIK_MAX_OPS 32    // moving joints on the union of the root->tip chains (+ off-chain goal variables)
+#define BIOIK_MAX_TIPS 8
+#define BIOIK_MAX_GOALS 24  // per class (primary / secondary)
+
+enum { BIOIK_OP_NONE = 0, BIOIK_OP_REVOLUTE = 1, BIOIK_OP_PRISMATIC = 2 };
+
+// One moving joint of the link schedule (reference src/forward_kinematics.h:268-282).  The fixed links between the
+// previous moving joint and this one are folded into the constant frame C on the host, so one op is
+//     F_out = F_src o C o J(x)            (reference :331-354: global[l] = global[parent] o origin o joint_frame)
+// with  revolute : C o J = ( C.pos , cos(x/2) * A + sin(x/2) * B ),  A = C.rot, B = C.rot (x) (axis, 0)
+//       prismatic: C o J = ( C.pos + x * Pv , A ),                  Pv = C.rot * axis   (stored in cb[0..2])
+struct DevOp {
+    double cpos[3];
+    double ca[4];
+    double cb[4];
+    double axis[3];                  // joint axis in the joint frame (analytic Jacobian, forward_kinematics.h:639-693)
+    double clip_min, clip_max, span; // RobotInfo (include/bio_ik/robot_info.h:70-106) of the variable
+    double vmin, vmax;               // variable bounds (random re-initialisation, ik_evolution_2.cpp:626-631)
+    double vw;                       // minimal_displacement_factors (src/problem.cpp:207-225)
+    int32_t type;                    // BIOIK_OP_*
+    int32_t var;                     // robot variable index
+    int32_t gene;                    // index into Problem::active_variables, or -1 (inactive: value comes from the seed)
+    int32_t src;                     // op whose output frame is the parent frame, -1 = model root (identity)
+    int32_t load_slot;               // >=0: parent frame must be fetched from this LDS slot (branching trees)
+    int32_t save_slot;               // >=0: output frame is parked in this LDS slot for a later branch
+    int32_t tip_first, tip_count;    // device tips whose frame is F_out o E (evaluated right after this op)
+    int32_t unbounded;               // clip_max == DBL_MAX (goal_types.h:394,419)
+    int32_t pad;
+};
+
+struct DevTip {
+    double e[7];                       // constant trailing frame E (fixed links behind the last moving joint)
+    int32_t src;                       // op index, -1 = root
+    int32_t has_e;                     // 0: E is the identity
+    int32_t out_index;                 // index in Problem::tip_link_indices (order of the public API)
+    int32_t goal_first, goal_count;    // primary link goals reading this tip: DevProblem::primary[goal_first..)
+    uint32_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
+};
+
+struct DevGoal {
+    double weight_sq;   // Problem::GoalInfo::weight_sq (problem.cpp:178)
+    int32_t type;       // BIOIK_GOAL_*
+    int32_t tip;        // device tip index, -1 when the goal reads no link
+    int32_t var_op;     // op index of the goal's variable (JointVariableGoal), -1 none
+    int32_t var_seed;   // robot variable index when the goal's joint is fixed (GoalContext::getVariablePosition, goal.h:70-77), -1 none
+    int32_t param_off;  // offset of the goal's numbers inside the per-query parameter vector
+    int32_t pad;
+};
+
+struct DevProblem {
+    int32_t n_ops;        // ops[0..n_chain_ops) walk the kinematic tree; [n_chain_ops..n_ops) are off-chain goal variables
+    int32_t n_chain_ops;
+    int32_t D;            // Problem::active_variables.size()
+    int32_t T;            // Problem::tip_link_indices.size()
+    int32_t V;            // robot variables
+    int32_t P;            // doubles per query in goal_params
+    int32_t n_root_tips;  // tips[0..n_root_tips) hang off the model root without any moving joint
+    int32_t n_link_primary;  // primary[0..n_link_primary) are link goals grouped by tip; the rest read genes only
+    int32_t n_primary;
+    int32_t n_secondary;
+    int32_t n_slots;
+    int32_t pad;
+    int32_t op_of_gene[BIOIK_MAX_OPS];
+    int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
+    DevOp ops[BIOIK_MAX_OPS];
+    DevTip tips[BIOIK_MAX_TIPS];
+    DevGoal primary[BIOIK_MAX_GOALS];
+    DevGoal secondary[BIOIK_MAX_GOALS];
+};
+
+// solver parameters as the kernels see them (bioik_solve_params after normalisation, problem.cpp:90-95)
+struct DevSolveParams {
+    double dpos, drot, dtwist;  // DBL_MAX = disabled
+    uint64_t random_seed;
+    uint64_t first_query;       // global index of query 0 of this launch (multi-GPU shards keep their RNG streams)
+    int32_t memetic;            // 0, 'q', 'l'
+    int32_t fk_mode;            // BIOIK_FK_*
+    int32_t lambda;             // children per species per generation
+    int32_t islands;
+    int32_t max_steps;
+    int32_t no_wipeout;
+    int32_t generations;        // 8 (memetic) or 16 (ik_evolution_2.cpp:349-351)
+    int32_t pad;
+};

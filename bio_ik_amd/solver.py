@@ -1,0 +1,208 @@
+"""ctypes binding of the HIP solver library (include/bioik_hip.h) — the product compute path.
+
+`HipSolver` owns one (model, problem template) pair on one MI355X and exposes the batched solve plus the
+function-level entry points.  There is no CPU path: if `libbioik_hip.so` is missing, or no HIP device is visible,
+construction raises (`bioik_model_create` -> BIOIK_ERR_NO_DEVICE).  Host arrays are NumPy; the `*_device` methods take
+raw device pointers (e.g. `torch.Tensor.data_ptr()` of CUDA tensors) and a HIP stream handle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbioik_hip.so")
+_lib = None
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+
+EXPORTS = [
+    "bioik_goal_param_count", "bioik_default_solve_params", "bioik_last_error", "bioik_abi_version", "bioik_device_count",
+    "bioik_model_create", "bioik_model_destroy", "bioik_problem_create", "bioik_problem_destroy",
+    "bioik_problem_active_variable_count", "bioik_problem_active_variables", "bioik_problem_tip_count", "bioik_problem_tip_links",
+    "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch",
+    "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
+    "bioik_eval_check", "bioik_stream_fitness_device",
+]
+
+
+class BioIKError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bioik status %d: %s" % (code, msg))
+        self.code = code
+
+
+def _declare(L):
+    L.bioik_last_error.restype = C.c_char_p
+    L.bioik_model_create.argtypes = [C.POINTER(abi.ModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+    L.bioik_model_destroy.argtypes = [C.c_void_p]
+    L.bioik_model_destroy.restype = None
+    L.bioik_problem_create.argtypes = [C.c_void_p, C.POINTER(abi.ProblemDesc), C.POINTER(C.c_void_p)]
+    L.bioik_problem_destroy.argtypes = [C.c_void_p]
+    L.bioik_problem_destroy.restype = None
+    for f in ("bioik_problem_active_variable_count", "bioik_problem_tip_count", "bioik_problem_param_count", "bioik_problem_variable_count"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.bioik_problem_active_variables.argtypes = [C.c_void_p, _pi]
+    L.bioik_problem_tip_links.argtypes = [C.c_void_p, _pi]
+    L.bioik_problem_set_first_query.argtypes = [C.c_void_p, C.c_uint64]
+    L.bioik_default_solve_params.argtypes = [C.POINTER(abi.SolveParams)]
+    L.bioik_default_solve_params.restype = None
+    L.bioik_solve_batch.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi]
+    L.bioik_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bioik_eval_fk.argtypes = [C.c_void_p, C.c_size_t, _pd, _pd, _pd]
+    L.bioik_eval_fitness.argtypes = [C.c_void_p, C.c_int, C.c_size_t, _pd, _pd, _pd, _pd, _pd, _pd]
+    L.bioik_eval_approximator.argtypes = [C.c_void_p, _pd, _pd, _pd, _pd]
+    L.bioik_eval_reproduce.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, _pd, _pd, _pd]
+    L.bioik_eval_check.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pi]
+    L.bioik_stream_fitness_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def load_library(path=None):
+    """Load (once) the HIP solver library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if path is not None:
+        return _declare(C.CDLL(path))
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); bio_ik_amd has no CPU compute path" % LIB_PATH)
+        _lib = _declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def device_count():
+    return int(load_library().bioik_device_count())
+
+
+def _d(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _i(a):
+    return a.ctypes.data_as(_pi)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipSolver:
+    """One problem template on one GPU.  `lib` is for the test suite only (it injects the host simulator)."""
+
+    def __init__(self, template, device=0, lib=None):
+        self.L = lib if lib is not None else load_library()
+        self.template = template
+        self.model = C.c_void_p()
+        self.problem = C.c_void_p()
+        md = template.model.desc()
+        self._chk(self.L.bioik_model_create(C.byref(md), int(device), C.byref(self.model)))
+        pd = template.desc()
+        rc = self.L.bioik_problem_create(self.model, C.byref(pd), C.byref(self.problem))
+        if rc != abi.OK:
+            msg = self.L.bioik_last_error().decode()
+            self.L.bioik_model_destroy(self.model)
+            self.model = C.c_void_p()
+            raise BioIKError(rc, msg)
+        self.D = self.L.bioik_problem_active_variable_count(self.problem)
+        self.T = self.L.bioik_problem_tip_count(self.problem)
+        self.P = self.L.bioik_problem_param_count(self.problem)
+        self.V = self.L.bioik_problem_variable_count(self.problem)
+        self.active_variables = np.zeros(self.D, dtype=np.int32)
+        self.L.bioik_problem_active_variables(self.problem, _i(self.active_variables))
+        self.tip_links = np.zeros(self.T, dtype=np.int32)
+        self.L.bioik_problem_tip_links(self.problem, _i(self.tip_links))
+
+    def close(self):
+        if getattr(self, "problem", None):
+            self.L.bioik_problem_destroy(self.problem)
+            self.problem = C.c_void_p()
+        if getattr(self, "model", None):
+            self.L.bioik_model_destroy(self.model)
+            self.model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != abi.OK:
+            raise BioIKError(rc, self.L.bioik_last_error().decode())
+
+    def _gp(self, goal_params, n=None):
+        if n is None:
+            g = _f64(goal_params).ravel() if self.P else np.zeros(1)
+            if self.P and g.size != self.P:
+                raise ValueError("goal_params must have %d entries" % self.P)
+            return g
+        return _f64(goal_params).reshape(n, self.P) if self.P else np.zeros((n, 1))
+
+    def set_first_query(self, first_query):
+        self._chk(self.L.bioik_problem_set_first_query(self.problem, int(first_query)))
+
+    # ---- the hot path -------------------------------------------------------------------------------------
+    def solve_batch(self, params, seeds, goal_params):
+        """n independent queries: seeds [n][V], goal_params [n][P] -> (solutions [n][V], fitness, success, steps)."""
+        s = _f64(seeds).reshape(-1, self.V)
+        n = s.shape[0]
+        gp = self._gp(goal_params, n)
+        sol = np.zeros((n, self.V))
+        fit = np.zeros(n)
+        suc = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.bioik_solve_batch(self.problem, C.byref(params), n, _d(s), _d(gp), _d(sol), _d(fit), _i(suc), _i(steps)))
+        return sol, fit, suc, steps
+
+    def solve_batch_device(self, params, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, stream=0):
+        """All arguments are device pointers (ints) of arrays resident in HBM; enqueues on `stream`, does not synchronise."""
+        self._chk(self.L.bioik_solve_batch_device(self.problem, C.byref(params), int(n), d_seeds, d_goal_params, d_solutions, d_fitness,
+                                                  d_success, d_steps, stream))
+
+    def stream_fitness_device(self, n_units, population, d_seeds, d_goal_params, d_genes, d_fitness, stream=0):
+        self._chk(self.L.bioik_stream_fitness_device(self.problem, int(n_units), int(population), d_seeds, d_goal_params, d_genes, d_fitness, stream))
+
+    # ---- function-level entry points -----------------------------------------------------------------------
+    def fk_genes(self, seed, genes):
+        g = _f64(genes).reshape(-1, self.D)
+        tips = np.zeros((g.shape[0], self.T, 7))
+        self._chk(self.L.bioik_eval_fk(self.problem, g.shape[0], _d(_f64(seed)), _d(g), _d(tips)))
+        return tips
+
+    def fk(self, vars_):
+        """exact FK of full variable vectors (every row is its own seed)"""
+        v = _f64(vars_).reshape(-1, self.V)
+        return np.concatenate([self.fk_genes(row, row[self.active_variables][None, :]) for row in v], axis=0)
+
+    def fitness(self, fk_mode, seed, goal_params, genes, base_genes=None):
+        g = _f64(genes).reshape(-1, self.D)
+        n = g.shape[0]
+        prim, sec = np.zeros(n), np.zeros(n)
+        b = _f64(base_genes) if base_genes is not None else None
+        self._chk(self.L.bioik_eval_fitness(self.problem, int(fk_mode), n, _d(_f64(seed)), _d(self._gp(goal_params)), _d(b) if b is not None else None,
+                                            _d(g), _d(prim), _d(sec)))
+        return prim, sec
+
+    def approximator(self, seed, base_genes):
+        tips = np.zeros((self.T, 7))
+        deltas = np.zeros((self.T, self.D, 7))
+        self._chk(self.L.bioik_eval_approximator(self.problem, _d(_f64(seed)), _d(_f64(base_genes)), _d(tips), _d(deltas)))
+        return tips, deltas
+
+    def reproduce(self, population, rng_key, species, generation, parents):
+        par = _f64(parents).reshape(2, 2, self.D)
+        genes = np.zeros((population, self.D))
+        grads = np.zeros((population, self.D))
+        self._chk(self.L.bioik_eval_reproduce(self.problem, int(population), int(rng_key), int(species), int(generation), _d(par), _d(genes), _d(grads)))
+        return genes, grads
+
+    def check(self, params, seed, goal_params, genes):
+        g = _f64(genes).reshape(-1, self.D)
+        ok = np.zeros(g.shape[0], dtype=np.int32)
+        self._chk(self.L.bioik_eval_check(self.problem, C.byref(params), g.shape[0], _d(_f64(seed)), _d(self._gp(goal_params)), _d(g), _i(ok)))
+        return ok

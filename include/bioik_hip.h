@@ -190,6 +190,10 @@ int bioik_problem_tip_count(const bioik_problem* p);                      /* Pro
 int bioik_problem_tip_links(const bioik_problem* p, int32_t* out);
 int bioik_problem_param_count(const bioik_problem* p);                    /* doubles per query in goal_params   */
 int bioik_problem_variable_count(const bioik_problem* p);                 /* robot variables V                  */
+/* Global index of query 0 of the following bioik_solve_batch* calls (default 0).  The random stream of a query is
+ * keyed by (random_seed, global query index, island), so a batch sharded over several GPUs / calls reproduces the
+ * unsharded run when every shard announces its offset.  (New: the reference has one query per call.) */
+int bioik_problem_set_first_query(bioik_problem* p, uint64_t first_query);
 
 /*
  * The batched solve: replaces IKParallel::solve() for n independent queries
