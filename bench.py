@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — IK solves/sec of the MI355X bio2_memetic hot path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: `bioik_solve_batch_device` on 4096 independent PR2-like
+right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), inputs already resident in HBM.
+`value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
+GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
+collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel k_solve against the HBM roofline: ALGORITHMIC bytes per launch (SURVEY.md §8d,
+               B_gen = 8*(pop*(3D+1) + 8D) per generation per species per query, from the device step counters)
+               / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s.  The fused kernel
+               keeps the population in LDS, so the measured HBM traffic (profiles/) is far below the algorithmic
+               figure; the kernel is FP64-VALU bound.
+  cpu_baseline the CPU oracle (oracle/, a port of the reference algorithm built with the reference's Release flags)
+               timed on this host, rank 0, N=1 only, on a bounded sample of the same queries.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 4096
+POP = 128
+MAX_STEPS = 64
+HBM_PEAK = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from bio_ik_amd import PoseGoal, ProblemTemplate, abi, pr2_like
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.workload import make_queries
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: bio_ik_amd has no CPU compute path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    template = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
+    h = HipSolver(template, device=local_rank)
+    D, V, T = h.D, h.V, h.T
+    # synthetic queries of the reference's own self-test recipe (README.md:410-418); every rank draws its own shard
+    seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank)
+    h.set_first_query(rank * BATCH)
+    p = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1)
+
+    d_seeds = torch.from_numpy(seeds).to(dev)
+    d_params = torch.from_numpy(params).to(dev)
+    d_sol = torch.empty((BATCH, V), dtype=torch.float64, device=dev)
+    d_fit = torch.empty(BATCH, dtype=torch.float64, device=dev)
+    d_suc = torch.empty(BATCH, dtype=torch.int32, device=dev)
+    d_steps = torch.empty(BATCH, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        h.solve_batch_device(p, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), d_sol.data_ptr(), d_fit.data_ptr(), d_suc.data_ptr(),
+                             d_steps.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)  # events on the stream the kernel is launched on
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else 0.0
+
+    suc = d_suc.cpu().numpy()
+    steps_q = d_steps.cpu().numpy()
+    n_success = int(suc.sum())
+    total_success = float(n_success * args.steps)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ts = torch.tensor([total_success], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        total_success = float(ts.item())
+
+    # result-level check of what was timed: every success reproduces its goal pose under the device's own exact FK
+    sol = d_sol.cpu().numpy()
+    ok_idx = np.nonzero(suc)[0][:256]
+    tips = np.stack([h.fk_genes(sol[i], sol[i][h.active_variables][None, :])[0] for i in ok_idx]) if len(ok_idx) else np.zeros((0, T, 7))
+    pos_err = float(np.linalg.norm(tips[:, 0, :3] - params[ok_idx, :3], axis=1).max()) if len(ok_idx) else 0.0
+
+    # algorithmic bytes of one launch
+    gens_per_step = 2 * (8 if p.mode != abi.MODE_BIO2 else 16)
+    b_gen = 8 * (POP * (3 * D + 1) + 8 * D)
+    generations = float(steps_q.astype(np.float64).sum()) * gens_per_step
+    alg_bytes = generations * b_gen + BATCH * (8 * (7 * T + V) + 8 * (V + 3))
+    achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_solve_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "IK solves/sec (pop=128, 7-DOF PoseGoal batch)",
+        "value": total_success / elapsed if elapsed > 0 else 0.0,
+        "unit": "solves/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
+                   "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective"},
+        "success_rate": float(suc.mean()),
+        "mean_steps_per_solve": float(steps_q.mean()),
+        "max_pos_err_m_of_successes": pos_err,
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "kernel": "k_solve", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6)"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import orc
+        o = orc.Oracle(template, kind="ref")  # reference Release flags, libm trigonometry
+        ns = min(args.cpu_sample, BATCH)
+        t1 = time.perf_counter()
+        _, _, osuc, osteps = o.solve_batch(p, orc.RNG_COUNTER, seeds[:ns], params[:ns], n_threads=1)
+        dt = time.perf_counter() - t1
+        cb = {"value": float(osuc.sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+              "sample": "first %d of the same 4096 queries, same parameters (pop=128, exact FK, max_steps=%d), 1 thread, oracle built with the reference's "
+                        "Release flags (-O3 -ffast-math ...)" % (ns, MAX_STEPS),
+              "success_rate": float(osuc.mean()), "seconds": dt, "host_cpus": os.cpu_count()}
+        # the reference's own configuration (16 children, linearised phenotypes, minstd_rand tables), same queries and step budget
+        pr = abi.default_solve_params(population=16, fk_mode=abi.FK_LINEAR, max_steps=MAX_STEPS * 8, random_seed=1)
+        t1 = time.perf_counter()
+        _, _, rsuc, _ = o.solve_batch(pr, orc.RNG_REFERENCE, seeds[:ns], params[:ns], n_threads=1)
+        dt = time.perf_counter() - t1
+        cb["reference_defaults"] = {"value": float(rsuc.sum()) / dt, "success_rate": float(rsuc.mean()), "seconds": dt, "cores": 1,
+                                    "config": "16 children, linearised FK, reference RNG, 1 island, max_steps=%d" % (MAX_STEPS * 8)}
+        ncpu = os.cpu_count() or 1
+        t1 = time.perf_counter()
+        _, _, asuc, _ = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=ncpu)
+        dt = time.perf_counter() - t1
+        cb["all_cores"] = {"value": float(asuc.sum()) / dt, "cores": ncpu, "seconds": dt, "sample": "all 4096 queries, query-parallel"}
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,7 +75,7 @@ BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p
 
 // ---------------------------------------------------------------------------------------------------------
 // Counter-based RNG: Philox2x32-10 (Salmon et al., SC'11; Random123 constants) with integer-only
-// post-processing, so that the device and the CPU oracle (oracle/orc_rng.h) produce bit-identical doubles.
+// post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
 enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4 };
 #define RNG_SLOT_RATE 255u

@@ -208,9 +208,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp, size_t n, c
     const DevProblem& dp = p->host.dev;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
-    const int nth = solve_threads(sp, units);
+    int nth = solve_threads(sp, units);
+    while (nth > 64 && lds_bytes(p, nth, sp.lambda) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
     const size_t lds = lds_bytes(p, nth, sp.lambda);
-    if (lds > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 64 KiB of LDS per workgroup");
+    if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+#if !defined(BIOIK_HOSTSIM)
+    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;

@@ -55,10 +55,6 @@ template <class T>
 BIOIK_DEV T p_shfl_xor(T v, int mask) { return p_shfl(v, (sim::tid & 63) ^ mask); }
 BIOIK_DEV int p_uniform(int v) { return v; }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
-BIOIK_DEV void p_sincos(double x, double* s, double* c) {
-    *s = std::sin(x);
-    *c = std::cos(x);
-}
 #define P_INF (__builtin_inf())
 
 #else
@@ -77,9 +73,13 @@ template <class T>
 BIOIK_DEV T p_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
-BIOIK_DEV void p_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 #define P_INF (__builtin_inf())
 #endif
+
+// sin/cos of the joint half angles: the shared bit-reproducible implementation (bioik_sincos.h)
+#define BIOIK_SINCOS_FN BIOIK_DEV
+#include "bioik_sincos.h"
+BIOIK_DEV void p_sincos(double x, double* s, double* c) { bioik_sincos(x, s, c); }
 
 #define BIOIK_DBL_MAX 1.7976931348623157e308
 #define BIOIK_PI 3.14159265358979323846

@@ -48,6 +48,8 @@ static void dump_state(E& ik, double* species_genes, double* species_fitness, do
 extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
+void orc_set_trig_mode(int mode) { trig_mode() = mode ? 1 : 0; }
+int orc_get_trig_mode(void) { return trig_mode(); }
 
 void* orc_model_create(const bioik_model_desc* desc) {
     try {

@@ -35,6 +35,9 @@ enum {
 };
 
 const char* orc_last_error(void);
+/* 0: libm sin/cos as in the reference (default); 1: bioik_sincos shared bit-for-bit with the device (orc_model.h) */
+void orc_set_trig_mode(int mode);
+int orc_get_trig_mode(void);
 
 void* orc_model_create(const bioik_model_desc* desc);
 void orc_model_destroy(void* model);

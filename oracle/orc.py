@@ -47,6 +47,11 @@ def lib(kind="strict"):
     return _libs[kind]
 
 
+def set_trig_mode(mode, kind="strict"):
+    """0 = libm (reference behaviour, default), 1 = bioik_sincos shared bit-for-bit with the device kernels."""
+    lib(kind).orc_set_trig_mode(C.c_int(mode))
+
+
 def _d(a):
     return a.ctypes.data_as(_pd)
 

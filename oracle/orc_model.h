@@ -11,9 +11,19 @@
 #include <vector>
 
 #include "../include/bioik_hip.h"
+#include "../bio_ik_amd/csrc/bioik_sincos.h"
 #include "orc_math.h"
 
 namespace orc {
+
+// Trigonometry of the revolute joint frames.  0 (default): libm sin/cos, as the reference calls them
+// (forward_kinematics.h:96-97).  1: the bit-reproducible bioik_sincos shared with the device kernels — libm and the
+// GPU math library differ in the last ulp, which bio2_memetic's line search amplifies into different trajectories,
+// so trajectory-level (bit-for-bit) parity tests run the oracle in mode 1.  The two modes agree to < 2 ulp.
+inline int& trig_mode() {
+    static int mode = 0;
+    return mode;
+}
 
 struct Link {
     int parent;
@@ -126,8 +136,13 @@ struct RobotFK {
             case BIOIK_JOINT_REVOLUTE: {
                 double v = vars[l.first_var];
                 double half_angle = v * 0.5;
-                double fcos = std::cos(half_angle);
-                double fsin = std::sin(half_angle);
+                double fcos, fsin;
+                if (trig_mode() == 1) {
+                    bioik_sincos(half_angle, &fsin, &fcos);
+                } else {
+                    fcos = std::cos(half_angle);
+                    fsin = std::sin(half_angle);
+                }
                 frame = Frame{{0.0, 0.0, 0.0}, {l.axis.x * fsin, l.axis.y * fsin, l.axis.z * fsin, fcos}};
                 return;
             }

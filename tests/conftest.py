@@ -48,3 +48,72 @@ def random_configuration(model, rng, n=None):
     hi = np.asarray(model.var_max)
     shape = (model.n_variables,) if n is None else (n, model.n_variables)
     return lo + (hi - lo) * rng.random(shape)
+
+
+def gnarly_robot():
+    """A deliberately awkward tree (test fixture only): rotated joint origins, oblique axes, a prismatic joint inside a
+    chain, a tip on a fixed link behind the last joint, a tip that hangs off the root without any joint, three
+    branches, and a joint outside every goal chain (only reachable through a JointVariableGoal)."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("gnarly")
+    m.add_link("root")
+    m.add_link("plate", "root", "plate_joint", "fixed", xyz=(0.1, -0.2, 0.3), rpy=(0.3, -0.2, 0.5))
+    m.add_link("waist", "plate", "waist_joint", "revolute", xyz=(0.0, 0.05, 0.2), rpy=(0.1, 0.2, -0.3), axis=(0.2, -0.3, 0.9), lower=-2.0, upper=2.5, velocity=1.5)
+    m.add_link("lift", "waist", "lift_joint", "prismatic", xyz=(0.02, 0.0, 0.1), rpy=(0.0, 0.4, 0.0), axis=(0.1, 0.1, 1.0), lower=-0.1, upper=0.4, velocity=0.2)
+    for side, sgn in (("a", 1.0), ("b", -1.0)):
+        m.add_link(side + "1", "lift", side + "1_joint", "revolute", xyz=(0.0, sgn * 0.15, 0.05), rpy=(sgn * 0.7, 0.0, 0.2), axis=(0, 1, 0), lower=-1.5, upper=1.2, velocity=2.0)
+        m.add_link(side + "1f", side + "1", side + "1f_joint", "fixed", xyz=(0.2, 0.0, 0.0), rpy=(0.0, 0.3, 0.0))
+        m.add_link(side + "2", side + "1f", side + "2_joint", "continuous", xyz=(0.1, 0.0, 0.02), rpy=(0.2, 0.0, 0.0), axis=(1, 0, 0), velocity=3.0)
+        m.add_link(side + "3", side + "2", side + "3_joint", "revolute", xyz=(0.15, 0.0, 0.0), rpy=(0.0, 0.0, sgn * 0.4), axis=(0.0, 0.6, 0.8), lower=-2.2, upper=0.3, velocity=2.5)
+        m.add_link(side + "_tool", side + "3", side + "_tool_joint", "fixed", xyz=(0.05, 0.01, 0.12), rpy=(0.3, 0.3, 0.3))
+    m.add_link("head", "waist", "head_joint", "revolute", xyz=(0.0, 0.0, 0.4), rpy=(0.0, 0.0, 0.0), axis=(0, 0, 1), lower=-1.0, upper=1.0, velocity=1.0)
+    m.add_link("antenna", "root", "antenna_joint", "revolute", xyz=(0.3, 0.0, 0.0), axis=(0, 0, 1), lower=-0.5, upper=0.5, velocity=1.0)
+    joints = ["waist_joint", "lift_joint", "a1_joint", "a2_joint", "a3_joint", "b1_joint", "b2_joint", "b3_joint", "head_joint", "antenna_joint"]
+    m.add_group("body", joints=joints, tips=["a_tool", "b_tool", "head"])
+    return m
+
+
+@pytest.fixture(scope="session")
+def gnarly():
+    return gnarly_robot()
+
+
+def gnarly_goals():
+    """one goal of every device opcode, spread over four tips (one of them the joint-less `plate`)"""
+    from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, ConeGoal, DirectionGoal, JointVariableGoal, LineGoal, LookAtGoal,
+                            MaxDistanceGoal, MinDistanceGoal, MinimalDisplacementGoal, OrientationGoal, PlaneGoal, PoseGoal, PositionGoal,
+                            RegularizationGoal, SideGoal)
+    sec = MinimalDisplacementGoal(weight=0.7)
+    sec.secondary_ = True
+    sec2 = JointVariableGoal("head_joint", 0.2, weight=0.5)
+    sec2.secondary_ = True
+    return [
+        PoseGoal("a_tool", (0.4, 0.2, 0.6), (0.1, 0.2, 0.3, 0.9), weight=1.0),
+        PositionGoal("b_tool", (0.3, -0.3, 0.5), weight=0.8),
+        OrientationGoal("b_tool", (0.0, 0.3, 0.1, 0.9), weight=0.6),
+        LookAtGoal("head", (1, 0, 0), (1.0, 0.5, 0.7), weight=0.5),
+        MaxDistanceGoal("a3", (0.2, 0.2, 0.2), 0.3, weight=1.1),
+        MinDistanceGoal("a3", (0.25, 0.2, 0.5), 0.4, weight=0.9),
+        LineGoal("b3", (0.0, 0.0, 0.5), (0.0, 1.0, 0.0), weight=0.4),
+        PlaneGoal("b3", (0.0, 0.0, 0.6), (0.0, 0.0, 1.0), weight=0.3),
+        SideGoal("a_tool", (0, 0, 1), (0, 1, 0), weight=0.7),
+        DirectionGoal("b_tool", (0, 0, 1), (1, 0, 0), weight=0.2),
+        ConeGoal("head", (1, 0, 0), (0, 0, 1), 0.3, weight=0.6, position=(0.1, 0.0, 0.9), position_weight=0.5),
+        PositionGoal("plate", (0.1, -0.2, 0.31), weight=0.05),
+        AvoidJointLimitsGoal(weight=0.3),
+        CenterJointsGoal(weight=0.2),
+        RegularizationGoal(weight=0.1),
+        JointVariableGoal("antenna_joint", 0.1, weight=0.4),
+        sec,
+        sec2,
+    ]
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    """TEST INFRASTRUCTURE: the kernel bodies of bio_ik_amd/csrc built for the host (tests/hostsim)."""
+    import subprocess
+    from bio_ik_amd import solver
+    d = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.run(["make", "-C", d, "-s"], check=True)
+    return solver.load_library(os.path.join(d, "libbioik_hostsim.so"))

@@ -1,0 +1,89 @@
+"""Parity cases shared by the GPU suite (tests/test_gpu_parity.py, through the C-ABI of libbioik_hip.so) and by the
+host-simulator suite (tests/test_hostsim_parity.py, same kernel bodies built for the host).
+
+`h` is a bio_ik_amd.solver.HipSolver, `o` an oracle.orc.Oracle of the same problem template.  The oracle must be in
+trig mode 1 (bioik_sincos shared with the device) wherever bit-exactness is asserted."""
+import numpy as np
+
+from bio_ik_amd import abi
+from bio_ik_amd.workload import make_queries
+from conftest import random_configuration
+from oracle import orc
+
+
+def assert_same_structure(h, o):
+    assert (h.D, h.T, h.P, h.V) == (o.D, o.T, o.P, o.V)
+    assert np.array_equal(h.active_variables, o.active_variables)
+    assert np.array_equal(h.tip_links, o.tip_links)
+
+
+def function_level(h, o, model, rng, n=200, frame_tol=1e-12, fit_rtol=1e-10, exact_bits=False):
+    """K7 exact FK, K4 goal fitness (exact and linear), K8 approximator tables, K1 reproduce, K9 success check."""
+    assert_same_structure(h, o)
+    seed = random_configuration(model, rng)
+    genes = random_configuration(model, rng, n)[:, o.active_variables]
+    par = rng.normal(size=o.P)
+    # quaternion parameters must be unit quaternions for the twist-based success test to be meaningful
+    a, b = o.fk_genes(seed, genes), h.fk_genes(seed, genes)
+    assert np.abs(a - b).max() <= (0.0 if exact_bits else frame_tol)
+    pa, sa = o.fitness(abi.FK_EXACT, seed, par, genes)
+    pb, sb = h.fitness(abi.FK_EXACT, seed, par, genes)
+    tol = 0.0 if exact_bits else fit_rtol
+    assert np.all(np.abs(pa - pb) <= tol * np.abs(pa))
+    assert np.all(np.abs(sa - sb) <= tol * np.abs(sa) + (0.0 if exact_bits else 1e-300))
+    base = genes[0]
+    near = base + 0.01 * rng.normal(size=(n, o.D))
+    pa, sa = o.fitness(abi.FK_LINEAR, seed, par, near, base)
+    pb, sb = h.fitness(abi.FK_LINEAR, seed, par, near, base)
+    assert np.all(np.abs(pa - pb) <= tol * np.abs(pa))
+    ta, da, _ = o.approximator(seed, base)
+    tb, db = h.approximator(seed, base)
+    assert np.abs(ta - tb).max() <= (0.0 if exact_bits else frame_tol)
+    assert np.abs(da - db).max() <= (0.0 if exact_bits else frame_tol)
+    # reproduce: bit-exact always (counter RNG + strict arithmetic on both sides)
+    parents = rng.normal(size=(2, 2, o.D)) * 0.1
+    parents[:, 0, :] = random_configuration(model, rng, 2)[:, o.active_variables]
+    for lam, key, sp, gen in ((16, 12345, 1, 37), (130, 0xDEADBEEF, 0, 1601)):
+        ga, gra = o.reproduce_counter(lam, key, sp, gen, parents)
+        gb, grb = h.reproduce(lam, key, sp, gen, parents)
+        assert np.array_equal(ga, gb) and np.array_equal(gra, grb)
+    for kw in ({}, {"dpos": 0.05, "drot": 5.0, "dtwist": -1.0}, {"dpos": 0.3, "drot": -1.0, "dtwist": 0.2}):
+        p = abi.default_solve_params(**kw)
+        assert np.array_equal(o.check(p, seed, par, genes), h.check(p, seed, par, genes))
+
+
+def success_check_near_goal(h, o, template, rng, n=64):
+    """K9 around the decision threshold: goals taken from FK of the genes themselves, perturbed by ~dtwist."""
+    seeds, params, targets = make_queries(template, o.active_variables, o.fk_genes, n, seed=int(rng.integers(1 << 30)))
+    p = abi.default_solve_params()
+    for k in range(0, n, 8):
+        g = targets[k] + rng.normal(size=(16, o.D)) * rng.choice([0.0, 1e-7, 3e-6, 1e-5, 1e-3], size=(16, 1))
+        a = o.check(p, seeds[k], params[k], g)
+        b = h.check(p, seeds[k], params[k], g)
+        assert np.array_equal(a, b)
+        assert a[np.all(g == targets[k], axis=1)].all() if np.any(np.all(g == targets[k], axis=1)) else True
+
+
+def trajectory(h, o, template, n, pop, steps_list, seed=7, exact_bits=True, **kw):
+    """Whole solves with identical RNG streams: the device result must equal the oracle's (bit for bit when both sides
+    use bioik_sincos and unfused arithmetic)."""
+    seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=seed)
+    for steps in steps_list:
+        p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=11, **kw)
+        sa = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
+        sb = h.solve_batch(p, seeds, params)
+        if exact_bits:
+            assert np.array_equal(sa[0], sb[0]), "solutions differ after %d steps: %g" % (steps, np.abs(sa[0] - sb[0]).max())
+            assert np.array_equal(sa[1], sb[1])
+        else:
+            assert np.abs(sa[0] - sb[0]).max() < 1e-9
+        assert np.array_equal(sa[2], sb[2]) and np.array_equal(sa[3], sb[3])
+
+
+def pose_errors(o, sol, params, tip=0, off=0):
+    """position [m] and rotation [rad] error of the returned solutions under the ORACLE's exact FK"""
+    tips = o.fk(sol)
+    perr = np.linalg.norm(tips[:, tip, :3] - params[:, off:off + 3], axis=1)
+    dots = np.abs(np.einsum("ij,ij->i", tips[:, tip, 3:], params[:, off + 3:off + 7]))
+    rerr = 2 * np.arccos(np.minimum(1.0, dots))
+    return perr, rerr

@@ -1,0 +1,184 @@
+"""Parity tests proper: the HIP path (libbioik_hip.so on a real MI355X, through the C-ABI) against the CPU oracle.
+
+Three levels: function level (same genes -> same frames / fitness / tables / children / success flags),
+trajectory level (same RNG streams -> the same solution, bit for bit: both sides use bioik_sincos and unfused IEEE
+arithmetic), result level at BASELINE.json's full sizes (every reported success reproduces its goal pose under the
+ORACLE's exact FK within 1e-4 m / 1e-3 rad, joints inside their limits, success rate equal to the oracle's on a sample)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from bio_ik_amd import ProblemTemplate, abi
+from bio_ik_amd.workload import make_queries
+from conftest import gnarly_goals
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ROT_TOL = 1e-4, 1e-3  # north-star tolerance on PoseGoal results [m], [rad]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def shared_trigonometry():
+    orc.set_trig_mode(1)
+    yield
+    orc.set_trig_mode(0)
+
+
+@pytest.fixture(scope="module")
+def gpus(templates):
+    from bio_ik_amd.solver import HipSolver, device_count
+    assert device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return {k: HipSolver(t, device=0) for k, t in templates.items()}
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_function_level(gpus, oracles, templates, cfg):
+    pc.function_level(gpus[cfg], oracles[cfg], templates[cfg].model, np.random.default_rng(1), n=3000, exact_bits=True)
+
+
+def test_function_level_gnarly(gnarly):
+    from bio_ik_amd.solver import HipSolver
+    t = ProblemTemplate(gnarly, "body", gnarly_goals())
+    pc.function_level(HipSolver(t), orc.Oracle(t), gnarly, np.random.default_rng(2), n=2000)
+    t2 = ProblemTemplate(gnarly, "body", gnarly_goals(), fixed_joints=["lift_joint", "antenna_joint"])
+    pc.function_level(HipSolver(t2), orc.Oracle(t2), gnarly, np.random.default_rng(3), n=2000)
+
+
+def test_success_check_near_threshold(gpus, oracles, templates):
+    pc.success_check_near_goal(gpus["c2"], oracles["c2"], templates["c2"], np.random.default_rng(4), n=64)
+
+
+@pytest.mark.parametrize("cfg,pop,kw", [
+    ("c2", 16, {}),
+    ("c2", 16, {"fk_mode": abi.FK_LINEAR}),
+    ("c2", 128, {}),
+    ("c3", 128, {}),
+    ("c4", 512, {}),
+    ("c2", 130, {"mode": "bio2"}),
+    ("c4", 16, {"mode": "bio2_memetic_l", "fk_mode": abi.FK_LINEAR}),
+    ("c2", 16, {"islands": 4}),
+    ("c2", 16, {"no_wipeout": 1, "dpos": 1e-4, "drot": 0.05, "dtwist": -1.0}),
+])
+def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
+    pc.trajectory(gpus[cfg], oracles[cfg], templates[cfg], n=24, pop=pop, steps_list=(1, 4, 12), **kw)
+
+
+@pytest.mark.parametrize("threads", ["64", "128", "256"])
+def test_trajectory_independent_of_workgroup_shape(gpus, oracles, templates, threads, monkeypatch):
+    """the same solve with 1, 2 and 4 wavefronts per query"""
+    monkeypatch.setenv("BIOIK_SOLVE_THREADS", threads)
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=16, pop=128, steps_list=(6,))
+    pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=8, pop=100, steps_list=(3,))
+
+
+def test_full_batch_c2_result_level(gpus, oracles, templates):
+    """BASELINE.json configs[1]: 4096 PoseGoals, pop=128.  FK -> IK -> FK round trip (reference README.md:404-447)."""
+    h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
+    n = 4096
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=0xB101C)
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=1)
+    sol, fit, suc, steps = h.solve_batch(p, seeds, params)
+    assert suc.mean() >= 0.99
+    perr, rerr = pc.pose_errors(o, sol, params)
+    assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+    info = o.robot_info()
+    bounded = info[:, 1] != np.finfo(float).max
+    assert np.all(sol[:, bounded] >= info[bounded, 3] - 1e-12) and np.all(sol[:, bounded] <= info[bounded, 4] + 1e-12)
+    inactive = np.setdiff1d(np.arange(h.V), h.active_variables)
+    assert np.array_equal(sol[:, inactive], seeds[:, inactive])  # variables outside the group come back untouched
+    # the oracle, given the same streams, returns the same answers (sample: CPU time)
+    k = 96
+    so = o.solve_batch(p, orc.RNG_COUNTER, seeds[:k], params[:k], n_threads=8)
+    assert np.array_equal(so[0], sol[:k]) and np.array_equal(so[2], suc[:k]) and np.array_equal(so[3], steps[:k])
+    # determinism / idempotence: a second launch returns identical bits
+    sol2, fit2, suc2, steps2 = h.solve_batch(p, seeds, params)
+    assert np.array_equal(sol, sol2) and np.array_equal(steps, steps2)
+
+
+def test_full_batch_c3_c4_result_level(gpus, oracles, templates):
+    """configs[2] (two tips + MinimalDisplacement) and configs[3] (31-DOF snake + AvoidJointLimits, pop=512)"""
+    for cfg, pop, n, max_steps, min_rate in (("c3", 128, 4096, 64, 0.3), ("c4", 512, 4096, 64, 0.99)):
+        h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=0xB101C)
+        p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=1)
+        sol, fit, suc, steps = h.solve_batch(p, seeds, params)
+        assert suc.mean() >= min_rate
+        off = 0
+        for tip in range(h.T):
+            perr, rerr = pc.pose_errors(o, sol, params, tip=tip, off=off)
+            assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+            off += 8
+        k = 8
+        so = o.solve_batch(p, orc.RNG_COUNTER, seeds[:k], params[:k], n_threads=8)
+        assert np.array_equal(so[0], sol[:k]) and np.array_equal(so[2], suc[:k])
+
+
+def test_sharded_batch_equals_whole_batch(gpus, templates):
+    """the multi-GPU split: shards solved separately with their query offsets reproduce the unsharded batch"""
+    h, t = gpus["c2"], templates["c2"]
+    n = 512
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=5)
+    p = abi.default_solve_params(population=128, max_steps=32, random_seed=9)
+    h.set_first_query(0)
+    whole = h.solve_batch(p, seeds, params)
+    parts = []
+    for r in range(4):
+        h.set_first_query(r * 128)
+        parts.append(h.solve_batch(p, seeds[r * 128:(r + 1) * 128], params[r * 128:(r + 1) * 128]))
+    h.set_first_query(0)
+    for i in range(4):
+        assert np.array_equal(np.concatenate([q[i] for q in parts]), whole[i])
+
+
+def test_device_pointer_entry_and_streamed_fitness(gpus, oracles, templates):
+    """bioik_solve_batch_device / bioik_stream_fitness_device on arrays resident in HBM (torch only supplies memory)"""
+    torch = pytest.importorskip("torch")
+    h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
+    dev = torch.device("cuda", 0)
+    n = 256
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=6)
+    p = abi.default_solve_params(population=128, max_steps=16, random_seed=2)
+    ref = h.solve_batch(p, seeds, params)
+    ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
+    sol = torch.empty((n, h.V), dtype=torch.float64, device=dev)
+    fit = torch.empty(n, dtype=torch.float64, device=dev)
+    suc = torch.empty(n, dtype=torch.int32, device=dev)
+    steps = torch.empty(n, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+        h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), sol.data_ptr(), fit.data_ptr(), suc.data_ptr(), steps.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(sol.cpu().numpy(), ref[0]) and np.array_equal(steps.cpu().numpy(), ref[3])
+    # streamed generation: genes [unit][D][pop] in HBM -> fitness [unit][pop], against the oracle
+    pop, units = 128, 8
+    rng = np.random.default_rng(0)
+    genes = rng.uniform(-1, 1, size=(units, h.D, pop))
+    dg = torch.from_numpy(genes).to(dev)
+    df = torch.empty((units, pop), dtype=torch.float64, device=dev)
+    h.stream_fitness_device(units, pop, ds.data_ptr(), dp.data_ptr(), dg.data_ptr(), df.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    got = df.cpu().numpy()
+    for u in range(units):
+        want, _ = o.fitness(abi.FK_EXACT, seeds[u], params[u], genes[u].T)
+        assert np.array_equal(got[u], want)
+
+
+def test_error_conventions(pr2):
+    """status codes instead of exceptions/aborts (include/bioik_hip.h)"""
+    from bio_ik_amd import PoseGoal, RobotModel
+    from bio_ik_amd.solver import BioIKError, HipSolver
+    m = RobotModel("float")
+    m.add_link("base")
+    m.add_link("body", "base", "fj", "floating")
+    m.add_group("g", joints=["fj"], tips=["body"])
+    with pytest.raises(BioIKError) as e:
+        HipSolver(ProblemTemplate(m, "g", [PoseGoal("body")]))
+    assert e.value.code == abi.ERR_UNSUPPORTED
+    with pytest.raises(BioIKError) as e:
+        HipSolver(ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")]), device=99)
+    assert e.value.code == abi.ERR_NO_DEVICE
+    from bio_ik_amd import JointVariableGoal
+    with pytest.raises(BioIKError) as e:  # variable outside the group: reference ERROR("joint variable not found"), problem.cpp:125
+        HipSolver(ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), JointVariableGoal("l_elbow_flex_joint", 0.0)]))
+    assert e.value.code == abi.ERR_NOT_FOUND

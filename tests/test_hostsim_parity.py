@@ -1,0 +1,81 @@
+"""CPU-side parity of the KERNEL BODIES (bio_ik_amd/csrc built with -DBIOIK_HOSTSIM, every lane an OS thread) against
+the oracle.  Same source as the gfx950 kernels, so the solver logic (selection order, RNG contexts, memetic phase,
+species management, pre-selection by secondary goals, multi-wave reductions) is stepped against the reference
+restatement on a machine without a GPU.  The GPU suite (test_gpu_parity.py) repeats these cases through
+libbioik_hip.so at larger sizes."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from bio_ik_amd import ProblemTemplate, abi
+from bio_ik_amd.solver import HipSolver
+from conftest import gnarly_goals
+from oracle import orc
+
+
+@pytest.fixture(scope="module", autouse=True)
+def shared_trigonometry():
+    """bit-exact comparisons need the oracle on the sincos it shares with the device (oracle/orc_model.h)"""
+    orc.set_trig_mode(1)
+    yield
+    orc.set_trig_mode(0)
+
+
+@pytest.fixture(scope="module")
+def sims(hostsim_lib, templates, oracles):
+    return {k: HipSolver(t, lib=hostsim_lib) for k, t in templates.items()}
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_function_level_bit_exact(sims, oracles, templates, cfg):
+    """the fixtures have axis-aligned joint origins, for which folding fixed links into the joint program is exact"""
+    pc.function_level(sims[cfg], oracles[cfg], templates[cfg].model, np.random.default_rng(1), n=70, exact_bits=True)
+
+
+def test_function_level_gnarly(hostsim_lib, gnarly):
+    """rotated origins, oblique axes, prismatic joint, branches with parked frames, root tip, all 16 goal opcodes"""
+    t = ProblemTemplate(gnarly, "body", gnarly_goals())
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    pc.function_level(h, o, gnarly, np.random.default_rng(2), n=70)
+    t2 = ProblemTemplate(gnarly, "body", gnarly_goals(), fixed_joints=["lift_joint", "antenna_joint"])
+    h2, o2 = HipSolver(t2, lib=hostsim_lib), orc.Oracle(t2)
+    assert h2.D == 8
+    pc.function_level(h2, o2, gnarly, np.random.default_rng(3), n=70)
+
+
+def test_success_check_near_threshold(sims, oracles, templates):
+    pc.success_check_near_goal(sims["c2"], oracles["c2"], templates["c2"], np.random.default_rng(4), n=16)
+
+
+@pytest.mark.parametrize("cfg,pop,kw", [
+    ("c2", 16, {}),                                # one wavefront, exact FK per individual, memetic 'q'
+    ("c2", 16, {"fk_mode": abi.FK_LINEAR}),        # the reference's linearised phenotypes
+    ("c3", 24, {}),                                # two tips + secondary goal: pre-selection by secondary fitness
+    ("c2", 130, {"mode": "bio2"}),                 # no memetic phase, 16 generations, several children per lane
+    ("c4", 16, {"mode": "bio2_memetic_l", "fk_mode": abi.FK_LINEAR}),
+])
+def test_trajectory_bit_exact(sims, oracles, templates, cfg, pop, kw):
+    pc.trajectory(sims[cfg], oracles[cfg], templates[cfg], n=2, pop=pop, steps_list=(1, 3), **kw)
+
+
+def test_trajectory_two_wavefronts_and_islands(sims, oracles, templates, monkeypatch):
+    monkeypatch.setenv("BIOIK_SOLVE_THREADS", "128")
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(2,), islands=2)
+
+
+def test_edge_cases(sims, oracles, templates):
+    h, o, t = sims["c2"], oracles["c2"], templates["c2"]
+    p = abi.default_solve_params(population=16, max_steps=0)
+    seeds = np.tile(t.model.default_positions(), (3, 1))
+    params = np.tile(t.pack_params(), (3, 1))
+    sol, fit, suc, steps = h.solve_batch(p, seeds, params)  # no budget: the seed comes back, fitness DBL_MAX (ik_parallel.h:208-209)
+    assert np.array_equal(sol, seeds) and np.all(fit == np.finfo(float).max) and not suc.any() and not steps.any()
+    sol, fit, suc, steps = h.solve_batch(p, seeds[:0], params[:0])  # empty batch
+    assert sol.shape == (0, h.V)
+    # a query that starts at its goal succeeds after the first step
+    from bio_ik_amd.workload import make_queries
+    s2, p2, targets = make_queries(t, o.active_variables, o.fk_genes, 2, seed=3)
+    s2[:, o.active_variables] = targets
+    p = abi.default_solve_params(population=16, max_steps=5)
+    sol, fit, suc, steps = h.solve_batch(p, s2, p2)
+    assert suc.all() and np.all(steps == 1)
