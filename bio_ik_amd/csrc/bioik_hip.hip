@@ -92,7 +92,10 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
 }
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 
-__global__ void __launch_bounds__(256) k_solve(SolveArgs a) {
+#ifndef BIOIK_SOLVE_WAVES_PER_SIMD
+#define BIOIK_SOLVE_WAVES_PER_SIMD 1
+#endif
+__global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body(a, blockIdx.x, lds);
 }

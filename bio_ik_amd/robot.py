@@ -278,3 +278,51 @@ def snake(n=31, link_length=0.1, limit=1.5, velocity=1.0):
     m.add_link("tip", prev, "tip_joint", "fixed", xyz=(link_length, 0, 0))
     m.add_group("snake", chain=("base", "tip"))
     return m
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side frame helpers for the plugin boundary (goal poses into the model frame,
+# reference src/kinematics_plugin.cpp:487-502: RobotState::getGlobalLinkTransform(getBaseFrame()))
+# ---------------------------------------------------------------------------------------------
+def quat_rotate(q, v):
+    x, y, z, w = q
+    t = 2.0 * np.cross([x, y, z], v)
+    return np.asarray(v, dtype=np.float64) + w * t + np.cross([x, y, z], t)
+
+
+def quat_multiply(p, q):
+    px, py, pz, pw = p
+    qx, qy, qz, qw = q
+    return np.array([pw * qx + px * qw + py * qz - pz * qy, pw * qy - px * qz + py * qw + pz * qx,
+                     pw * qz + px * qy - py * qx + pz * qw, pw * qw - px * qx - py * qy - pz * qz])
+
+
+def frame_concat(a, b):
+    """a o b for frames (px py pz qx qy qz qw)"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.concatenate([a[:3] + quat_rotate(a[3:], b[:3]), quat_multiply(a[3:], b[3:])])
+
+
+def link_transform(model, link, positions):
+    """Global frame of `link` at the given variable positions (fixed / revolute / prismatic joints): setup-time helper of
+    the plugin mirror, not part of the solver."""
+    chain = []
+    l = link
+    while l >= 0:
+        chain.append(l)
+        l = model.link_parent[l]
+    f = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    for l in reversed(chain):
+        f = frame_concat(f, model.link_origin[l])
+        jt = model.joint_type[l]
+        if jt == abi.JOINT_REVOLUTE:
+            h = 0.5 * positions[model.joint_first_variable[l]]
+            a = np.asarray(model.joint_axis[l])
+            f = frame_concat(f, np.concatenate([[0, 0, 0], a * math.sin(h), [math.cos(h)]]))
+        elif jt == abi.JOINT_PRISMATIC:
+            a = np.asarray(model.joint_axis[l]) * positions[model.joint_first_variable[l]]
+            f = frame_concat(f, np.concatenate([a, [0, 0, 0, 1.0]]))
+        elif jt != abi.JOINT_FIXED:
+            raise NotImplementedError("floating / planar joints above the base frame")
+    return f

@@ -6,7 +6,9 @@ construction raises (`bioik_model_create` -> BIOIK_ERR_NO_DEVICE).  Host arrays 
 raw device pointers (e.g. `torch.Tensor.data_ptr()` of CUDA tensors) and a HIP stream handle.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -62,15 +64,44 @@ def _declare(L):
     return L
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process cannot both
+    open the GPU, so when torch is installed but not imported yet, its bundled runtime is loaded first and
+    libbioik_hip.so binds to it by SONAME — whichever of the two libraries is used first, they share one runtime.
+    (torch itself is not imported: it only supplies device memory and streams to callers that want it.)"""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library(path=None):
     """Load (once) the HIP solver library.  Raises if it has not been built: there is no fallback."""
     global _lib
     if path is not None:
         return _declare(C.CDLL(path))
     if _lib is None:
+        path = os.environ.get("BIOIK_HIP_LIBRARY", LIB_PATH)  # deployment override: another build of the same library
+        if path != LIB_PATH:
+            _share_hip_runtime_with_torch()
+            _lib = _declare(C.CDLL(path))
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); bio_ik_amd has no CPU compute path" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         _lib = _declare(C.CDLL(LIB_PATH))
     return _lib
 

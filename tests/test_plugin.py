@@ -1,0 +1,91 @@
+"""The plugin mirror (bio_ik_amd/plugin.py) against the reference's searchPositionIK contract
+(src/kinematics_plugin.cpp:437-655), driven on CPU through the host simulator of the kernels."""
+import numpy as np
+import pytest
+
+from bio_ik_amd import (BioIKKinematicsPlugin, BioIKKinematicsQueryOptions, KinematicsQueryOptions, MoveItErrorCodes, PositionGoal, abi)
+from bio_ik_amd.robot import frame_concat, link_transform
+from bio_ik_amd.solver import HipSolver
+from conftest import random_configuration
+from oracle import orc
+
+
+@pytest.fixture(scope="module")
+def plugin(hostsim_lib, pr2):
+    p = BioIKKinematicsPlugin(solver_factory=lambda template, device: HipSolver(template, device=device, lib=hostsim_lib))
+    assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0,
+                        params={"gpu_population": 16, "gpu_fk": "linear", "gpu_max_steps": 40, "random_seed": 3})
+    return p
+
+
+def goal_in_base_frame(pr2, target_state):
+    """pose of the tip expressed in the group's base frame, as a MoveIt caller would pass it"""
+    tip = link_transform(pr2, pr2.link_index("r_wrist_roll_link"), target_state)
+    base = link_transform(pr2, pr2.link_index("torso_lift_link"), pr2.default_positions())
+    inv_q = np.array([-base[3], -base[4], -base[5], base[6]])
+    from bio_ik_amd.robot import quat_multiply, quat_rotate
+    return np.concatenate([quat_rotate(inv_q, tip[:3] - base[:3]), quat_multiply(inv_q, tip[3:])])
+
+
+def test_interface_shape(plugin):
+    assert plugin.getJointNames()[0] == "r_shoulder_pan_joint" and len(plugin.getJointNames()) == 7
+    assert plugin.getLinkNames() == ["r_wrist_roll_link"]
+    assert plugin.getPositionFK([], [], []) is False and plugin.getPositionIK(None, [], [], MoveItErrorCodes()) is False
+    assert plugin.supportsGroup(None)
+    with pytest.raises(RuntimeError):
+        BioIKKinematicsPlugin().initialize(plugin.robot_model, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"mode": "nonsense"})
+
+
+def test_search_position_ik_round_trip(plugin, pr2):
+    rng = np.random.default_rng(5)
+    target = pr2.default_positions()
+    gv = plugin._group_vars
+    target[gv] = random_configuration(pr2, rng)[gv]
+    pose = goal_in_base_frame(pr2, target)
+    seed = np.clip(target[gv] + 0.2 * rng.normal(size=len(gv)), np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv])
+    solution, code = [], MoveItErrorCodes()
+    assert plugin.searchPositionIK([pose], list(seed), 0.005, solution, code) is True
+    assert code.val == MoveItErrorCodes.SUCCESS and len(solution) == 7
+    state = pr2.default_positions()
+    state[gv] = solution
+    got = link_transform(pr2, pr2.link_index("r_wrist_roll_link"), state)
+    want = frame_concat(link_transform(pr2, pr2.link_index("torso_lift_link"), pr2.default_positions()), pose)
+    assert np.linalg.norm(got[:3] - want[:3]) < 1e-4 and 2 * np.arccos(min(1.0, abs(got[3:] @ want[3:]))) < 1e-3
+    lo, hi = np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv]
+    assert np.all(np.asarray(solution) >= lo - 1e-12) and np.all(np.asarray(solution) <= hi + 1e-12)
+    # callback semantics (:644-649): the callback's verdict is the return value
+    def reject(p, s, e):
+        e.val = MoveItErrorCodes.NO_IK_SOLUTION
+    assert plugin.searchPositionIK([pose], list(seed), 0.005, [], MoveItErrorCodes(), solution_callback=reject) is False
+
+
+def test_unreachable_goal_error_codes(plugin, pr2):
+    far = np.array([5.0, 5.0, 5.0, 0, 0, 0, 1.0])
+    seed = list(pr2.default_positions()[plugin._group_vars])
+    plugin.params["gpu_max_steps"] = 2
+    try:
+        sol, code = [], MoveItErrorCodes()
+        assert plugin.searchPositionIK([far], seed, 0.005, sol, code) is False and code.val == MoveItErrorCodes.NO_IK_SOLUTION  # :638-641
+        sol, code = [], MoveItErrorCodes()
+        assert plugin.searchPositionIK([far], seed, 0.005, sol, code, options=KinematicsQueryOptions(return_approximate_solution=True)) is True
+        assert len(sol) == 7
+        opts = BioIKKinematicsQueryOptions()  # replace: only the caller's goals (:540-556)
+        opts.replace = True
+        opts.return_approximate_solution = True
+        opts.goals.append(PositionGoal("r_wrist_roll_link", (0.5, -0.2, 0.9)))
+        assert plugin.searchPositionIK([], seed, 0.005, sol, MoveItErrorCodes(), options=opts) is True
+        assert opts.solution_fitness >= 0.0
+    finally:
+        plugin.params["gpu_max_steps"] = 40
+
+
+def test_angle_wrapping_matches_oracle(plugin, oracles, pr2):
+    """kinematics_plugin.cpp:580-616 restated twice (oracle C++, plugin NumPy) must agree"""
+    o = oracles["c2"]
+    rng = np.random.default_rng(9)
+    seed = random_configuration(pr2, rng, 64)
+    state = seed + rng.normal(size=seed.shape) * 7.0
+    want = np.stack([o.wrap_angles(seed[k], state[k]) for k in range(64)])
+    got = plugin._wrap_angles(state, seed, o.active_variables)
+    act = o.active_variables
+    assert np.abs(got[:, act] - want[:, act]).max() < 1e-12
