@@ -26,9 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BATCH = 4096
-POP = 128
-MAX_STEPS = 64
+BATCH = int(os.environ.get("BIOIK_BENCH_BATCH", "4096"))      # experiments only: the reported metric uses the defaults
+POP = int(os.environ.get("BIOIK_BENCH_POP", "128"))
+FK_MODE = os.environ.get("BIOIK_BENCH_FK", "exact")
+MAX_STEPS = int(os.environ.get("BIOIK_BENCH_MAX_STEPS", "64"))
 HBM_PEAK = 8.0e12
 
 
@@ -68,7 +69,7 @@ def main():
     # synthetic queries of the reference's own self-test recipe (README.md:410-418); every rank draws its own shard
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank)
     h.set_first_query(rank * BATCH)
-    p = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1)
+    p = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, fk_mode=abi.FK_EXACT if FK_MODE == "exact" else abi.FK_LINEAR)
 
     d_seeds = torch.from_numpy(seeds).to(dev)
     d_params = torch.from_numpy(params).to(dev)

@@ -354,7 +354,10 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.V = nv;
     dev.P = param_count;
     dev.n_slots = n_slots;
-    for (size_t k = 0; k < ops.size(); k++) dev.ops[k] = ops[k];
+    for (size_t k = 0; k < ops.size(); k++) {
+        dev.ops[k] = ops[k];
+        if (ops[k].gene >= 0) dev.active_mask |= 1u << k;
+    }
 }
 
 DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query) {

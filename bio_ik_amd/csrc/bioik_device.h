@@ -279,7 +279,7 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) 
 // ---------------------------------------------------------------------------------------------------------
 // exact FK: every lane walks the joint program with the values of ITS individual (forward_kinematics.h:331-354)
 //   slots      LDS, [slot][7][nthreads]: parked branch frames of this lane
-//   frames_out LDS or null, [op][7]: when set, lane 0 of the workgroup publishes every joint's global frame
+//   frames_out LDS or null, [op][7]: the lane that passes it publishes every joint's global frame
 //              (the per-joint frame chain the analytic Jacobian reads)
 //   tip_fn(t, frame): called with device tip index t as soon as the tip's frame is complete
 // The loop trip count and every constant are wave-uniform: control flow is scalar, constants arrive in SGPRs.
@@ -298,48 +298,57 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
             tip_fn(t, f);
         }
     }
-    for (int k = 0; k < n_chain; k++) {
-        const int ls = pb->ops[k].load_slot;
-        if (ls >= 0) {
-            const double* s = slots + (size_t)ls * 7 * nth + tid;
-            f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
-        } else if (k > 0 && pb->ops[k].src < 0) {
-            f = f7_identity();
+    // Four joints per trip.  Phase A: their values and half-angle trigonometry — four independent polynomial
+    // chains the scheduler can interleave (sincos is computed for prismatic joints too and discarded: no branch).
+    // Phase B: the four rigid transforms, which are inherently sequential.
+    for (int k0 = 0; k0 < n_chain; k0 += 4) {
+        double xv[4], sn[4], cs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int kk = k0 + j < n_chain ? k0 + j : n_chain - 1;
+            xv[j] = x(kk);
         }
-        const double xv = x(k);
-        const V3 cp = v3(pb->ops[k].cpos[0], pb->ops[k].cpos[1], pb->ops[k].cpos[2]);
-        const Q4 ca = Q4{pb->ops[k].ca[0], pb->ops[k].ca[1], pb->ops[k].ca[2], pb->ops[k].ca[3]};
-        if (pb->ops[k].type == BIOIK_OP_REVOLUTE) {
-            double s, c;
-            p_sincos(xv * 0.5, &s, &c);
-            Q4 lq = Q4{c * ca.x + s * pb->ops[k].cb[0], c * ca.y + s * pb->ops[k].cb[1], c * ca.z + s * pb->ops[k].cb[2], c * ca.w + s * pb->ops[k].cb[3]};
-            f.p = f.p + qrot(f.q, cp);
-            f.q = qmul(f.q, lq);
-        } else {
-            V3 lp = v3(cp.x + xv * pb->ops[k].cb[0], cp.y + xv * pb->ops[k].cb[1], cp.z + xv * pb->ops[k].cb[2]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k >= n_chain) break;
+            const int ls = pb->ops[k].load_slot;
+            if (ls >= 0) {
+                const double* s = slots + (size_t)ls * 7 * nth + tid;
+                f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
+            } else if (k > 0 && pb->ops[k].src < 0) {
+                f = f7_identity();
+            }
+            const bool rev = pb->ops[k].type == BIOIK_OP_REVOLUTE;
+            const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
+            const Q4 lq = Q4{c * pb->ops[k].ca[0] + s * pb->ops[k].cb[0], c * pb->ops[k].ca[1] + s * pb->ops[k].cb[1],
+                             c * pb->ops[k].ca[2] + s * pb->ops[k].cb[2], c * pb->ops[k].ca[3] + s * pb->ops[k].cb[3]};
+            const V3 lp = v3(pb->ops[k].cpos[0] + xp * pb->ops[k].cb[0], pb->ops[k].cpos[1] + xp * pb->ops[k].cb[1], pb->ops[k].cpos[2] + xp * pb->ops[k].cb[2]);
             f.p = f.p + qrot(f.q, lp);
-            f.q = qmul(f.q, ca);
-        }
-        const int ss = pb->ops[k].save_slot;
-        if (ss >= 0) {
-            double* s = slots + (size_t)ss * 7 * nth + tid;
-            s[0] = f.p.x;
-            s[(size_t)nth] = f.p.y;
-            s[(size_t)2 * nth] = f.p.z;
-            s[(size_t)3 * nth] = f.q.x;
-            s[(size_t)4 * nth] = f.q.y;
-            s[(size_t)5 * nth] = f.q.z;
-            s[(size_t)6 * nth] = f.q.w;
-        }
-        if (frames_out && tid == 0) f7_store(frames_out + k * 7, f);
-        const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
-        for (int t = t0; t < t1; t++) {
-            if (pb->tips[t].has_e) {
-                double e[7];
-                for (int c = 0; c < 7; c++) e[c] = pb->tips[t].e[c];
-                tip_fn(t, f7_concat(f, f7_load(e)));
-            } else {
-                tip_fn(t, f);
+            f.q = qmul(f.q, lq);
+            const int ss = pb->ops[k].save_slot;
+            if (ss >= 0) {
+                double* sl = slots + (size_t)ss * 7 * nth + tid;
+                sl[0] = f.p.x;
+                sl[(size_t)nth] = f.p.y;
+                sl[(size_t)2 * nth] = f.p.z;
+                sl[(size_t)3 * nth] = f.q.x;
+                sl[(size_t)4 * nth] = f.q.y;
+                sl[(size_t)5 * nth] = f.q.z;
+                sl[(size_t)6 * nth] = f.q.w;
+            }
+            if (frames_out) f7_store(frames_out + k * 7, f);  // only the publishing lane passes a non-null pointer
+            const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+            for (int t = t0; t < t1; t++) {
+                if (pb->tips[t].has_e) {
+                    double e[7];
+                    for (int c2 = 0; c2 < 7; c2++) e[c2] = pb->tips[t].e[c2];
+                    tip_fn(t, f7_concat(f, f7_load(e)));
+                } else {
+                    tip_fn(t, f);
+                }
             }
         }
     }
@@ -364,23 +373,36 @@ struct LinModel {
     const double* base;
 };
 
-// forward_kinematics.h:1186-1231 (no renormalisation of the quaternion)
+// forward_kinematics.h:1186-1231 (no renormalisation of the quaternion).  Four joints per trip: their 4 + 28 LDS
+// operands are requested together and waited for once; inactive / padding joints contribute d * 0.0 (exact no-op).
 BIOIK_DEV F7 linear_tip(ProbPtr pb, int t, const XV& x, const LinModel& lm) {
     const int n_ops = pb->n_ops;
+    const uint32_t active = pb->active_mask;
     const double* tb = lm.tipbase + t * 7;
     double px = tb[0], py = tb[1], pz = tb[2], rx = tb[3], ry = tb[4], rz = tb[5], rw = tb[6];
-    for (int k = 0; k < n_ops; k++)
-        if (pb->ops[k].gene >= 0) {
-            const double* d = lm.delta + ((size_t)t * n_ops + k) * 7;
-            double dv = x(k) - lm.base[k];
-            px += d[0] * dv;
-            py += d[1] * dv;
-            pz += d[2] * dv;
-            rx += d[3] * dv;
-            ry += d[4] * dv;
-            rz += d[5] * dv;
-            rw += d[6] * dv;
+    for (int k0 = 0; k0 < n_ops; k0 += 4) {
+        double dv[4], d[4][7];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int kk = k0 + j < n_ops ? k0 + j : n_ops - 1;
+            const bool on = k0 + j < n_ops && ((active >> kk) & 1u);
+            const double xv = x(kk), bv = lm.base[kk];
+            dv[j] = on ? xv - bv : 0.0;
+            const double* dp = lm.delta + ((size_t)t * n_ops + kk) * 7;
+#pragma unroll
+            for (int c = 0; c < 7; c++) d[j][c] = dp[c];
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            px += d[j][0] * dv[j];
+            py += d[j][1] * dv[j];
+            pz += d[j][2] * dv[j];
+            rx += d[j][3] * dv[j];
+            ry += d[j][4] * dv[j];
+            rz += d[j][5] * dv[j];
+            rw += d[j][6] * dv[j];
+        }
+    }
     return F7{{px, py, pz}, {rx, ry, rz, rw}};
 }
 
@@ -434,34 +456,77 @@ BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames
 //   p0g / p0d / p1d: LDS, op-indexed genes of parent 0 and momentum ("gradients") of parents 0 and 1
 //   xo / go (stride xs / gs): where the child's genes / momentum go; go may be null
 // ---------------------------------------------------------------------------------------------------------
+// four independent Philox2x32-10 streams advanced in lock step: the ten rounds of one stream are a dependent chain of
+// 32x32->64 multiplies, so interleaving four of them gives the in-order wavefront something to issue every cycle
+BIOIK_DEV void philox2x32_10_x4(uint32_t key, const uint32_t (&c0in)[4], uint32_t c1in, uint32_t (&o0)[4], uint32_t (&o1)[4]) {
+    uint32_t c0[4], c1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) c0[j] = c0in[j], c1[j] = c1in;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        if (r > 0) key += 0x9E3779B9u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0[j];
+            uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
+            c0[j] = hi ^ key ^ c1[j];
+            c1[j] = lo;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) o0[j] = c0[j], o1[j] = c1[j];
+}
+
 BIOIK_DEV void reproduce_child(ProbPtr pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
                                double* xo, int xs, double* go, int gs) {
     BIOIK_FP_STRICT
-    const int n_ops = pb->n_ops;
+    const int n_ops = pb->n_ops, D = pb->D;
+    const double fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
+    const double gradient_factor = (double)(child_index % 3u);
     uint32_t r0, r1;
     philox2x32_10(key, rng_ctr0(child_index, RNG_SLOT_RATE), ctr1, r0, r1);
-    double mutation_rate = (double)(1u << (r0 & 15u)) * (1.0 / (double)(1 << 23));
-    double fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
-    double gradient_factor = (double)(child_index % 3u);
-    for (int k = 0; k < n_ops; k++) {
-        if (pb->ops[k].gene >= 0) {
-            philox2x32_10(key, rng_ctr0(child_index, (uint32_t)pb->ops[k].gene), ctr1, r0, r1);
-            double r = rng_gauss(r0, r1);
+    const double mutation_rate = (double)(1u << (r0 & 15u)) * (1.0 / (double)(1 << 23));
+    // genes in blocks of four: four random streams and four gene updates per trip, free of branches so that the
+    // scheduler can interleave them (a padding gene past D recomputes gene D-1 and is not stored)
+    for (int g0 = 0; g0 < D; g0 += 4) {
+        uint32_t c0[4], q0[4], q1[4];
+        int kk[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int g = g0 + j < D ? g0 + j : D - 1;
+            kk[j] = pb->op_of_gene[g];
+            c0[j] = rng_ctr0(child_index, (uint32_t)g);
+        }
+        philox2x32_10_x4(key, c0, ctr1, q0, q1);
+        double gene[4], mom[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kk[j];
+            double r = rng_gauss(q0[j], q1[j]);
             double f = mutation_rate * pb->ops[k].span;
             double parent_gene = p0g[k];
-            double gene = parent_gene;
-            gene += r * f;
+            double gn = parent_gene;
+            gn += r * f;
             double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
-            double g = parent_gradient * gradient_factor;
-            gene += g;
-            gene = fmin(fmax(gene, pb->ops[k].clip_min), pb->ops[k].clip_max);
-            xo[(size_t)k * xs] = gene;
-            if (go) go[(size_t)k * gs] = parent_gradient * (1.0 - 0.3) + (gene - parent_gene) * 0.3;
-        } else {
-            xo[(size_t)k * xs] = p0g[k];  // inactive op: the seed's value, carried by every elite
-            if (go) go[(size_t)k * gs] = 0.0;
+            double g2 = parent_gradient * gradient_factor;
+            gn += g2;
+            gn = fmin(fmax(gn, pb->ops[k].clip_min), pb->ops[k].clip_max);
+            gene[j] = gn;
+            mom[j] = parent_gradient * (1.0 - 0.3) + (gn - parent_gene) * 0.3;
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (g0 + j < D) {
+                xo[(size_t)kk[j] * xs] = gene[j];
+                if (go) go[(size_t)kk[j] * gs] = mom[j];
+            }
     }
+    if (D < n_ops)
+        for (int k = 0; k < n_ops; k++)
+            if (pb->ops[k].gene < 0) {
+                xo[(size_t)k * xs] = p0g[k];  // inactive op: the seed's value, carried by every elite
+                if (go) go[(size_t)k * gs] = 0.0;
+            }
 }
 
 // ---------------------------------------------------------------------------------------------------------

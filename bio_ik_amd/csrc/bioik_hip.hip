@@ -6,6 +6,7 @@
 // hipcc for gfx950 and refuses to do anything without a HIP device.
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -93,7 +94,7 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
-#define BIOIK_SOLVE_WAVES_PER_SIMD 1
+#define BIOIK_SOLVE_WAVES_PER_SIMD 4
 #endif
 __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve(SolveArgs a) {
     extern __shared__ double lds[];
@@ -177,13 +178,15 @@ static int fail(const std::exception& e) {
         return fail(e);              \
     }
 
+// lanes per (query, island).  The two species run concurrently on two lane groups when the workgroup has >= 2 wavefronts;
+// each group gets one lane per child up to 128 lanes (pop=128 -> 256 lanes: 4 wavefronts on the 4 SIMDs of a CU).
 static int solve_threads(const DevSolveParams& sp, uint64_t units) {
-    int t = 64;
+    int t;
     if (const char* e = std::getenv("BIOIK_SOLVE_THREADS")) {
         t = std::atoi(e);
-    } else if (units < 1024) {
-        // few queries: spread one query's children over up to 4 wavefronts
-        while (t < sp.lambda && t < 256) t *= 2;
+    } else {
+        int per_species = sp.lambda >= 128 ? 128 : (sp.lambda > 32 ? 64 : 32);
+        t = 2 * per_species;
     }
     if (t < 64) t = 64;
     t = (t + 63) / 64 * 64;
@@ -200,20 +203,31 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0).total * 8;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0, child_cols, groups).total * 8;
 }
 
-static void launch_solve(bioik_problem* p, const DevSolveParams& sp, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
+static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
                          double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream) {
     if (n == 0) return;
+    DevSolveParams sp = sp_in;
     const DevProblem& dp = p->host.dev;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     int nth = solve_threads(sp, units);
-    while (nth > 64 && lds_bytes(p, nth, sp.lambda) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
-    const size_t lds = lds_bytes(p, nth, sp.lambda);
+    while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
+    // keep every child of a generation in LDS (winners are then read, not re-derived) when that costs <= 32 KiB
+    sp.species_parallel = (nth % 128 == 0) ? 1 : 0;
+    if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && nth % 128 == 0) ? 1 : 0;
+    const int groups = sp.species_parallel ? 2 : 1, G = nth / groups;
+    sp.child_cols = (sp.lambda + G - 1) / G;
+    if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
+        if (std::atoi(e) == 0) sp.child_cols = 1;
+    } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups) > 48 * 1024) {
+        sp.child_cols = 1;
+    }
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
 #if !defined(BIOIK_HOSTSIM)
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -223,6 +237,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp, size_t n, c
     a.sp = sp;
     a.seeds = d_seeds;
     a.params = d_params;
+    a.phase_cycles = nullptr;
+#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+    DevBuf phase_buf(units * 8 * sizeof(unsigned long long));
+    const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
+    if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
+#endif
     if (sp.islands == 1) {
         a.solutions = d_solutions, a.fitness = d_fitness, a.success = d_success, a.steps = d_steps;
     } else {
@@ -241,6 +261,17 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp, size_t n, c
         a.steps = (int32_t*)w;
     }
     LAUNCH(k_solve, solve_body(a, b_, l_), units, nth, lds, stream, a);
+#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+    if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
+        std::vector<unsigned long long> h(units * 8);
+        be_d2h(h.data(), phase_buf.p, h.size() * sizeof(unsigned long long), stream);
+        be_sync(stream);
+        if (FILE* f = std::fopen(phase_path, "wb")) {
+            std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+            std::fclose(f);
+        }
+    }
+#endif
     if (sp.islands > 1) {
         SelectArgs s;
         s.islands = sp.islands, s.V = dp.V, s.n = n;

@@ -20,10 +20,12 @@
 #define BIOIK_HD __host__ __device__ inline
 #endif
 
-struct LdsLayout {  // offsets in doubles
-    int seed, par, pop, sol, xn, gv, frames, tips, delta, base, grad, xcol, slots, red, sec, order, total;
+struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species group (stride g_stride)
+    int seed, par, pop, sol, state, xcol, slots, g_first, g_stride, total;
+    int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
 };
-BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary) {
+BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
+                               int groups = 1) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -31,18 +33,24 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.par = o, o += P > 0 ? P : 1;
     L.pop = o, o += 2 * 2 * 2 * 2 * m;  // [species][buffer][individual][genes|momentum][op]
     L.sol = o, o += m;
-    L.xn = o, o += m;
-    L.gv = o, o += m;
-    L.frames = o, o += m * 7;
-    L.tips = o, o += T * 7;
-    L.delta = o, o += T * m * 7;
-    L.base = o, o += m;
-    L.grad = o, o += m;
-    L.xcol = o, o += m * nthreads;  // genotype columns: [op][lane]
+    L.state = o, o += 2 * 8 + 4;        // species bookkeeping exchanged between the two species groups + workgroup broadcast slots
+    L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
     L.slots = o, o += n_slots * 7 * nthreads;
-    L.red = o, o += 2 * (nthreads / 64) + 2;
-    L.sec = o, o += has_secondary ? lambda : 0;
-    L.order = o, o += has_secondary ? (lambda + 1) / 2 : 0;
+    int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
+    L.xn = g, g += m;
+    L.gv = g, g += m;
+    L.frames = g, g += m * 7;
+    L.tips = g, g += T * 7;
+    L.delta = g, g += T * m * 7;
+    L.base = g, g += m;
+    L.grad = g, g += m;
+    L.red = g, g += 4 * (nthreads / 64) + 4;
+    L.bc = g, g += 4;  // values broadcast from the group's leading wavefront
+    L.sec = g, g += has_secondary ? lambda : 0;
+    L.order = g, g += has_secondary ? (lambda + 1) / 2 : 0;
+    L.g_first = o;
+    L.g_stride = g;
+    o += g * (groups > 0 ? groups : 1);
     L.total = o;
     return L;
 }
@@ -54,26 +62,41 @@ struct Cand {
 };
 BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f < of) || (f == of && pos < opos); }
 
-// all-lanes arg-min of (f,pos) over the workgroup: wave64 xor-butterfly, then one LDS hop across waves
-BIOIK_DEV void argmin_reduce(double& f, int& pos, double* s_red) {
+// all-lanes top-2 of (f,pos) over the workgroup: every lane brings its own best two (b1 <= b2); wave64 xor-butterfly
+// merging sorted pairs, then one LDS hop across waves.  Positions are unique, so (f,pos) is a total order.
+BIOIK_DEV void top2_reduce(double& b1f, int& b1p, double& b2f, int& b2p, double* s_red, int gtid, int G) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        double of = p_shfl_xor(f, m);
-        int op = p_shfl_xor(pos, m);
-        if (cand_better(of, op, f, pos)) f = of, pos = op;
+        double o1f = p_shfl_xor(b1f, m), o2f = p_shfl_xor(b2f, m);
+        int o1p = p_shfl_xor(b1p, m), o2p = p_shfl_xor(b2p, m);
+        if (cand_better(o1f, o1p, b1f, b1p)) {
+            if (cand_better(b1f, b1p, o2f, o2p)) b2f = b1f, b2p = b1p; else b2f = o2f, b2p = o2p;
+            b1f = o1f, b1p = o1p;
+        } else if (cand_better(o1f, o1p, b2f, b2p)) {
+            b2f = o1f, b2p = o1p;
+        }
     }
-    const int nw = p_nthreads() >> 6;
-    if (nw > 1) {
-        const int tid = p_tid();
-        if ((tid & 63) == 0) {
-            s_red[2 * (tid >> 6)] = f;
-            s_red[2 * (tid >> 6) + 1] = (double)pos;
+    const int nw = G >> 6;  // wavefronts of this species group (s_red is the group's own scratch)
+    if ((p_nthreads() >> 6) > 1) {
+        if ((gtid & 63) == 0) {
+            double* d = s_red + 4 * (gtid >> 6);
+            d[0] = b1f, d[1] = (double)b1p, d[2] = b2f, d[3] = (double)b2p;
         }
         p_barrier();
+        b1f = b2f = P_INF;
+        b1p = b2p = 0x7fffffff;
         for (int w = 0; w < nw; w++) {
-            double of = s_red[2 * w];
-            int op = (int)s_red[2 * w + 1];
-            if (cand_better(of, op, f, pos)) f = of, pos = op;
+            const double* d = s_red + 4 * w;
+            for (int i = 0; i < 2; i++) {
+                double of = d[2 * i];
+                int op = (int)d[2 * i + 1];
+                if (cand_better(of, op, b1f, b1p)) {
+                    b2f = b1f, b2p = b1p;
+                    b1f = of, b1p = op;
+                } else if (cand_better(of, op, b2f, b2p)) {
+                    b2f = of, b2p = op;
+                }
+            }
         }
         p_barrier();
     }
@@ -81,15 +104,16 @@ BIOIK_DEV void argmin_reduce(double& f, int& pos, double* s_red) {
 
 // RobotFK::applyConfiguration + initializeMutationApproximator at the (workgroup-shared) individual x:
 // the joint frames are published to LDS by lane 0 (the per-joint frame chain), then lanes fan out over (tip, op).
-BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base) {
-    const int tid = p_tid(), nth = p_nthreads();
+// (gtid, G): index and size of the cooperating lane group (the whole workgroup, or one species group of it)
+BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G) {
     const int n_ops = pb->n_ops, T = pb->T;
-    fk_walk(pb, x, slots, s_frames, [&](int t, const F7& f) {
-        if (tid == 0) f7_store(s_tips + t * 7, f);
-    });
-    for (int k = tid; k < n_ops; k += nth) s_base[k] = x(k);
+    if (gtid < 64)  // one wavefront walks the chain (lane 0 publishes); the others wait at the barrier
+        fk_walk(pb, x, slots, gtid == 0 ? s_frames : nullptr, [&](int t, const F7& f) {
+            if (gtid == 0) f7_store(s_tips + t * 7, f);
+        });
+    for (int k = gtid; k < n_ops; k += G) s_base[k] = x(k);
     p_barrier();
-    for (int idx = tid; idx < T * n_ops; idx += nth) {
+    for (int idx = gtid; idx < T * n_ops; idx += G) {
         int t = idx / n_ops, k = idx - t * n_ops;
         double o[7];
         approximator_entry(pb, t, k, s_frames, s_tips, o);
@@ -108,6 +132,7 @@ struct SolveArgs {
     double* fitness;        // [n*islands]   ranking fitness of ik_parallel.h:229-246
     int32_t* success;       // [n*islands]
     int32_t* steps;         // [n*islands]
+    unsigned long long* phase_cycles;  // [n*islands][8] or null: per-phase shader cycles (builds with -DBIOIK_PHASE_TIMING)
 };
 
 struct SpeciesState {
@@ -127,28 +152,37 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int lambda = sp.lambda;
     const bool has_sec = pb->n_secondary > 0;
     const bool exact = sp.fk_mode == FK_EXACT;
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec);
+    const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
+    // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
+    // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
+    const int groups = sp.species_parallel ? 2 : 1;
+    const int G = nth / groups;        // lanes per species group (a multiple of 64)
+    const int grp = tid / G, gtid = tid - grp * G;
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec, n_cols, groups);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
     double* s_sol = lds + L.sol;
-    double* s_xn = lds + L.xn;
-    double* s_gv = lds + L.gv;
-    double* s_frames = lds + L.frames;
-    double* s_tips = lds + L.tips;
-    double* s_delta = lds + L.delta;
-    double* s_base = lds + L.base;
-    double* s_grad = lds + L.grad;
+    double* s_state = lds + L.state;
     double* s_slots = lds + L.slots;
-    double* s_red = lds + L.red;
-    double* s_sec = lds + L.sec;
-    int32_t* s_order = (int32_t*)(lds + L.order);
-    double* xcol = lds + L.xcol + tid;  // this lane's genotype column, stride nth
-    const XV xl{xcol, nth};
+    double* gbase = lds + L.g_first + grp * L.g_stride;  // this group's scratch
+    double* s_xn = gbase + L.xn;
+    double* s_gv = gbase + L.gv;
+    double* s_frames = gbase + L.frames;
+    double* s_tips = gbase + L.tips;
+    double* s_delta = gbase + L.delta;
+    double* s_base = gbase + L.base;
+    double* s_grad = gbase + L.grad;
+    double* s_red = gbase + L.red;
+    double* s_sec = gbase + L.sec;
+    int32_t* s_order = (int32_t*)(gbase + L.order);
     const int M = n_ops > 0 ? n_ops : 1;
+    double* xcol = lds + L.xcol + tid;  // this lane's genotype column(s): [col][op][lane], stride nth
+    const XV xl{xcol, nth};
     const int SP = 2 * 2 * 2 * M;  // doubles per species in s_pop
     const int BF = 4 * M;          // doubles per buffer: [ind0 genes][ind0 momentum][ind1 genes][ind1 momentum]
 
+    PHASE_DECL;
     const uint64_t q = unit / (uint64_t)sp.islands;
     const uint32_t island = (uint32_t)(unit % (uint64_t)sp.islands);
     for (int i = tid; i < V; i += nth) s_seed[i] = a.seeds[q * V + i];
@@ -157,6 +191,35 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const QueryCtx qc{s_seed, s_par};
     const LinModel lm{s_tips, s_delta, s_base};
     const uint32_t key = rng_query_key(sp.random_seed, sp.first_query + q, island);
+    // Values every lane needs but one wavefront can compute (fitness of an elite, of the solution ...): the leading
+    // wavefront of the species group / of the workgroup evaluates and publishes through LDS; the other wavefronts sleep
+    // at the barrier instead of spending issue slots of their SIMDs on identical copies.
+    double* s_bc = gbase + L.bc;
+    double* s_wbc = s_state + 16;
+    const bool glead = gtid < 64, wlead = tid < 64;
+    auto group_value = [&](auto&& fn) -> double {
+        double v = 0.0;
+        if (glead) v = fn();
+        if (G > 64) {
+            if (gtid == 0) s_bc[0] = v;
+            p_barrier();
+            v = s_bc[0];
+            p_barrier();
+        }
+        return v;
+    };
+    auto wg_check = [&](const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
+        FitCheck fc{0.0, 0};
+        if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check);
+        if (nth > 64) {
+            if (tid == 0) s_wbc[0] = fc.fitness, s_wbc[1] = (double)fc.ok;
+            p_barrier();
+            fc.fitness = s_wbc[0];
+            fc.ok = (int)s_wbc[1];
+            p_barrier();
+        }
+        return fc;
+    };
 
     // ik_evolution_2.cpp:129-179: solution = seed, 2 species x 2 clones of the seed, zero momentum.
     // Inactive ops carry the seed's value in every vector, so the chain walk never distinguishes them.
@@ -170,22 +233,24 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         s_sol[k] = v;
     }
     p_barrier();
-    double sol_fit = exact_fitness_check(pb, XV{s_sol, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
+    double sol_fit = wg_check(XV{s_sol, 1}, 0.0, 0.0, 0.0, 0).fitness;
     SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0};
+    const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
+    PHASE_MARK(PH_INIT);
 
     int steps = 0;
     bool success = false;
     double final_fit = BIOIK_DBL_MAX;
     for (int step = 0; step < sp.max_steps; step++) {
-        for (int rank = 0; rank < 2; rank++) {
+        for (int rank = rank_begin; rank < rank_end; rank++) {
             SpeciesState S = rank == 0 ? A : B;
             double* popS = s_pop + S.slot * SP;
             if (!exact) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
                 const double* cb = popS + S.cur * BF;
-                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base);
-                S.pf0 = eval_linear_primary(pb, XV{cb, 1}, qc, lm);
-                S.pf1 = eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm);
+                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G);
+                S.pf0 = group_value([&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
+                S.pf1 = group_value([&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
             }
             for (int gen = 0; gen < sp.generations; gen++) {
                 const double* cb = popS + S.cur * BF;
@@ -195,12 +260,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 int n_eval = lambda;
                 if (has_sec) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
-                    for (int c = tid; c < lambda; c += nth) {
+                    for (int c = gtid; c < lambda; c += G) {
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
                         s_sec[c] = secondary_fitness(pb, xl, qc);
                     }
                     p_barrier();
-                    for (int c = tid; c < lambda; c += nth) {
+                    for (int c = gtid; c < lambda; c += G) {
                         double my = s_sec[c];
                         int r = 0;
                         for (int j = 0; j < lambda; j++) {
@@ -213,14 +278,20 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     uint32_t o0, o1;
                     philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
                     n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
+                    PHASE_MARK(PH_PRESELECT);
                 }
-                // genotype -> phenotype -> fitness (:391-407): lane r scores the child at sorted position r
+                // genotype -> phenotype -> fitness (:391-407): lane r of the group scores the child at sorted position r
                 double b1f = P_INF, b2f = P_INF;
                 int b1p = 0x7fffffff, b2p = 0x7fffffff;
-                for (int r = tid; r < n_eval; r += nth) {
+                const bool stored = n_cols * G >= lambda;  // every child keeps its own column until selection
+                for (int r = gtid, j = 0; r < n_eval; r += G, j++) {
                     int c = has_sec ? s_order[r] : r;
-                    reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
-                    double f = exact ? eval_exact_primary(pb, xl, qc, s_slots) : eval_linear_primary(pb, xl, qc, lm);
+                    double* xc = stored ? xcol + (size_t)j * M * nth : xcol;
+                    const XV xv{xc, nth};
+                    reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xc, nth, nullptr, 0);
+                    PHASE_MARK(PH_REPRODUCE);
+                    double f = exact ? eval_exact_primary(pb, xv, qc, s_slots) : eval_linear_primary(pb, xv, qc, lm);
+                    PHASE_MARK(PH_FITNESS);
                     int pos = r + 2;
                     if (cand_better(f, pos, b1f, b1p)) {
                         b2f = b1f, b2p = b1p;
@@ -230,28 +301,42 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
-                double cf = b1f;
-                int cp = b1p;
-                argmin_reduce(cf, cp, s_red);
+                top2_reduce(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 Cand first{S.pf0, 0, 0};
                 if (cand_better(S.pf1, 1, first.f, first.pos)) first = Cand{S.pf1, 1, 1};
-                if (cand_better(cf, cp, first.f, first.pos)) first = Cand{cf, cp, cp};
-                double c2f = (b1p == first.id) ? b2f : b1f;
-                int c2p = (b1p == first.id) ? b2p : b1p;
-                argmin_reduce(c2f, c2p, s_red);
+                if (cand_better(b1f, b1p, first.f, first.pos)) first = Cand{b1f, b1p, b1p};
+                const double c2f = (b1p == first.id) ? b2f : b1f;
+                const int c2p = (b1p == first.id) ? b2p : b1p;
                 Cand second{P_INF, 0x7fffffff, -1};
                 if (first.id != 0) second = Cand{S.pf0, first.pos, 0};  // parent 0 was swapped to the winner's position
                 if (first.id != 1 && (second.id < 0 || cand_better(S.pf1, 1, second.f, second.pos))) second = Cand{S.pf1, 1, 1};
                 if (second.id < 0 || cand_better(c2f, c2p, second.f, second.pos)) second = Cand{c2f, c2p, c2p};
-                // the winners become the elites; a winning child is re-derived from the RNG by lane 0, not fetched
+                // the winners become the elites (written to the species' other buffer)
                 double* nb = popS + (S.cur ^ 1) * BF;
                 for (int i = 0; i < 2; i++) {
                     const int id = i == 0 ? first.id : second.id;
                     double* dst = nb + i * 2 * M;
                     if (id < 2) {
                         const double* src = cb + id * 2 * M;
-                        for (int k = tid; k < 2 * M; k += nth) dst[k] = src[k];
-                    } else if (tid == 0) {
+                        for (int k = gtid; k < 2 * M; k += G) dst[k] = src[k];
+                    } else if (stored) {
+                        // the winner's genes are still in its owner's column; its momentum follows from the genes
+                        // (ik_evolution_2.cpp:299: gradient = mix(parent_gradient, gene - parent_gene, 0.3))
+                        BIOIK_FP_STRICT
+                        const int r = id - 2;
+                        const int c = has_sec ? s_order[r] : r;
+                        const double fmix = (((uint32_t)c + 2u) % 2u == 0u) ? 0.2 : 0.0;
+                        const double* src = (lds + L.xcol) + (size_t)(r / G) * M * nth + (grp * G + r % G);
+                        for (int k = gtid; k < n_ops; k += G) {
+                            double gene = src[(size_t)k * nth];
+                            double mom = 0.0;
+                            if (pb->ops[k].gene >= 0) {
+                                double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
+                                mom = parent_gradient * (1.0 - 0.3) + (gene - p0g[k]) * 0.3;
+                            }
+                            dst[k] = gene, dst[M + k] = mom;
+                        }
+                    } else if (gtid == 0) {  // not stored: re-derive the child from the counter RNG
                         int c = has_sec ? s_order[id - 2] : id - 2;
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, dst, 1, dst + M, 1);
                     }
@@ -260,84 +345,111 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 S.pf0 = first.f;
                 S.pf1 = second.f;
                 p_barrier();
+                PHASE_MARK(PH_SELECTION);
             }
 
-            // memetic phase on the elite (:436-570)
+            // memetic phase on the elite (:436-570).  The workgroup barriers inside are executed a fixed number of times
+            // per iteration whether or not this species is still descending, so that two species groups stay in step.
             if (sp.memetic) {
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
-                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base);  // fresh linearisation at the elite
+                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G);  // fresh linearisation at the elite
                 double dp = 0.0000001;
                 {
                     uint32_t o0, o1;
                     philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)S.id, RNG_MEMETIC_SIGN), o0, o1);
                     if (rng_uniform(o0, o1) < 0.5) dp = -dp;
                 }
-                const int my_op = tid < D ? pb->op_of_gene[tid] : -1;  // lane i differentiates gene i
+                const int my_op = gtid < D ? pb->op_of_gene[gtid] : -1;  // lane i of the group differentiates gene i
+                bool live = true;  // still descending; the leading wavefront of the group does the arithmetic
                 for (int it = 0; it < 8; it++) {
-                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
-                    double f2p = 0.0, fbp = 0.0;
-                    for (int t = 0; t < T; t++) {
-                        F7 f = linear_tip(pb, t, xe, lm);
-                        f2p += tip_goals(pb, t, f, xe, qc);
+                    double f2p = 0.0, fa = 0.0;
+                    if (live && glead) {
+                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
+                        double fbp = 0.0;
+                        for (int t = 0; t < T; t++) {
+                            F7 f = linear_tip(pb, t, xe, lm);
+                            f2p += tip_goals(pb, t, f, xe, qc);
+                            if (my_op >= 0) {
+                                const double* d = s_delta + ((size_t)t * n_ops + my_op) * 7;  // computeApproximateMutation1
+                                F7 f3 = F7{{f.p.x + d[0] * dp, f.p.y + d[1] * dp, f.p.z + d[2] * dp},
+                                           {f.q.x + d[3] * dp, f.q.y + d[4] * dp, f.q.z + d[5] * dp, f.q.w + d[6] * dp}};
+                                fbp += tip_goals(pb, t, f3, xl, qc);
+                            }
+                        }
+                        f2p += nonlink_primary(pb, xe, qc);
+                        fa = f2p + secondary_fitness(pb, xe, qc);
                         if (my_op >= 0) {
-                            const double* d = s_delta + ((size_t)t * n_ops + my_op) * 7;  // computeApproximateMutation1
-                            F7 f3 = F7{{f.p.x + d[0] * dp, f.p.y + d[1] * dp, f.p.z + d[2] * dp},
-                                       {f.q.x + d[3] * dp, f.q.y + d[4] * dp, f.q.z + d[5] * dp, f.q.w + d[6] * dp}};
-                            fbp += tip_goals(pb, t, f3, xl, qc);
+                            fbp += nonlink_primary(pb, xl, qc);
+                            double fb = fbp + secondary_fitness(pb, xl, qc);
+                            s_grad[gtid] = fb - fa;
                         }
                     }
-                    f2p += nonlink_primary(pb, xe, qc);
-                    const double fa = f2p + secondary_fitness(pb, xe, qc);
-                    if (my_op >= 0) {
-                        fbp += nonlink_primary(pb, xl, qc);
-                        double fb = fbp + secondary_fitness(pb, xl, qc);
-                        s_grad[tid] = fb - fa;
+                    p_barrier();
+                    if (live && glead) {
+                        double sum = dp * dp;  // :477-482
+                        for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
+                        const double fnorm = 1.0 / sum * dp;
+                        for (int k = gtid; k < n_ops; k += 64) s_gv[k] = pb->ops[k].gene >= 0 ? s_grad[pb->ops[k].gene] * fnorm : 0.0;
                     }
                     p_barrier();
-                    double sum = dp * dp;  // :477-482
-                    for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
-                    const double fnorm = 1.0 / sum * dp;
-                    for (int k = tid; k < n_ops; k += nth) s_gv[k] = pb->ops[k].gene >= 0 ? s_grad[pb->ops[k].gene] * fnorm : 0.0;
-                    p_barrier();
-                    // support points x-g (even lanes) and x+g (odd lanes), :485-495
-                    const double sgn = (lane & 1) ? 1.0 : -1.0;
-                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * s_gv[k];
-                    double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
-                    const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
-                    double step_size;
-                    if (sp.memetic == 'q') {  // :498-539
-                        double v1 = f2 - f1, v2 = f3 - f2;
-                        double v = (v1 + v2) * 0.5, aa = v1 - v2;
-                        step_size = v / aa;
-                    } else {  // 'l' :545-568
-                        double cost_diff = (f3 - f1) * 0.5;
-                        step_size = -(f2 / cost_diff);
+                    if (live && glead) {
+                        // support points x-g (even lanes) and x+g (odd lanes), :485-495
+                        const double sgn = (lane & 1) ? 1.0 : -1.0;
+                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * s_gv[k];
+                        double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
+                        const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
+                        double step_size;
+                        if (sp.memetic == 'q') {  // :498-539
+                            double v1 = f2 - f1, v2 = f3 - f2;
+                            double v = (v1 + v2) * 0.5, aa = v1 - v2;
+                            step_size = v / aa;
+                        } else {  // 'l' :545-568
+                            double cost_diff = (f3 - f1) * 0.5;
+                            step_size = -(f2 / cost_diff);
+                        }
+                        for (int k = gtid; k < n_ops; k += 64)
+                            s_xn[k] = pb->ops[k].gene >= 0 ? fmin(fmax(el[k] + s_gv[k] * step_size, pb->ops[k].clip_min), pb->ops[k].clip_max) : el[k];
                     }
-                    for (int k = tid; k < n_ops; k += nth)
-                        s_xn[k] = pb->ops[k].gene >= 0 ? fmin(fmax(el[k] + s_gv[k] * step_size, pb->ops[k].clip_min), pb->ops[k].clip_max) : el[k];
                     p_barrier();
-                    const double f4p = eval_linear_primary(pb, XV{s_xn, 1}, qc, lm);
-                    if (!(f4p < f2p)) break;
+                    if (live && glead) {
+                        const double f4p = eval_linear_primary(pb, XV{s_xn, 1}, qc, lm);
+                        if (!(f4p < f2p)) live = false;  // accept iff the primary fitness improves, else stop (:527-538)
+                    }
+                    if (gtid == 0) s_bc[1] = live ? 1.0 : 0.0;
                     p_barrier();
-                    for (int k = tid; k < n_ops; k += nth) el[k] = s_xn[k];
+                    live = s_bc[1] != 0.0;
+                    if (live)
+                        for (int k = gtid; k < n_ops; k += G) el[k] = s_xn[k];
                     p_barrier();
+                    if (groups == 1 && !live) break;  // a single group need not keep the barrier count of a partner
                 }
                 p_barrier();
+                PHASE_MARK(PH_MEMETICS);
+            }
+            // species ranking fitness: exact FK of the elite (:607-614)
+            {
+                const double* cb = popS + S.cur * BF;
+                double fit = group_value([&]() { return exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness; });
+                S.improved = (fit != S.fit) ? 1 : 0;
+                S.fit = fit;
+                S.pf0 = fit;
             }
             if (rank == 0) A = S; else B = S;
         }
-
-        // species management (:604-645)
-        for (int rank = 0; rank < 2; rank++) {
-            SpeciesState S = rank == 0 ? A : B;
-            const double* cb = s_pop + S.slot * SP + S.cur * BF;
-            double fit = exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
-            S.improved = (fit != S.fit) ? 1 : 0;
-            S.fit = fit;
-            S.pf0 = fit;
-            if (rank == 0) A = S; else B = S;
+        if (groups == 2) {  // each group publishes its species' bookkeeping, everybody reads both
+            if (gtid == 0) {
+                const SpeciesState& S = grp == 0 ? A : B;
+                double* d = s_state + grp * 8;
+                d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved;
+            }
+            p_barrier();
+            A = SpeciesState{s_state[0], s_state[1], s_state[2], (int)s_state[3], (int)s_state[4], (int)s_state[5], (int)s_state[6]};
+            B = SpeciesState{s_state[8], s_state[9], s_state[10], (int)s_state[11], (int)s_state[12], (int)s_state[13], (int)s_state[14]};
+            p_barrier();
         }
+
+        // species management (:617-645)
         if (B.fit < A.fit) {
             SpeciesState tmp = A;
             A = B;
@@ -364,10 +476,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     cb[2 * M + k] = v, cb[3 * M + k] = 0.0;
                 }
                 p_barrier();
-                if (exact) B.pf0 = B.pf1 = exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness;
+                if (exact) B.pf0 = B.pf1 = wg_check(XV{cb, 1}, 0.0, 0.0, 0.0, 0).fitness;
             }
         }
         steps++;
+        PHASE_MARK(PH_SPECIES);
         if (A.fit < sol_fit) {
             const double* cb = s_pop + A.slot * SP + A.cur * BF;
             p_barrier();
@@ -376,11 +489,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             p_barrier();
         }
         // ik_parallel.h:173-181: exact FK of the solution, success test, fitness
-        FitCheck fc = exact_fitness_check(pb, XV{s_sol, 1}, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1);
+        FitCheck fc = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
         final_fit = fc.fitness;
         success = fc.ok != 0;
+        PHASE_MARK(PH_CHECK);
         if (success) break;
     }
+    PHASE_DUMP(a.phase_cycles, unit);
 
     // result of this island; ranking fitness of ik_parallel.h:229-246
     double rank_fit = final_fit;
@@ -485,11 +600,12 @@ BIOIK_DEV void eval_fitness_body(const EvalArgs& a, uint64_t block, double* lds)
     load_query(a, lds + L.seed, lds + L.par);
     const QueryCtx qc{lds + L.seed, lds + L.par};
     if (a.fk_mode == FK_LINEAR) {
-        if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.xn, 1);
+        if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.g_first + L.xn, 1);
         p_barrier();
-        build_approximator(pb, XV{lds + L.xn, 1}, lds + L.slots, lds + L.frames, lds + L.tips, lds + L.delta, lds + L.base);
+        build_approximator(pb, XV{lds + L.g_first + L.xn, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
+                           lds + L.g_first + L.base, tid, nth);
     }
-    const LinModel lm{lds + L.tips, lds + L.delta, lds + L.base};
+    const LinModel lm{lds + L.g_first + L.tips, lds + L.g_first + L.delta, lds + L.g_first + L.base};
     uint64_t i = block * (uint64_t)nth + tid;
     if (i >= a.n) return;
     double* xcol = lds + L.xcol + tid;
@@ -505,17 +621,18 @@ BIOIK_DEV void eval_approximator_body(const EvalArgs& a, double* lds) {
     const int tid = p_tid(), nth = p_nthreads();
     const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
     load_query(a, lds + L.seed, lds + L.par);
-    if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.xn, 1);
+    if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.g_first + L.xn, 1);
     p_barrier();
-    build_approximator(pb, XV{lds + L.xn, 1}, lds + L.slots, lds + L.frames, lds + L.tips, lds + L.delta, lds + L.base);
+    build_approximator(pb, XV{lds + L.g_first + L.xn, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
+                           lds + L.g_first + L.base, tid, nth);
     const int T = pb->T, D = pb->D, n_ops = pb->n_ops;
     for (int idx = tid; idx < T * 7; idx += nth) {
         int t = idx / 7, c = idx - t * 7;
-        a.out0[pb->tips[t].out_index * 7 + c] = lds[L.tips + idx];
+        a.out0[pb->tips[t].out_index * 7 + c] = lds[L.g_first + L.tips + idx];
     }
     for (int idx = tid; idx < T * D * 7; idx += nth) {
         int t = idx / (D * 7), rem = idx - t * D * 7, g = rem / 7, c = rem - g * 7;
-        a.out1[((size_t)pb->tips[t].out_index * D + g) * 7 + c] = lds[L.delta + ((size_t)t * n_ops + pb->op_of_gene[g]) * 7 + c];
+        a.out1[((size_t)pb->tips[t].out_index * D + g) * 7 + c] = lds[L.g_first + L.delta + ((size_t)t * n_ops + pb->op_of_gene[g]) * 7 + c];
     }
 }
 

@@ -76,6 +76,28 @@ BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 #define P_INF (__builtin_inf())
 #endif
 
+// Phase profiler (the reference's BLOCKPROFILER taxonomy, src/ik_evolution_2.cpp:330-437,605): compiled in only with
+// -DBIOIK_PHASE_TIMING; lane 0 of the workgroup accumulates shader-clock cycles per phase.
+#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+#define PHASE_DECL unsigned long long ph_t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last_ = __builtin_readcyclecounter()
+#define PHASE_MARK(i)                                          \
+    do {                                                       \
+        unsigned long long now_ = __builtin_readcyclecounter(); \
+        ph_t_[i] += now_ - ph_last_;                           \
+        ph_last_ = now_;                                       \
+    } while (0)
+#define PHASE_DUMP(ptr, unit)                                                       \
+    do {                                                                            \
+        if ((ptr) && p_tid() == 0)                                                  \
+            for (int i_ = 0; i_ < 8; i_++) (ptr)[(unit) * 8 + i_] = ph_t_[i_];      \
+    } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#define PHASE_DUMP(ptr, unit)
+#endif
+enum { PH_INIT = 0, PH_REPRODUCE = 1, PH_FITNESS = 2, PH_SELECTION = 3, PH_MEMETICS = 4, PH_SPECIES = 5, PH_CHECK = 6, PH_PRESELECT = 7 };
+
 // sin/cos of the joint half angles: the shared bit-reproducible implementation (bioik_sincos.h)
 #define BIOIK_SINCOS_FN BIOIK_DEV
 #include "bioik_sincos.h"

@@ -68,7 +68,7 @@ struct DevProblem {
     int32_t n_primary;
     int32_t n_secondary;
     int32_t n_slots;
-    int32_t pad;
+    uint32_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
     int32_t op_of_gene[BIOIK_MAX_OPS];
     int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
     DevOp ops[BIOIK_MAX_OPS];
@@ -89,5 +89,8 @@ struct DevSolveParams {
     int32_t max_steps;
     int32_t no_wipeout;
     int32_t generations;        // 8 (memetic) or 16 (ik_evolution_2.cpp:349-351)
-    int32_t pad;
+    int32_t child_cols;         // genotype columns per lane: ceil(lambda / lanes) = every child of a generation stays in LDS
+                                // until selection; 1 = only the lane's current child (winners are re-derived from the RNG)
+    int32_t species_parallel;   // 1: the workgroup splits into two lane groups, one species each, running concurrently
+    int32_t pad2;
 };

@@ -64,12 +64,21 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     pc.trajectory(gpus[cfg], oracles[cfg], templates[cfg], n=24, pop=pop, steps_list=(1, 4, 12), **kw)
 
 
-@pytest.mark.parametrize("threads", ["64", "128", "256"])
-def test_trajectory_independent_of_workgroup_shape(gpus, oracles, templates, threads, monkeypatch):
-    """the same solve with 1, 2 and 4 wavefronts per query"""
-    monkeypatch.setenv("BIOIK_SOLVE_THREADS", threads)
+@pytest.mark.parametrize("env", [
+    {"BIOIK_SOLVE_THREADS": "64"},                                        # one wavefront, species one after the other
+    {"BIOIK_SOLVE_THREADS": "128"},                                       # one wavefront per species, concurrently
+    {"BIOIK_SOLVE_THREADS": "256"},                                       # two wavefronts per species
+    {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_SPECIES_PARALLEL": "0"},  # four wavefronts, species one after the other
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_STORE_CHILDREN": "0"},    # winners re-derived from the RNG
+    {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+])
+def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
+    """the same solve under every lane <-> work mapping the launcher can choose"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=16, pop=128, steps_list=(6,))
     pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=8, pop=100, steps_list=(3,))
+    pc.trajectory(gpus["c4"], oracles["c4"], templates["c4"], n=4, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
 def test_full_batch_c2_result_level(gpus, oracles, templates):

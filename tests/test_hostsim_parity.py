@@ -59,8 +59,22 @@ def test_trajectory_bit_exact(sims, oracles, templates, cfg, pop, kw):
 
 
 def test_trajectory_two_wavefronts_and_islands(sims, oracles, templates, monkeypatch):
+    """128 lanes: the two species run concurrently on one wavefront each, two children per lane kept in LDS"""
     monkeypatch.setenv("BIOIK_SOLVE_THREADS", "128")
     pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(2,), islands=2)
+
+
+@pytest.mark.parametrize("env", [
+    {"BIOIK_SOLVE_THREADS": "128"},                                      # species-parallel + secondary pre-selection + memetic
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_STORE_CHILDREN": "0"},   # winners re-derived from the RNG instead of read back
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_SPECIES_PARALLEL": "0"}, # two wavefronts, species one after the other
+    {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+])
+def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=70, steps_list=(2,))
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
 def test_edge_cases(sims, oracles, templates):
