@@ -156,6 +156,31 @@ def main():
                      "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6)"},
     }
 
+    # Secondary measurement (north-star layout): the population genotype array resident in HBM, genes [unit][D][pop]
+    # (individual index fastest), one launch = exact-FK fitness of every individual.  Reported next to the solver line;
+    # it is not what `value` measures.
+    if rank == 0 and world == 1 and os.environ.get("BIOIK_BENCH_STREAM", "1") != "0":
+        units = 16384
+        g = torch.rand((units, D, POP), dtype=torch.float64, device=dev) * 2.0 - 1.0
+        f = torch.empty((units, POP), dtype=torch.float64, device=dev)
+        us = d_seeds[torch.arange(units, device=dev) % BATCH].contiguous()
+        up = d_params[torch.arange(units, device=dev) % BATCH].contiguous()
+        for _ in range(2):
+            h.stream_fitness_device(units, POP, us.data_ptr(), up.data_ptr(), g.data_ptr(), f.data_ptr(), stream.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record(stream)
+        for _ in range(reps):
+            h.stream_fitness_device(units, POP, us.data_ptr(), up.data_ptr(), g.data_ptr(), f.data_ptr(), stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        sbytes = units * POP * 8 * (D + 1) + units * 8 * (V + h.P)
+        out["streamed_fitness"] = {"kernel": "k_stream_fitness", "individuals_per_launch": units * POP, "ms": ms,
+                                   "evaluations_per_s": units * POP / (ms * 1e-3), "algorithmic_bytes_per_launch": sbytes,
+                                   "achieved_GBps": sbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": sbytes / (ms * 1e-3) / HBM_PEAK,
+                                   "layout": "genes [unit][D][pop] f64 in HBM, 512-byte segments per wavefront load"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc
         o = orc.Oracle(template, kind="ref")  # reference Release flags, libm trigonometry

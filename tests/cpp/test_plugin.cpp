@@ -1,0 +1,119 @@
+// C++ driver of the plugin mirror (bio_ik_amd/cpp): FK -> IK -> FK round trip through searchPositionIK /
+// searchPositionIKBatch on a PR2-like right arm, error-code conventions, user goals through BioIKKinematicsQueryOptions.
+// Linked against libbioik_hip.so on a GPU box, or against the host simulator of the kernels in the CPU suite.
+#include <cstdio>
+#include <random>
+
+#include <bio_ik/kinematics_plugin.h>
+
+using namespace bio_ik_kinematics_plugin;
+
+static bio_ik::RobotModel pr2Arm() {
+    bio_ik::RobotModel m;
+    const double z[3] = {0, 0, 0}, ax[3] = {1, 0, 0}, ay[3] = {0, 1, 0}, az[3] = {0, 0, 1};
+    m.addLink("base_footprint", "", "", "fixed", z, z, az);
+    m.addLink("base_link", "base_footprint", "base_footprint_joint", "fixed", {0, 0, 0.051}, z, az);
+    m.addLink("torso_lift_link", "base_link", "torso_lift_joint", "prismatic", {-0.05, 0, 0.739675}, z, az, 0.0, 0.33, 0.013);
+    m.addLink("r_shoulder_pan_link", "torso_lift_link", "r_shoulder_pan_joint", "revolute", {0, -0.188, 0}, z, az, -2.2854, 0.7146, 2.088);
+    m.addLink("r_shoulder_lift_link", "r_shoulder_pan_link", "r_shoulder_lift_joint", "revolute", {0.1, 0, 0}, z, ay, -0.5236, 1.3963, 2.082);
+    m.addLink("r_upper_arm_roll_link", "r_shoulder_lift_link", "r_upper_arm_roll_joint", "revolute", z, z, ax, -3.9, 0.8, 3.27);
+    m.addLink("r_upper_arm_link", "r_upper_arm_roll_link", "r_upper_arm_joint", "fixed", z, z, az);
+    m.addLink("r_elbow_flex_link", "r_upper_arm_link", "r_elbow_flex_joint", "revolute", {0.4, 0, 0}, z, ay, -2.3213, 0.0, 3.3);
+    m.addLink("r_forearm_roll_link", "r_elbow_flex_link", "r_forearm_roll_joint", "continuous", z, z, ax, 0, 0, 3.6);
+    m.addLink("r_forearm_link", "r_forearm_roll_link", "r_forearm_joint", "fixed", z, z, az);
+    m.addLink("r_wrist_flex_link", "r_forearm_link", "r_wrist_flex_joint", "revolute", {0.321, 0, 0}, z, ay, -2.18, 0.0, 3.078);
+    m.addLink("r_wrist_roll_link", "r_wrist_flex_link", "r_wrist_roll_joint", "continuous", z, z, ax, 0, 0, 3.6);
+    m.addChainGroup("right_arm", "torso_lift_link", "r_wrist_roll_link");
+    return m;
+}
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+int main() {
+    bio_ik::RobotModel rm = pr2Arm();
+    BioIKKinematicsPlugin plugin;
+    BioIKParams params;
+    params.gpu_population = 16, params.gpu_fk = "linear", params.gpu_max_steps = 60, params.random_seed = 3;
+    CHECK(plugin.initialize(rm, "right_arm", "torso_lift_link", {"r_wrist_roll_link"}, 0.0, params));
+    CHECK(plugin.getJointNames().size() == 7 && plugin.getJointNames()[0] == "r_shoulder_pan_joint");
+    CHECK(plugin.getLinkNames().size() == 1 && plugin.supportsGroup(nullptr));
+    {
+        std::vector<geometry_msgs::Pose> poses;
+        CHECK(!plugin.getPositionFK({}, {}, poses));
+    }
+    // targets: FK of random valid configurations, expressed in the base frame of the group (reference README.md:404-447)
+    std::mt19937 rng(5);
+    auto uniform = [&](double lo, double hi) { return std::uniform_real_distribution<double>(lo, hi)(rng); };
+    const int n = 2;
+    std::vector<std::vector<geometry_msgs::Pose>> poses(n);
+    std::vector<std::vector<double>> seeds(n);
+    std::vector<int> gv;
+    for (auto& name : plugin.getJointNames()) gv.push_back(rm.variableIndex(name));
+    double base[7], inv[7];
+    rm.linkTransform(rm.linkIndex("torso_lift_link"), rm.defaultPositions(), base);
+    double iq[4] = {-base[3], -base[4], -base[5], base[6]}, np[3] = {-base[0], -base[1], -base[2]}, ip[3];
+    bio_ik::RobotModel::rotate(iq, np, ip);
+    for (int c = 0; c < 3; c++) inv[c] = ip[c];
+    for (int c = 0; c < 4; c++) inv[3 + c] = iq[c];
+    std::vector<std::vector<double>> want(n, std::vector<double>(7));
+    for (int k = 0; k < n; k++) {
+        std::vector<double> target = rm.defaultPositions();
+        for (int v : gv) target[v] = uniform(rm.var_min[v], rm.var_max[v]);
+        double tip[7], rel[7];
+        rm.linkTransform(rm.linkIndex("r_wrist_roll_link"), target, tip);
+        for (int c = 0; c < 7; c++) want[k][c] = tip[c];
+        bio_ik::RobotModel::concat(inv, tip, rel);
+        geometry_msgs::Pose p;
+        p.position.x = rel[0], p.position.y = rel[1], p.position.z = rel[2];
+        p.orientation.x = rel[3], p.orientation.y = rel[4], p.orientation.z = rel[5], p.orientation.w = rel[6];
+        poses[k].push_back(p);
+        for (int v : gv) seeds[k].push_back(std::min(std::max(target[v] + uniform(-0.2, 0.2), rm.var_min[v]), rm.var_max[v]));
+    }
+    std::vector<std::vector<double>> sols;
+    std::vector<moveit_msgs::MoveItErrorCodes> codes;
+    CHECK(plugin.searchPositionIKBatch(poses, seeds, sols, codes));
+    for (int k = 0; k < n; k++) {
+        CHECK(codes[k].val == moveit_msgs::MoveItErrorCodes::SUCCESS && sols[k].size() == 7);
+        std::vector<double> st = rm.defaultPositions();
+        for (size_t i = 0; i < gv.size(); i++) st[gv[i]] = sols[k][i];
+        double got[7];
+        rm.linkTransform(rm.linkIndex("r_wrist_roll_link"), st, got);
+        double dp = 0, dot = 0;
+        for (int c = 0; c < 3; c++) dp += (got[c] - want[k][c]) * (got[c] - want[k][c]);
+        for (int c = 3; c < 7; c++) dot += got[c] * want[k][c];
+        CHECK(std::sqrt(dp) < 1e-4 && 2 * std::acos(std::min(1.0, std::fabs(dot))) < 1e-3);  // north-star tolerance
+    }
+    // single-query form + callback semantics (kinematics_plugin.cpp:644-649)
+    std::vector<double> solution;
+    moveit_msgs::MoveItErrorCodes code;
+    CHECK(plugin.searchPositionIK(poses[0][0], seeds[0], 0.005, solution, code) && code.val == moveit_msgs::MoveItErrorCodes::SUCCESS);
+    CHECK(solution == sols[0]);  // deterministic: same query, same stream
+    IKCallbackFn reject = [](const geometry_msgs::Pose&, const std::vector<double>&, moveit_msgs::MoveItErrorCodes& e) { e.val = moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION; };
+    CHECK(!plugin.searchPositionIK(poses[0][0], seeds[0], 0.005, solution, reject, code));
+    // unreachable goal: NO_IK_SOLUTION unless approximate solutions are allowed (:638-641); a tiny budget keeps it short
+    BioIKKinematicsPlugin quick;
+    params.gpu_max_steps = 2;
+    CHECK(quick.initialize(rm, "right_arm", "torso_lift_link", {"r_wrist_roll_link"}, 0.0, params));
+    geometry_msgs::Pose far;
+    far.position.x = far.position.y = far.position.z = 5.0;
+    CHECK(!quick.searchPositionIK(far, seeds[0], 0.005, solution, code) && code.val == moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION);
+    bio_ik::KinematicsQueryOptions approx;
+    approx.return_approximate_solution = true;
+    CHECK(quick.searchPositionIK(far, seeds[0], 0.005, solution, code, approx) && solution.size() == 7);
+    // user goals replacing the defaults (:540-556)
+    bio_ik::BioIKKinematicsQueryOptions opts;
+    opts.replace = true;
+    opts.return_approximate_solution = true;
+    opts.goals.emplace_back(new bio_ik::PositionGoal("r_wrist_roll_link", bio_ik::Vector3(0.5, -0.2, 0.9)));
+    opts.goals.emplace_back(new bio_ik::MinimalDisplacementGoal(0.1));
+    CHECK(quick.searchPositionIK(std::vector<geometry_msgs::Pose>(), seeds[0], 0.005, std::vector<double>(), solution, IKCallbackFn(), code, opts));
+    CHECK(opts.solution_fitness >= 0.0);
+    std::printf("ok\n");
+    return 0;
+}
