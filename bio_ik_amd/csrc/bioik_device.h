@@ -284,6 +284,9 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) 
 //   tip_fn(t, frame): called with device tip index t as soon as the tip's frame is complete
 // The loop trip count and every constant are wave-uniform: control flow is scalar, constants arrive in SGPRs.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef BIOIK_FK_BLOCK
+#define BIOIK_FK_BLOCK 1  // measured on MI355X: 1, 2 and 4 are within 3 % (the kernel is not latency-bound here)
+#endif
 template <class TipFn>
 BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn) {
     const int tid = p_tid(), nth = p_nthreads();
@@ -298,20 +301,20 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
             tip_fn(t, f);
         }
     }
-    // Four joints per trip.  Phase A: their values and half-angle trigonometry — four independent polynomial
+    // BIOIK_FK_BLOCK joints per trip.  Phase A: their values and half-angle trigonometry — independent polynomial
     // chains the scheduler can interleave (sincos is computed for prismatic joints too and discarded: no branch).
     // Phase B: the four rigid transforms, which are inherently sequential.
-    for (int k0 = 0; k0 < n_chain; k0 += 4) {
-        double xv[4], sn[4], cs[4];
+    for (int k0 = 0; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
+        double xv[BIOIK_FK_BLOCK], sn[BIOIK_FK_BLOCK], cs[BIOIK_FK_BLOCK];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
             const int kk = k0 + j < n_chain ? k0 + j : n_chain - 1;
             xv[j] = x(kk);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
+        for (int j = 0; j < BIOIK_FK_BLOCK; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
             const int k = k0 + j;
             if (k >= n_chain) break;
             const int ls = pb->ops[k].load_slot;

@@ -94,7 +94,7 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
-#define BIOIK_SOLVE_WAVES_PER_SIMD 4
+#define BIOIK_SOLVE_WAVES_PER_SIMD 3
 #endif
 __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve(SolveArgs a) {
     extern __shared__ double lds[];
@@ -185,7 +185,10 @@ static int solve_threads(const DevSolveParams& sp, uint64_t units) {
     if (const char* e = std::getenv("BIOIK_SOLVE_THREADS")) {
         t = std::atoi(e);
     } else {
-        int per_species = sp.lambda >= 128 ? 128 : (sp.lambda > 32 ? 64 : 32);
+        // large batches: one wavefront per species (every wavefront busy in every phase, best throughput);
+        // small batches: one lane per child up to 128 lanes per species (lowest latency per query)
+        int per_species = sp.lambda > 32 ? 64 : 32;
+        if (units < 2048 && sp.lambda >= 128) per_species = 128;
         t = 2 * per_species;
     }
     if (t < 64) t = 64;

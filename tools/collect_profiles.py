@@ -1,0 +1,27 @@
+"""Copy the rocprofv3 summaries of the last GPU run from gpurun_out/ (scratch) into profiles/ (tracked)."""
+import collections, csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+g = os.path.join(ROOT, "gpurun_out"); p = os.path.join(ROOT, "profiles"); rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+shutil.copy(os.path.join(g, "prof_r01", "r01_kernel_stats.csv"), os.path.join(p, rnd + "_kernel_stats.csv"))
+shutil.copy(os.path.join(g, "bench_r01.json"), os.path.join(p, rnd + "_bench.json"))
+out = {}
+for f in ("pmc_fetch/f_counter_collection.csv", "pmc_write/w_counter_collection.csv", "pmc_sq/s_counter_collection.csv"):
+    rows = list(csv.DictReader(open(os.path.join(g, f)))); agg = collections.defaultdict(list)
+    for r in rows:
+        if "k_solve" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    for k, v in agg.items():
+        out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "min": min(v), "max": max(v)}
+fk, wk = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
+summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 1 "
+                      "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)", "kernel": "k_solve(SolveArgs)", "counters": out,
+           "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
+                                    "total_corrected": 2 * fk * 1024 + wk * 1024,
+                                    "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "
+                                            "WRITE_SIZE uncalibrated.  Almost all of it is register-spill (scratch) traffic: the query data are 1.4 MB."}}
+json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
+json.dump({"k_solve_hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "source": "profiles/%s_pmc_k_solve.json" % rnd}, open(os.path.join(p, "traffic.json"), "w"), indent=1)
+for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
+    print(k, "%.4g" % out[k]["mean_per_launch"])
+print("hbm bytes/launch %.4g" % summary["hbm_bytes_per_launch"]["total_corrected"], out["dispatch"])
