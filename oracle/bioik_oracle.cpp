@@ -50,6 +50,7 @@ extern "C" {
 const char* orc_last_error(void) { return g_err.c_str(); }
 void orc_set_trig_mode(int mode) { trig_mode() = mode ? 1 : 0; }
 int orc_get_trig_mode(void) { return trig_mode(); }
+void orc_set_quirk_mode(int mode) { quirk_mode() = mode ? 1 : 0; }
 
 void* orc_model_create(const bioik_model_desc* desc) {
     try {
@@ -349,6 +350,18 @@ double orc_counter_uniform(uint32_t key, uint32_t c0, uint32_t c1) {
 uint32_t orc_query_key(uint64_t seed, uint64_t query, uint32_t island) { return query_key(seed, query, island); }
 
 // ---- L3 ----
+// the restated reference random sources, probed in the order reproduce() / step() consume them (cf. oracle/ref_driver.cpp)
+int orc_reference_random_probe(int seed, size_t n_gauss, double* gauss, size_t n_index, uint64_t* index16, size_t n_fast, double* fast, size_t n_rng,
+                               double* rng_uniform) {
+    ReferenceRandom r((uint32_t)seed);
+    const double* g = r.fast_random_gauss_n(n_gauss);
+    for (size_t i = 0; i < n_gauss; i++) gauss[i] = g[i];
+    for (size_t i = 0; i < n_index; i++) index16[i] = r.fast_random_index(16);
+    for (size_t i = 0; i < n_fast; i++) fast[i] = r.fast_random();
+    for (size_t i = 0; i < n_rng; i++) rng_uniform[i] = r.random();
+    return 0;
+}
+
 int orc_reproduce_counter(void* problem, int population, uint32_t rng_key, int species, uint32_t generation, const double* parents,
                           double* children_genes, double* children_gradients) {
     try {

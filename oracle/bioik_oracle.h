@@ -5,17 +5,19 @@
  * (TAMS-Group/bio_ik, bio2_memetic path).  Only tests/, __graft_entry__.smoke() and the
  * `cpu_baseline` leg of bench.py may load it; the product (bio_ik_amd/, include/) never does.
  *
- * PARITY STATUS: the reference itself cannot be compiled in this environment (every translation unit
- * needs ROS/MoveIt/tf2/KDL/Eigen, none of which is on disk) and its tree holds no
- * golden vectors for FK, goal costs or IK results.  The restatement is pinned against
- *   (1) the two properties of the reference's own test/utest.cpp (frame `change`, linear_int_distribution),
- *   (2) an independent NumPy float64/longdouble FK (tests/test_oracle_fk.py),
- *   (3) closed-form known answers for the goal costs listed in SURVEY.md §8c,
- *   (4) Random123 known-answer vectors for the Philox generator,
- *   (5) `oracle/_ref`: the reference's OWN frame.h / goal_types.h / forward_kinematics.h / problem.cpp /
- *       ik_evolution_2.cpp compiled verbatim from /root/reference against stand-in third-party headers
- *       (oracle/ref_shim), when built — see oracle/Makefile.
- * Where only (1)-(4) apply the status is "parity unpinned" at the IK-result level.
+ * PARITY STATUS: PINNED against the reference's own code.  The reference cannot be built with its own build system here
+ * (ROS / MoveIt / tf2 / KDL / Eigen are not on disk), but its hot-path sources — include/bio_ik/{frame,goal,goal_types,
+ * robot_info}.h, src/forward_kinematics.h, src/problem.{h,cpp}, src/ik_base.h, src/ik_evolution_2.cpp — compile UNMODIFIED,
+ * from where they lie, against the minimal stand-in third-party headers of oracle/ref_shim (`make -C oracle ref` ->
+ * oracle/_ref/libbioik_ref.so, driver oracle/ref_driver.cpp).  tests/test_oracle_vs_reference.py compares this restatement
+ * with that library and with the fixtures generated from it (tests/golden/reference_golden.npz), BIT FOR BIT:
+ *   (1) frame algebra, RobotInfo, exact FK, mutation approximator, all goal costs, success test;
+ *   (2) whole IKEvolution2 trajectories (bio2, bio2_memetic, bio2_memetic_l; PR2-like arm, two-arm + torso, 31-DOF snake)
+ *       driven by the reference's own random sources (std::minstd_rand + tables + XORShift64);
+ * plus, independently of the reference tree: the two properties of the reference's test/utest.cpp, a NumPy float64 /
+ * longdouble FK, closed-form known answers for the goal costs and Random123 known-answer vectors for Philox.
+ * What remains a restatement (the third-party libraries themselves are absent): tf2 vector / quaternion helpers,
+ * KDL::diff / Equal / Rotation, MoveIt's RobotModel container — oracle/ref_shim/README.md.
  *
  * Inputs use the PODs of include/bioik_hip.h so that the oracle and the HIP path consume identical data.
  */
@@ -38,6 +40,9 @@ const char* orc_last_error(void);
 /* 0: libm sin/cos as in the reference (default); 1: bioik_sincos shared bit-for-bit with the device (orc_model.h) */
 void orc_set_trig_mode(int mode);
 int orc_get_trig_mode(void);
+/* 0: quirks Q1 (stale masked tips) and Q4 (unstable pre-selection sort) fixed, as on the device (default);
+ * 1: literal reference behaviour, for the trajectory comparison against oracle/_ref (orc_model.h) */
+void orc_set_quirk_mode(int mode);
 
 void* orc_model_create(const bioik_model_desc* desc);
 void orc_model_destroy(void* model);
@@ -95,6 +100,10 @@ void orc_philox4x32(const uint32_t* key2, const uint32_t* ctr4, uint32_t* out4);
 double orc_counter_gauss(uint32_t key, uint32_t c0, uint32_t c1);
 double orc_counter_uniform(uint32_t key, uint32_t c0, uint32_t c1);
 uint32_t orc_query_key(uint64_t seed, uint64_t query, uint32_t island);
+
+/* the restated reference random sources (ORC_RNG_REFERENCE), probed in the order reproduce()/step() consume them */
+int orc_reference_random_probe(int seed, size_t n_gauss, double* gauss, size_t n_index, uint64_t* index16, size_t n_fast, double* fast, size_t n_rng,
+                               double* rng_uniform);
 
 /* ---- L3: ik_evolution_2.cpp ---- */
 int orc_reproduce_counter(void* problem, int population, uint32_t rng_key, int species, uint32_t generation,

@@ -52,6 +52,11 @@ def set_trig_mode(mode, kind="strict"):
     lib(kind).orc_set_trig_mode(C.c_int(mode))
 
 
+def set_quirk_mode(mode, kind="strict"):
+    """0 = reference quirks Q1/Q4 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
+    lib(kind).orc_set_quirk_mode(C.c_int(mode))
+
+
 def _d(a):
     return a.ctypes.data_as(_pd)
 

@@ -225,8 +225,12 @@ struct Evolution2 {
                     child_count = rng.preselect_count(population.size(), lambda);
                     for (size_t ci = population.size(); ci < children.size(); ci++)
                         children[ci].fitness = secondary_fitness(children[ci].genes.data());
-                    std::stable_sort(children.begin() + population.size(), children.end(),
-                                     [](const Individual& a, const Individual& b) { return a.fitness < b.fitness; });
+                    if (quirk_mode() == 1)
+                        std::sort(children.begin() + population.size(), children.end(),
+                                  [](const Individual& a, const Individual& b) { return a.fitness < b.fitness; });  // :376 verbatim
+                    else
+                        std::stable_sort(children.begin() + population.size(), children.end(),
+                                         [](const Individual& a, const Individual& b) { return a.fitness < b.fitness; });
                 }
                 // keep parents, :381-388
                 for (size_t i = 0; i < population.size(); i++) {

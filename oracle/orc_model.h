@@ -24,6 +24,15 @@ inline int& trig_mode() {
     static int mode = 0;
     return mode;
 }
+// Reference quirks.  0 (default): the two deliberate fixes the device shares — Q1: computeApproximateMutation1 writes the
+// unchanged input frame for tips a variable does not move; Q4: children are pre-selected in a STABLE order.
+// 1: literal reference behaviour — Q1: such tips keep whatever the output buffer held (forward_kinematics.h:1017 `continue`),
+// Q4: std::sort (ik_evolution_2.cpp:376).  Mode 1 exists to pin this restatement, trajectory by trajectory, against the
+// reference's own code compiled into oracle/_ref (tests/test_oracle_vs_reference.py).
+inline int& quirk_mode() {
+    static int mode = 0;
+    return mode;
+}
 
 struct Link {
     int parent;
@@ -372,7 +381,7 @@ struct RobotFK {
         output.resize(tip_count);
         for (size_t t = 0; t < tip_count; t++) {
             if (approx_mask[t][variable_index] == 0) {
-                output[t] = input[t];
+                if (quirk_mode() == 0) output[t] = input[t];  // mode 1: stale, as in the reference
                 continue;
             }
             const Frame& jd = approx_frames[t][variable_index];
