@@ -13,8 +13,9 @@ Extra objects on the JSON line:
                / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s.  The fused kernel
                keeps the population in LDS, so the measured HBM traffic (profiles/) is far below the algorithmic
                figure; the kernel is FP64-VALU bound.
-  cpu_baseline the CPU oracle (oracle/, a port of the reference algorithm built with the reference's Release flags)
-               timed on this host, rank 0, N=1 only, on a bounded sample of the same queries.
+  cpu_baseline the reference's own CPU code (oracle/_ref: the reference sources compiled unmodified, Release flags) when the
+               prebuilt library is present, else the oracle port; timed on this host, rank 0, N=1 only, one thread, on a
+               bounded sample of the same queries.  The port at the GPU run's own parameters is reported beside it.
 """
 import argparse
 import json
@@ -182,30 +183,42 @@ def main():
                                    "layout": "genes [unit][D][pop] f64 in HBM, 512-byte segments per wavefront load"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import orc
-        o = orc.Oracle(template, kind="ref")  # reference Release flags, libm trigonometry
+        from oracle import orc, ref
         ns = min(args.cpu_sample, BATCH)
+        # (1) the oracle (a port of the reference algorithm, reference Release flags, libm) with the SAME parameters as the
+        #     GPU run: 128 children per species, exact FK per individual, same step budget
+        o = orc.Oracle(template, kind="ref")
         t1 = time.perf_counter()
         _, _, osuc, osteps = o.solve_batch(p, orc.RNG_COUNTER, seeds[:ns], params[:ns], n_threads=1)
         dt = time.perf_counter() - t1
-        cb = {"value": float(osuc.sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-              "sample": "first %d of the same 4096 queries, same parameters (pop=128, exact FK, max_steps=%d), 1 thread, oracle built with the reference's "
-                        "Release flags (-O3 -ffast-math ...)" % (ns, MAX_STEPS),
-              "success_rate": float(osuc.mean()), "seconds": dt, "host_cpus": os.cpu_count()}
-        # the reference's own configuration (16 children, linearised phenotypes, minstd_rand tables), same queries and step budget
-        pr = abi.default_solve_params(population=16, fk_mode=abi.FK_LINEAR, max_steps=MAX_STEPS * 8, random_seed=1)
-        t1 = time.perf_counter()
-        _, _, rsuc, _ = o.solve_batch(pr, orc.RNG_REFERENCE, seeds[:ns], params[:ns], n_threads=1)
-        dt = time.perf_counter() - t1
-        cb["reference_defaults"] = {"value": float(rsuc.sum()) / dt, "success_rate": float(rsuc.mean()), "seconds": dt, "cores": 1,
-                                    "config": "16 children, linearised FK, reference RNG, 1 island, max_steps=%d" % (MAX_STEPS * 8)}
+        port = {"value": float(osuc.sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port", "success_rate": float(osuc.mean()), "seconds": dt,
+                "sample": "first %d of the same 4096 queries, same parameters as the GPU run (pop=%d, exact FK, max_steps=%d), 1 thread" % (ns, POP, MAX_STEPS)}
         ncpu = os.cpu_count() or 1
         t1 = time.perf_counter()
         _, _, asuc, _ = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=ncpu)
         dt = time.perf_counter() - t1
-        cb["all_cores"] = {"value": float(asuc.sum()) / dt, "cores": ncpu, "seconds": dt, "sample": "all 4096 queries, query-parallel"}
+        port["all_cores"] = {"value": float(asuc.sum()) / dt, "cores": ncpu, "seconds": dt, "sample": "all 4096 queries, query-parallel"}
+        if ref.release_available():
+            # (2) the REFERENCE'S OWN code (oracle/_ref: src/ik_evolution_2.cpp etc. compiled unmodified with the reference's
+            #     Release flags): bio2_memetic as shipped — 2 species x (2 elites + 16 children), linearised FK, its own RNG,
+            #     one island = one thread; budget form of the island loop (success test after every step, <= 512 steps)
+            pr = abi.default_solve_params(mode="bio2_memetic", random_seed=1)
+            r = ref.Reference(template, pr, release=True)
+            r.solve_batch(seeds[:4], params[:4], 512)  # constructs the solver (fills its 2 x 64 MiB random tables) outside the timing
+            t1 = time.perf_counter()
+            _, _, rsuc, rsteps = r.solve_batch(seeds[:ns], params[:ns], 512)
+            dt = time.perf_counter() - t1
+            cb = {"value": float(rsuc.sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "reference", "success_rate": float(rsuc.mean()), "seconds": dt,
+                  "mean_steps": float(rsteps.mean()), "host_cpus": ncpu,
+                  "sample": "first %d of the same 4096 queries; the reference's own bio2_memetic (oracle/_ref, reference Release flags), its hard-coded "
+                            "population (2 species x (2+16)), linearised FK, 1 island, success test after every step, <= 512 steps, 1 thread" % ns,
+                  "port_same_parameters": port}
+        else:
+            cb = dict(port)
+            cb["host_cpus"] = ncpu
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"] if cb["value"] > 0 else None
+        out["speedup_vs_port_same_parameters_1thread"] = out["value"] / port["value"] if port["value"] > 0 else None
 
     if rank == 0:
         print(json.dumps(out))

@@ -13,7 +13,9 @@ from bio_ik_amd import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "_ref", "libbioik_ref.so")
+PATH_RELEASE = os.path.join(HERE, "_ref", "libbioik_ref_release.so")  # reference Release flags: timing baseline
 _lib = None
+_libs = {}
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
 
@@ -22,23 +24,37 @@ def available():
     return os.path.exists(PATH) or os.path.isdir("/root/reference/src")
 
 
-def lib():
+def release_available():
+    return os.path.exists(PATH_RELEASE) or os.path.isdir("/root/reference/src")
+
+
+def lib(release=False):
     global _lib
+    if release:
+        if "release" not in _libs:
+            if not os.path.exists(PATH_RELEASE):
+                subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
+            _libs["release"] = _declare(C.CDLL(PATH_RELEASE))
+        return _libs["release"]
     if _lib is None:
         if not os.path.exists(PATH):
             subprocess.run(["make", "-C", HERE, "-s", "ref"], check=True)
-        L = C.CDLL(PATH)
-        L.ref_last_error.restype = C.c_char_p
-        L.ref_create.restype = C.c_void_p
-        L.ref_create.argtypes = [C.POINTER(abi.ModelDesc), C.POINTER(abi.ProblemDesc), C.POINTER(abi.SolveParams)]
-        L.ref_destroy.argtypes = [C.c_void_p]
-        L.ref_solver_create.restype = C.c_void_p
-        L.ref_solver_create.argtypes = [C.c_void_p, _pd, _pd]
-        L.ref_solver_destroy.argtypes = [C.c_void_p]
-        L.ref_solver_step.argtypes = [C.c_void_p]
-        L.ref_solver_result.argtypes = [C.c_void_p, _pd, _pd, _pi]
-        _lib = L
+        _lib = _declare(C.CDLL(PATH))
     return _lib
+
+
+def _declare(L):
+    L.ref_last_error.restype = C.c_char_p
+    L.ref_create.restype = C.c_void_p
+    L.ref_create.argtypes = [C.POINTER(abi.ModelDesc), C.POINTER(abi.ProblemDesc), C.POINTER(abi.SolveParams)]
+    L.ref_destroy.argtypes = [C.c_void_p]
+    L.ref_solver_create.restype = C.c_void_p
+    L.ref_solver_create.argtypes = [C.c_void_p, _pd, _pd]
+    L.ref_solver_destroy.argtypes = [C.c_void_p]
+    L.ref_solver_step.argtypes = [C.c_void_p]
+    L.ref_solver_result.argtypes = [C.c_void_p, _pd, _pd, _pi]
+    L.ref_solve_batch.argtypes = [C.c_void_p, C.c_size_t, _pd, _pd, C.c_int, _pd, _pd, _pi, _pi]
+    return L
 
 
 def _d(a):
@@ -60,8 +76,8 @@ class RefError(RuntimeError):
 class Reference:
     """One (model, problem template, solver parameters) loaded into the reference's own classes."""
 
-    def __init__(self, template, params=None):
-        self.L = lib()
+    def __init__(self, template, params=None, release=False):
+        self.L = lib(release)
         self.template = template
         self.params = params if params is not None else abi.default_solve_params()
         md, pd = template.model.desc(), template.desc()
@@ -135,6 +151,16 @@ class Reference:
         ok = np.zeros(g.shape[0], dtype=np.int32)
         self._chk(self.L.ref_check(self._h, C.c_size_t(g.shape[0]), _d(_f64(seed)), _d(self._gp(goal_params)), _d(g), _i(ok)))
         return ok
+
+    def solve_batch(self, seeds, goal_params, max_steps):
+        """n queries through one reference solver object (budget form of src/ik_parallel.h:160-184), single thread."""
+        s = _f64(seeds).reshape(-1, self.V)
+        n = s.shape[0]
+        gp = _f64(goal_params).reshape(n, self.P) if self.P else np.zeros((n, 1))
+        sol, fit = np.zeros((n, self.V)), np.zeros(n)
+        suc, steps = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._chk(self.L.ref_solve_batch(self._h, C.c_size_t(n), _d(s), _d(gp), C.c_int(max_steps), _d(sol), _d(fit), _i(suc), _i(steps)))
+        return sol, fit, suc, steps
 
     def solve_steps(self, seed, goal_params, n_steps):
         """IKEvolution2 through the reference's IKFactory: solution / exact fitness / success after every step()."""

@@ -109,6 +109,7 @@ struct Ref {
     IKParams ikparams;
     std::vector<std::unique_ptr<Goal>> goals;  // rebuilt per query
     Problem problem;
+    std::unique_ptr<IKSolver> batch_solver;  // ref_solve_batch: one solver object for all queries
 
     static tf2::Vector3 v3(const double* p) { return tf2::Vector3(p[0], p[1], p[2]); }
     // the reference's goal object for one opcode (constructors as in include/bio_ik/goal_types.h)
@@ -436,6 +437,41 @@ extern "C" int ref_evolution_state(void* ikbase, double* genes, double* fitness,
 int ref_solver_state(void* sp, double* species_genes, double* species_fitness, double* solution_fitness) {
     return ref_evolution_state(((RefSolver*)sp)->ik.get(), species_genes, species_fitness, solution_fitness);
 }
+// n queries through ONE solver object, as the plugin does (kinematics_plugin.cpp:273 creates IKParallel once, :566-578
+// re-initialises it per query): per query the island loop of src/ik_parallel.h:160-184 in budget form — step(); exact FK of
+// getSolution(); checkSolution; computeFitness — until success or max_steps.  This is the reference's own CPU path.
+int ref_solve_batch(void* h, size_t n, const double* seeds, const double* params, int max_steps, double* solutions, double* fitness, int32_t* success,
+                    int32_t* steps) {
+    TRY
+    Ref& r = *(Ref*)h;
+    size_t V = r.model->getVariableCount(), P = (size_t)r.P;
+    if (!r.batch_solver) r.batch_solver.reset(IKFactory::create(r.ikparams.solver_class_name, r.ikparams));  // once, like the plugin
+    IKSolver* ik = r.batch_solver.get();
+    std::vector<double> zero(1, 0.0);
+    for (size_t q = 0; q < n; q++) {
+        r.set_query(seeds + q * V, P ? params + q * P : zero.data());
+        ik->canceled = false;
+        ik->initialize(r.problem);
+        int st = 0;
+        bool ok = false;
+        double fit = DBL_MAX;
+        std::vector<double> sol(seeds + q * V, seeds + (q + 1) * V);
+        while (st < max_steps) {
+            ik->step();
+            st++;
+            sol = ik->getSolution();
+            ik->model.applyConfiguration(sol);
+            ok = ik->checkSolution(sol, ik->model.getTipFrames());
+            fit = ik->computeFitness(sol, ik->model.getTipFrames());
+            if (ok) break;
+        }
+        for (size_t v = 0; v < V; v++) solutions[q * V + v] = sol[v];
+        fitness[q] = fit, success[q] = ok ? 1 : 0, steps[q] = st;
+    }
+    return 0;
+    CATCH(-1)
+}
+
 // solution [V]; exact-FK fitness and success of the solution as src/ik_parallel.h:173-181 computes them
 int ref_solver_result(void* sp, double* solution, double* fitness, int32_t* success) {
     TRY

@@ -50,5 +50,7 @@
 #include <tf2_kdl/tf2_kdl.h>
 #include <tf_conversions/tf_kdl.h>
 
+#if !defined(REF_NATIVE_KERNELS)  // the timing build of the solver keeps the reference's own AVX/SSE2 dispatch
 #undef __x86_64__
 #undef __i386__
+#endif
