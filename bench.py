@@ -71,6 +71,8 @@ def main():
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank)
     h.set_first_query(rank * BATCH)
     p = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, fk_mode=abi.FK_EXACT if FK_MODE == "exact" else abi.FK_LINEAR)
+    if "BIOIK_BENCH_DTWIST" in os.environ:  # experiments only (e.g. 1e-300: no query ever succeeds, every workgroup runs max_steps)
+        p.dtwist = float(os.environ["BIOIK_BENCH_DTWIST"])
 
     d_seeds = torch.from_numpy(seeds).to(dev)
     d_params = torch.from_numpy(params).to(dev)

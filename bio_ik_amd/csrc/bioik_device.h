@@ -43,7 +43,7 @@ BIOIK_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
 BIOIK_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 BIOIK_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 BIOIK_DEV V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
-BIOIK_DEV double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+BIOIK_DEV double dot3(V3 a, V3 b) { return bk_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 BIOIK_DEV V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 BIOIK_DEV double len2(V3 a) { return dot3(a, a); }
 BIOIK_DEV double dist2(V3 a, V3 b) { return len2(b - a); }
@@ -51,25 +51,22 @@ BIOIK_DEV V3 normalized3(V3 a) {
     double l = sqrt(len2(a));
     return V3{a.x / l, a.y / l, a.z / l};
 }
-BIOIK_DEV double qdot(Q4 a, Q4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+BIOIK_DEV double qdot(Q4 a, Q4 b) { return bk_dot4(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
 BIOIK_DEV Q4 qinv(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
 BIOIK_DEV double clamped_acos(double x) { return acos(fmin(1.0, fmax(-1.0, x))); }
 BIOIK_DEV F7 f7_identity() { return F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 1.0}}; }
 
-// rotate v by unit quaternion q (frame.h:108-149; its identity/zero short-cuts are arithmetic no-ops)
+// rotate v by unit quaternion q (frame.h:108-149; its identity/zero short-cuts are arithmetic no-ops); fused form
 BIOIK_DEV V3 qrot(Q4 q, V3 v) {
-    double tx = q.y * v.z - q.z * v.y;
-    double ty = q.z * v.x - q.x * v.z;
-    double tz = q.x * v.y - q.y * v.x;
-    double rx = q.w * tx + q.y * tz - q.z * ty;
-    double ry = q.w * ty + q.z * tx - q.x * tz;
-    double rz = q.w * tz + q.x * ty - q.y * tx;
-    return V3{rx + rx + v.x, ry + ry + v.y, rz + rz + v.z};
+    V3 o;
+    bk_qrot(q.x, q.y, q.z, q.w, v.x, v.y, v.z, o.x, o.y, o.z);
+    return o;
 }
-// Hamilton product (frame.h:151-172)
+// Hamilton product (frame.h:151-172); fused form
 BIOIK_DEV Q4 qmul(Q4 p, Q4 q) {
-    return Q4{(p.w * q.x + p.x * q.w) + (p.y * q.z - p.z * q.y), (p.w * q.y - p.x * q.z) + (p.y * q.w + p.z * q.x),
-              (p.w * q.z + p.x * q.y) - (p.y * q.x - p.z * q.w), (p.w * q.w - p.x * q.x) - (p.y * q.y + p.z * q.z)};
+    Q4 o;
+    bk_qmul(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w, o.x, o.y, o.z, o.w);
+    return o;
 }
 BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p), qmul(a.q, b.q)}; }
 
@@ -144,20 +141,23 @@ struct XV {
 // ---------------------------------------------------------------------------------------------------------
 BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
     const int n_ops = pb->n_ops;
+#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
+    type = G_POSE;
+#endif
     switch (type) {
         case G_POSITION:  // goal_types.h:96
             return dist2(fb.p, v3(P[0], P[1], P[2]));
         case G_ORIENTATION: {  // :115-124
-            double dx = P[0] - fb.q.x, dy = P[1] - fb.q.y, dz = P[2] - fb.q.z, dw = P[3] - fb.q.w;
-            double sx = P[0] + fb.q.x, sy = P[1] + fb.q.y, sz = P[2] + fb.q.z, sw = P[3] + fb.q.w;
-            return fmin(dx * dx + dy * dy + dz * dz + dw * dw, sx * sx + sy * sy + sz * sz + sw * sw);
+            const Q4 d = Q4{P[0] - fb.q.x, P[1] - fb.q.y, P[2] - fb.q.z, P[3] - fb.q.w};
+            const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
+            return fmin(qdot(d, d), qdot(a, a));
         }
         case G_POSE: {  // :149-180
             double e = dist2(fb.p, v3(P[0], P[1], P[2]));
-            double dx = P[3] - fb.q.x, dy = P[4] - fb.q.y, dz = P[5] - fb.q.z, dw = P[6] - fb.q.w;
-            double sx = P[3] + fb.q.x, sy = P[4] + fb.q.y, sz = P[5] + fb.q.z, sw = P[6] + fb.q.w;
+            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
+            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
             double rs = P[7];
-            e += fmin(dx * dx + dy * dy + dz * dz + dw * dw, sx * sx + sy * sy + sz * sz + sw * sw) * (rs * rs);
+            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
             return e;
         }
         case G_LOOK_AT: {  // :204-211
@@ -326,9 +326,10 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
             }
             const bool rev = pb->ops[k].type == BIOIK_OP_REVOLUTE;
             const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
-            const Q4 lq = Q4{c * pb->ops[k].ca[0] + s * pb->ops[k].cb[0], c * pb->ops[k].ca[1] + s * pb->ops[k].cb[1],
-                             c * pb->ops[k].ca[2] + s * pb->ops[k].cb[2], c * pb->ops[k].ca[3] + s * pb->ops[k].cb[3]};
-            const V3 lp = v3(pb->ops[k].cpos[0] + xp * pb->ops[k].cb[0], pb->ops[k].cpos[1] + xp * pb->ops[k].cb[1], pb->ops[k].cpos[2] + xp * pb->ops[k].cb[2]);
+            const Q4 lq = Q4{BK_FMA(c, pb->ops[k].ca[0], s * pb->ops[k].cb[0]), BK_FMA(c, pb->ops[k].ca[1], s * pb->ops[k].cb[1]),
+                             BK_FMA(c, pb->ops[k].ca[2], s * pb->ops[k].cb[2]), BK_FMA(c, pb->ops[k].ca[3], s * pb->ops[k].cb[3])};
+            const V3 lp = v3(BK_FMA(xp, pb->ops[k].cb[0], pb->ops[k].cpos[0]), BK_FMA(xp, pb->ops[k].cb[1], pb->ops[k].cpos[1]),
+                             BK_FMA(xp, pb->ops[k].cb[2], pb->ops[k].cpos[2]));
             f.p = f.p + qrot(f.q, lp);
             f.q = qmul(f.q, lq);
             const int ss = pb->ops[k].save_slot;
@@ -397,13 +398,13 @@ BIOIK_DEV F7 linear_tip(ProbPtr pb, int t, const XV& x, const LinModel& lm) {
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            px += d[j][0] * dv[j];
-            py += d[j][1] * dv[j];
-            pz += d[j][2] * dv[j];
-            rx += d[j][3] * dv[j];
-            ry += d[j][4] * dv[j];
-            rz += d[j][5] * dv[j];
-            rw += d[j][6] * dv[j];
+            px = BK_FMA(d[j][0], dv[j], px);
+            py = BK_FMA(d[j][1], dv[j], py);
+            pz = BK_FMA(d[j][2], dv[j], pz);
+            rx = BK_FMA(d[j][3], dv[j], rx);
+            ry = BK_FMA(d[j][4], dv[j], ry);
+            rz = BK_FMA(d[j][5], dv[j], rz);
+            rw = BK_FMA(d[j][6], dv[j], rw);
         }
     }
     return F7{{px, py, pz}, {rx, ry, rz, rw}};
@@ -603,7 +604,11 @@ BIOIK_DEV double angle_shortest_path(Q4 a, Q4 b) {  // tf2::Quaternion::angleSho
 }
 
 BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const QueryCtx& qc, double dpos, double drot, double dtwist) {
+#ifdef BIOIK_EXP_POSE_ONLY
+    const int type = G_POSE;
+#else
     const int type = pb->primary[g].type;
+#endif
     const double* P = qc.par + pb->primary[g].param_off;
     bool ok = true;
     if (type == G_POSITION) {

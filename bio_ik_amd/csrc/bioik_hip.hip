@@ -242,7 +242,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.params = d_params;
     a.phase_cycles = nullptr;
 #if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
-    DevBuf phase_buf(units * 8 * sizeof(unsigned long long));
+    DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
     const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
     if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
 #endif
@@ -266,7 +266,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     LAUNCH(k_solve, solve_body(a, b_, l_), units, nth, lds, stream, a);
 #if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
-        std::vector<unsigned long long> h(units * 8);
+        std::vector<unsigned long long> h(units * PHASE_SLOTS);
         be_d2h(h.data(), phase_buf.p, h.size() * sizeof(unsigned long long), stream);
         be_sync(stream);
         if (FILE* f = std::fopen(phase_path, "wb")) {

@@ -64,7 +64,7 @@ BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f <
 
 // all-lanes top-2 of (f,pos) over the workgroup: every lane brings its own best two (b1 <= b2); wave64 xor-butterfly
 // merging sorted pairs, then one LDS hop across waves.  Positions are unique, so (f,pos) is a total order.
-BIOIK_DEV void top2_reduce(double& b1f, int& b1p, double& b2f, int& b2p, double* s_red, int gtid, int G) {
+BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         double o1f = p_shfl_xor(b1f, m), o2f = p_shfl_xor(b2f, m);
@@ -76,8 +76,15 @@ BIOIK_DEV void top2_reduce(double& b1f, int& b1p, double& b2f, int& b2p, double*
             b2f = o1f, b2p = o1p;
         }
     }
+}
+// rendezvous of one lane group: a single wavefront needs no s_barrier (p_wave_sync), several wavefronts take the workgroup
+// barrier -- every group of the workgroup then executes the same number of them
+BIOIK_DEV void group_sync(int G) {
+    if (G > 64) p_barrier(); else p_wave_sync();
+}
+BIOIK_DEV void top2_xwave(double& b1f, int& b1p, double& b2f, int& b2p, double* s_red, int gtid, int G) {
     const int nw = G >> 6;  // wavefronts of this species group (s_red is the group's own scratch)
-    if ((p_nthreads() >> 6) > 1) {
+    if (G > 64) {
         if ((gtid & 63) == 0) {
             double* d = s_red + 4 * (gtid >> 6);
             d[0] = b1f, d[1] = (double)b1p, d[2] = b2f, d[3] = (double)b2p;
@@ -112,7 +119,7 @@ BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* 
             if (gtid == 0) f7_store(s_tips + t * 7, f);
         });
     for (int k = gtid; k < n_ops; k += G) s_base[k] = x(k);
-    p_barrier();
+    group_sync(G);
     for (int idx = gtid; idx < T * n_ops; idx += G) {
         int t = idx / n_ops, k = idx - t * n_ops;
         double o[7];
@@ -120,7 +127,7 @@ BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* 
         double* d = s_delta + ((size_t)t * n_ops + k) * 7;
         for (int c = 0; c < 7; c++) d[c] = o[c];
     }
-    p_barrier();
+    group_sync(G);
 }
 
 struct SolveArgs {
@@ -264,7 +271,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
                         s_sec[c] = secondary_fitness(pb, xl, qc);
                     }
-                    p_barrier();
+                    group_sync(G);
                     for (int c = gtid; c < lambda; c += G) {
                         double my = s_sec[c];
                         int r = 0;
@@ -274,7 +281,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         }
                         s_order[r] = c;
                     }
-                    p_barrier();
+                    group_sync(G);
                     uint32_t o0, o1;
                     philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
                     n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
@@ -301,7 +308,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
-                top2_reduce(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
+                top2_wave(b1f, b1p, b2f, b2p);
+                PHASE_MARK(PH_SEL_TOP2);
+                top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
+                PHASE_MARK(PH_SEL_XWAVE);
                 Cand first{S.pf0, 0, 0};
                 if (cand_better(S.pf1, 1, first.f, first.pos)) first = Cand{S.pf1, 1, 1};
                 if (cand_better(b1f, b1p, first.f, first.pos)) first = Cand{b1f, b1p, b1p};
@@ -344,8 +354,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 S.cur ^= 1;
                 S.pf0 = first.f;
                 S.pf1 = second.f;
-                p_barrier();
-                PHASE_MARK(PH_SELECTION);
+                PHASE_MARK(PH_SEL_COPY);
+                group_sync(G);
+                PHASE_MARK(PH_SEL_BAR);
             }
 
             // memetic phase on the elite (:436-570).  The workgroup barriers inside are executed a fixed number of times
@@ -354,6 +365,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
                 if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G);  // fresh linearisation at the elite
+                PHASE_MARK(PH_MEM_APPROX);
                 double dp = 0.0000001;
                 {
                     uint32_t o0, o1;
@@ -364,6 +376,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 bool live = true;  // still descending; the leading wavefront of the group does the arithmetic
                 for (int it = 0; it < 8; it++) {
                     double f2p = 0.0, fa = 0.0;
+                    if (live) PHASE_COUNT(PH_N_MEM_ITER);
                     if (live && glead) {
                         for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
                         double fbp = 0.0;
@@ -372,8 +385,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             f2p += tip_goals(pb, t, f, xe, qc);
                             if (my_op >= 0) {
                                 const double* d = s_delta + ((size_t)t * n_ops + my_op) * 7;  // computeApproximateMutation1
-                                F7 f3 = F7{{f.p.x + d[0] * dp, f.p.y + d[1] * dp, f.p.z + d[2] * dp},
-                                           {f.q.x + d[3] * dp, f.q.y + d[4] * dp, f.q.z + d[5] * dp, f.q.w + d[6] * dp}};
+                                F7 f3 = F7{{BK_FMA(d[0], dp, f.p.x), BK_FMA(d[1], dp, f.p.y), BK_FMA(d[2], dp, f.p.z)},
+                                           {BK_FMA(d[3], dp, f.q.x), BK_FMA(d[4], dp, f.q.y), BK_FMA(d[5], dp, f.q.z), BK_FMA(d[6], dp, f.q.w)}};
                                 fbp += tip_goals(pb, t, f3, xl, qc);
                             }
                         }
@@ -385,14 +398,16 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             s_grad[gtid] = fb - fa;
                         }
                     }
-                    p_barrier();
+                    group_sync(G);
+                    PHASE_MARK(PH_MEM_GRAD);
                     if (live && glead) {
                         double sum = dp * dp;  // :477-482
                         for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
                         const double fnorm = 1.0 / sum * dp;
                         for (int k = gtid; k < n_ops; k += 64) s_gv[k] = pb->ops[k].gene >= 0 ? s_grad[pb->ops[k].gene] * fnorm : 0.0;
                     }
-                    p_barrier();
+                    group_sync(G);
+                    PHASE_MARK(PH_MEM_NORM);
                     if (live && glead) {
                         // support points x-g (even lanes) and x+g (odd lanes), :485-495
                         const double sgn = (lane & 1) ? 1.0 : -1.0;
@@ -411,21 +426,23 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         for (int k = gtid; k < n_ops; k += 64)
                             s_xn[k] = pb->ops[k].gene >= 0 ? fmin(fmax(el[k] + s_gv[k] * step_size, pb->ops[k].clip_min), pb->ops[k].clip_max) : el[k];
                     }
-                    p_barrier();
+                    group_sync(G);
+                    PHASE_MARK(PH_MEM_LINE);
                     if (live && glead) {
                         const double f4p = eval_linear_primary(pb, XV{s_xn, 1}, qc, lm);
                         if (!(f4p < f2p)) live = false;  // accept iff the primary fitness improves, else stop (:527-538)
                     }
                     if (gtid == 0) s_bc[1] = live ? 1.0 : 0.0;
-                    p_barrier();
+                    group_sync(G);
                     live = s_bc[1] != 0.0;
                     if (live)
                         for (int k = gtid; k < n_ops; k += G) el[k] = s_xn[k];
-                    p_barrier();
-                    if (groups == 1 && !live) break;  // a single group need not keep the barrier count of a partner
+                    group_sync(G);
+                    PHASE_MARK(PH_MEM_ACCEPT);
+                    if ((groups == 1 || G == 64) && !live) break;  // only groups sharing workgroup barriers must keep each other's count
                 }
-                p_barrier();
-                PHASE_MARK(PH_MEMETICS);
+                group_sync(G);
+                PHASE_MARK(PH_MEM_TAIL);
             }
             // species ranking fitness: exact FK of the elite (:607-614)
             {
@@ -434,6 +451,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 S.improved = (fit != S.fit) ? 1 : 0;
                 S.fit = fit;
                 S.pf0 = fit;
+                PHASE_MARK(PH_RANK);
             }
             if (rank == 0) A = S; else B = S;
         }
@@ -480,6 +498,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             }
         }
         steps++;
+        PHASE_COUNT(PH_N_STEPS);
         PHASE_MARK(PH_SPECIES);
         if (A.fit < sol_fit) {
             const double* cb = s_pop + A.slot * SP + A.cur * BF;

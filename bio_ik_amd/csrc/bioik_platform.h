@@ -36,6 +36,7 @@ extern thread_local int tid;
 BIOIK_DEV int p_tid() { return sim::tid; }
 BIOIK_DEV int p_nthreads() { return sim::blk->nthreads; }
 BIOIK_DEV void p_barrier() { sim::blk->bar->arrive_and_wait(); }
+BIOIK_DEV void p_wave_sync() { sim::blk->wave_bar[sim::tid >> 6]->arrive_and_wait(); }
 template <class T>
 BIOIK_DEV T p_shfl(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "");
@@ -67,6 +68,13 @@ typedef const DevProblem __attribute__((address_space(4))) * ProbPtr;
 BIOIK_DEV int p_tid() { return (int)threadIdx.x; }
 BIOIK_DEV int p_nthreads() { return (int)blockDim.x; }
 BIOIK_DEV void p_barrier() { __syncthreads(); }
+// LDS hand-over between lanes of ONE wavefront: a wavefront's LDS instructions execute in program order, so all that is
+// needed is that the compiler keeps them in program order (wavefront-scope fences cost no instruction)
+BIOIK_DEV void p_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <class T>
 BIOIK_DEV T p_shfl(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 template <class T>
@@ -79,28 +87,45 @@ BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 // Phase profiler (the reference's BLOCKPROFILER taxonomy, src/ik_evolution_2.cpp:330-437,605): compiled in only with
 // -DBIOIK_PHASE_TIMING; lane 0 of the workgroup accumulates shader-clock cycles per phase.
 #if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
-#define PHASE_DECL unsigned long long ph_t_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last_ = __builtin_readcyclecounter()
+#define PHASE_N 24      // phases (PH_*)
+#define PHASE_SLOTS 28  // PHASE_N phases, then: start / end of the workgroup on the 100 MHz wall clock, HW_ID | XCC_ID << 32, spare
+#define PHASE_DECL unsigned long long ph_t_[PHASE_N] = {0}, ph_last_ = __builtin_readcyclecounter(), ph_start_ = wall_clock64()
 #define PHASE_MARK(i)                                          \
     do {                                                       \
         unsigned long long now_ = __builtin_readcyclecounter(); \
         ph_t_[i] += now_ - ph_last_;                           \
         ph_last_ = now_;                                       \
     } while (0)
+#define PHASE_COUNT(i) (ph_t_[i] += 1)
 #define PHASE_DUMP(ptr, unit)                                                       \
     do {                                                                            \
         if ((ptr) && p_tid() == 0)                                                  \
-            for (int i_ = 0; i_ < 8; i_++) (ptr)[(unit) * 8 + i_] = ph_t_[i_];      \
+        {                                                                           \
+            for (int i_ = 0; i_ < PHASE_N; i_++) (ptr)[(unit) * PHASE_SLOTS + i_] = ph_t_[i_]; \
+            (ptr)[(unit) * PHASE_SLOTS + PHASE_N] = ph_start_;                      \
+            (ptr)[(unit) * PHASE_SLOTS + PHASE_N + 1] = wall_clock64();             \
+            (ptr)[(unit) * PHASE_SLOTS + PHASE_N + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+            (ptr)[(unit) * PHASE_SLOTS + PHASE_N + 3] = 0;                                   \
+        }                                                                           \
     } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(i)
 #define PHASE_DUMP(ptr, unit)
+#define PHASE_COUNT(i)
 #endif
-enum { PH_INIT = 0, PH_REPRODUCE = 1, PH_FITNESS = 2, PH_SELECTION = 3, PH_MEMETICS = 4, PH_SPECIES = 5, PH_CHECK = 6, PH_PRESELECT = 7 };
+enum { PH_INIT = 0, PH_REPRODUCE = 1, PH_FITNESS = 2, PH_SELECTION = 3, PH_MEMETICS = 4, PH_SPECIES = 5, PH_CHECK = 6, PH_PRESELECT = 7,
+       // finer marks of the profiling build: selection = top-2 butterfly / cross-wave hop / winner copy / closing barrier;
+       // memetics = linearisation / gradient / normalisation / line search / acceptance; counters of iterations
+       PH_SEL_TOP2 = 8, PH_SEL_XWAVE = 9, PH_SEL_COPY = 10, PH_SEL_BAR = 11, PH_MEM_APPROX = 12, PH_MEM_GRAD = 13, PH_MEM_NORM = 14,
+       PH_MEM_LINE = 15, PH_MEM_ACCEPT = 16, PH_MEM_TAIL = 17, PH_RANK = 18, PH_N_MEM_ITER = 19, PH_N_STEPS = 20, PH_LINEARISE = 21 };
 
 // sin/cos of the joint half angles: the shared bit-reproducible implementation (bioik_sincos.h)
 #define BIOIK_SINCOS_FN BIOIK_DEV
 #include "bioik_sincos.h"
+// fused forms of the frame algebra, shared with the oracle's device-arithmetic mode (bioik_fused.h)
+#define BIOIK_FUSED_FN BIOIK_DEV
+#include "bioik_fused.h"
 BIOIK_DEV void p_sincos(double x, double* s, double* c) { bioik_sincos(x, s, c); }
 
 #define BIOIK_DBL_MAX 1.7976931348623157e308

@@ -11,7 +11,22 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "../bio_ik_amd/csrc/bioik_fused.h"
+
 namespace orc {
+
+// Arithmetic of the oracle.  0 (default): the reference's own expressions — libm sin/cos (forward_kinematics.h:96-97) and
+// separate multiplies and adds (frame.h); in this mode the restatement is pinned bit-for-bit against the reference's code
+// (tests/test_oracle_vs_reference.py).  1: "device arithmetic" — the bit-reproducible bioik_sincos and the fused forms of
+// bioik_fused.h, both shared with the gfx950 kernels.  libm vs the GPU math library and fused vs unfused products differ in
+// the last ulp, which bio2_memetic's line search amplifies into different trajectories, so the bit-for-bit parity tests of
+// the kernels run the oracle in mode 1.  The two modes agree to a few ulp per operation.
+inline int& trig_mode() {
+    static int mode = 0;
+    return mode;
+}
+inline bool fused() { return trig_mode() == 1; }
+inline double madd(double a, double b, double c) { return fused() ? BK_FMA(a, b, c) : a * b + c; }  // a*b + c
 
 struct Vec3 {
     double x, y, z;
@@ -32,7 +47,10 @@ inline Vec3 operator+(const Vec3& a, const Vec3& b) { return {a.x + b.x, a.y + b
 inline Vec3 operator-(const Vec3& a, const Vec3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline Vec3 operator-(const Vec3& a) { return {-a.x, -a.y, -a.z}; }
 inline Vec3 operator*(const Vec3& a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-inline double dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline double dot(const Vec3& a, const Vec3& b) {
+    if (fused()) return bk_dot3(a.x, a.y, a.z, b.x, b.y, b.z);
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 inline double length2(const Vec3& a) { return dot(a, a); }
 inline double length(const Vec3& a) { return std::sqrt(length2(a)); }
 inline double distance2(const Vec3& a, const Vec3& b) { return length2(b - a); }  // tf2: (v - *this).length2()
@@ -55,7 +73,10 @@ inline double angle(const Vec3& a, const Vec3& b) {  // tf2::Vector3::angle
 }
 
 // ---- tf2::Quaternion semantics (tf2/LinearMath/Quaternion.h) ----
-inline double dot(const Quat& a, const Quat& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+inline double dot(const Quat& a, const Quat& b) {
+    if (fused()) return bk_dot4(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
 inline double length2(const Quat& a) { return dot(a, a); }
 inline Quat operator+(const Quat& a, const Quat& b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 inline Quat operator-(const Quat& a, const Quat& b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
@@ -87,6 +108,12 @@ inline Vec3 get_axis(const Quat& q) {                                   // tf2::
 
 // ---- reference frame.h:108-149 ----
 inline void quat_mul_vec(const Quat& q, const Vec3& v, Vec3& r) {
+    if (fused()) {
+        Vec3 o;
+        bk_qrot(q.x, q.y, q.z, q.w, v.x, v.y, v.z, o.x, o.y, o.z);
+        r = o;
+        return;
+    }
     double v_x = v.x, v_y = v.y, v_z = v.z;
     double q_x = q.x, q_y = q.y, q_z = q.z, q_w = q.w;
     if ((v_x == 0 && v_y == 0 && v_z == 0) || (q_x == 0 && q_y == 0 && q_z == 0 && q_w == 1)) {
@@ -110,6 +137,12 @@ inline void quat_mul_vec(const Quat& q, const Vec3& v, Vec3& r) {
 
 // ---- reference frame.h:151-172 ----
 inline void quat_mul_quat(const Quat& p, const Quat& q, Quat& r) {
+    if (fused()) {
+        Quat o;
+        bk_qmul(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w, o.x, o.y, o.z, o.w);
+        r = o;
+        return;
+    }
     double p_x = p.x, p_y = p.y, p_z = p.z, p_w = p.w;
     double q_x = q.x, q_y = q.y, q_z = q.z, q_w = q.w;
     double r_x = (p_w * q_x + p_x * q_w) + (p_y * q_z - p_z * q_y);

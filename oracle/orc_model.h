@@ -16,14 +16,6 @@
 
 namespace orc {
 
-// Trigonometry of the revolute joint frames.  0 (default): libm sin/cos, as the reference calls them
-// (forward_kinematics.h:96-97).  1: the bit-reproducible bioik_sincos shared with the device kernels — libm and the
-// GPU math library differ in the last ulp, which bio2_memetic's line search amplifies into different trajectories,
-// so trajectory-level (bit-for-bit) parity tests run the oracle in mode 1.  The two modes agree to < 2 ulp.
-inline int& trig_mode() {
-    static int mode = 0;
-    return mode;
-}
 // Reference quirks.  0 (default): the two deliberate fixes the device shares — Q1: computeApproximateMutation1 writes the
 // unchanged input frame for tips a variable does not move; Q4: children are pre-selected in a STABLE order.
 // 1: literal reference behaviour — Q1: such tips keep whatever the output buffer held (forward_kinematics.h:1017 `continue`),
@@ -388,13 +380,13 @@ struct RobotFK {
             const Frame& tf = input[t];
             double px = tf.pos.x, py = tf.pos.y, pz = tf.pos.z;
             double rx = tf.rot.x, ry = tf.rot.y, rz = tf.rot.z, rw = tf.rot.w;
-            px += jd.pos.x * variable_delta;
-            py += jd.pos.y * variable_delta;
-            pz += jd.pos.z * variable_delta;
-            rx += jd.rot.x * variable_delta;
-            ry += jd.rot.y * variable_delta;
-            rz += jd.rot.z * variable_delta;
-            rw += jd.rot.w * variable_delta;
+            px = madd(jd.pos.x, variable_delta, px);
+            py = madd(jd.pos.y, variable_delta, py);
+            pz = madd(jd.pos.z, variable_delta, pz);
+            rx = madd(jd.rot.x, variable_delta, rx);
+            ry = madd(jd.rot.y, variable_delta, ry);
+            rz = madd(jd.rot.z, variable_delta, rz);
+            rw = madd(jd.rot.w, variable_delta, rw);
             output[t] = Frame{{px, py, pz}, {rx, ry, rz, rw}};
         }
     }
@@ -412,13 +404,13 @@ struct RobotFK {
                 for (size_t vii : approx_map[t]) {
                     size_t variable_index = approx_variable_indices[vii];
                     double variable_delta = mutation_values[m][vii] - p_variables[variable_index];
-                    px += joint_deltas[variable_index].pos.x * variable_delta;
-                    py += joint_deltas[variable_index].pos.y * variable_delta;
-                    pz += joint_deltas[variable_index].pos.z * variable_delta;
-                    rx += joint_deltas[variable_index].rot.x * variable_delta;
-                    ry += joint_deltas[variable_index].rot.y * variable_delta;
-                    rz += joint_deltas[variable_index].rot.z * variable_delta;
-                    rw += joint_deltas[variable_index].rot.w * variable_delta;
+                    px = madd(joint_deltas[variable_index].pos.x, variable_delta, px);
+                    py = madd(joint_deltas[variable_index].pos.y, variable_delta, py);
+                    pz = madd(joint_deltas[variable_index].pos.z, variable_delta, pz);
+                    rx = madd(joint_deltas[variable_index].rot.x, variable_delta, rx);
+                    ry = madd(joint_deltas[variable_index].rot.y, variable_delta, ry);
+                    rz = madd(joint_deltas[variable_index].rot.z, variable_delta, rz);
+                    rw = madd(joint_deltas[variable_index].rot.w, variable_delta, rw);
                 }
                 out[m * tip_count + t] = Frame{{px, py, pz}, {rx, ry, rz, rw}};
             }
