@@ -139,27 +139,14 @@ struct XV {
 // ---------------------------------------------------------------------------------------------------------
 // goal costs (goal_types.h); joint-set goals walk the active ops.
 // ---------------------------------------------------------------------------------------------------------
-BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
-    const int n_ops = pb->n_ops;
-#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
-    type = G_POSE;
-#endif
+// The link goals beyond position / orientation / pose: one out-of-line copy (sqrt, divisions, acos) instead of one per
+// evaluation site.  p: the goal's numbers (at most 11, goal_types.h), by value.
+struct GoalPar {
+    double v[11];
+};
+BIOIK_CALL double goal_eval_link_rare(int type, GoalPar gp, F7 fb) {
+    const double* P = gp.v;
     switch (type) {
-        case G_POSITION:  // goal_types.h:96
-            return dist2(fb.p, v3(P[0], P[1], P[2]));
-        case G_ORIENTATION: {  // :115-124
-            const Q4 d = Q4{P[0] - fb.q.x, P[1] - fb.q.y, P[2] - fb.q.z, P[3] - fb.q.w};
-            const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
-            return fmin(qdot(d, d), qdot(a, a));
-        }
-        case G_POSE: {  // :149-180
-            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
-            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
-            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
-            double rs = P[7];
-            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
-            return e;
-        }
         case G_LOOK_AT: {  // :204-211
             V3 axis = qrot(fb.q, v3(P[0], P[1], P[2]));
             V3 target = v3(P[3], P[4], P[5]);
@@ -181,6 +168,56 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             V3 position = v3(P[0], P[1], P[2]), normal = v3(P[3], P[4], P[5]);
             double sd = dot3(fb.p - position, normal);
             return sd * sd;
+        }
+        case G_SIDE: {  // :606-613
+            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
+            double f = fmax(0.0, dot3(v, v3(P[3], P[4], P[5])));
+            return f * f;
+        }
+        case G_DIRECTION: {  // :637-643
+            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
+            return dist2(v, v3(P[3], P[4], P[5]));
+        }
+        case G_CONE: {  // :700-711
+            V3 v = qrot(fb.q, v3(P[4], P[5], P[6]));
+            V3 dir = v3(P[7], P[8], P[9]);
+            double ang = clamped_acos(dot3(v, dir) / sqrt(len2(v) * len2(dir)));
+            double d = fmax(0.0, ang - P[10]);
+            double w = P[3];
+            return d * d + w * w * len2(v3(P[0], P[1], P[2]) - fb.p);
+        }
+    }
+    return 0.0;
+}
+BIOIK_DEV int goal_param_count(int type) {  // include/bioik_hip.h bioik_goal_param_count
+    switch (type) {
+        case G_LOOK_AT: case G_LINE: case G_PLANE: case G_SIDE: case G_DIRECTION: return 6;
+        case G_MAX_DISTANCE: case G_MIN_DISTANCE: return 4;
+        case G_CONE: return 11;
+    }
+    return 0;
+}
+
+BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
+    const int n_ops = pb->n_ops;
+#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
+    type = G_POSE;
+#endif
+    switch (type) {
+        case G_POSITION:  // goal_types.h:96
+            return dist2(fb.p, v3(P[0], P[1], P[2]));
+        case G_ORIENTATION: {  // :115-124
+            const Q4 d = Q4{P[0] - fb.q.x, P[1] - fb.q.y, P[2] - fb.q.z, P[3] - fb.q.w};
+            const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
+            return fmin(qdot(d, d), qdot(a, a));
+        }
+        case G_POSE: {  // :149-180
+            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
+            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
+            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
+            double rs = P[7];
+            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
+            return e;
         }
         case G_AVOID_JOINT_LIMITS: {  // :387-401
             double sum = 0.0;
@@ -227,22 +264,12 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             double d = P[0] - v;
             return d * d;
         }
-        case G_SIDE: {  // :606-613
-            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
-            double f = fmax(0.0, dot3(v, v3(P[3], P[4], P[5])));
-            return f * f;
-        }
-        case G_DIRECTION: {  // :637-643
-            V3 v = qrot(fb.q, v3(P[0], P[1], P[2]));
-            return dist2(v, v3(P[3], P[4], P[5]));
-        }
-        case G_CONE: {  // :700-711
-            V3 v = qrot(fb.q, v3(P[4], P[5], P[6]));
-            V3 dir = v3(P[7], P[8], P[9]);
-            double ang = clamped_acos(dot3(v, dir) / sqrt(len2(v) * len2(dir)));
-            double d = fmax(0.0, ang - P[10]);
-            double w = P[3];
-            return d * d + w * w * len2(v3(P[0], P[1], P[2]) - fb.p);
+        default: {  // the remaining link goals
+            GoalPar gp;
+            const int np = goal_param_count(type);
+#pragma unroll
+            for (int i = 0; i < 11; i++) gp.v[i] = i < np ? P[i] : 0.0;
+            return goal_eval_link_rare(type, gp, fb);
         }
     }
     return 0.0;
@@ -317,22 +344,23 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
         for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
             const int k = k0 + j;
             if (k >= n_chain) break;
-            const int ls = pb->ops[k].load_slot;
+            const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
+            const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+            const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
+            const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
+            const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
             if (ls >= 0) {
                 const double* s = slots + (size_t)ls * 7 * nth + tid;
                 f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
-            } else if (k > 0 && pb->ops[k].src < 0) {
+            } else if (k > 0 && src < 0) {
                 f = f7_identity();
             }
-            const bool rev = pb->ops[k].type == BIOIK_OP_REVOLUTE;
+            const bool rev = type == BIOIK_OP_REVOLUTE;
             const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
-            const Q4 lq = Q4{BK_FMA(c, pb->ops[k].ca[0], s * pb->ops[k].cb[0]), BK_FMA(c, pb->ops[k].ca[1], s * pb->ops[k].cb[1]),
-                             BK_FMA(c, pb->ops[k].ca[2], s * pb->ops[k].cb[2]), BK_FMA(c, pb->ops[k].ca[3], s * pb->ops[k].cb[3])};
-            const V3 lp = v3(BK_FMA(xp, pb->ops[k].cb[0], pb->ops[k].cpos[0]), BK_FMA(xp, pb->ops[k].cb[1], pb->ops[k].cpos[1]),
-                             BK_FMA(xp, pb->ops[k].cb[2], pb->ops[k].cpos[2]));
+            const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
+            const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
             f.p = f.p + qrot(f.q, lp);
             f.q = qmul(f.q, lq);
-            const int ss = pb->ops[k].save_slot;
             if (ss >= 0) {
                 double* sl = slots + (size_t)ss * 7 * nth + tid;
                 sl[0] = f.p.x;
@@ -344,7 +372,6 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
                 sl[(size_t)6 * nth] = f.q.w;
             }
             if (frames_out) f7_store(frames_out + k * 7, f);  // only the publishing lane passes a non-null pointer
-            const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
             for (int t = t0; t < t1; t++) {
                 if (pb->tips[t].has_e) {
                     double e[7];
@@ -364,6 +391,109 @@ BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc,
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); });
     sum += nonlink_primary(pb, x, qc);
     return sum;
+}
+
+// N individuals per lane at once (the children a lane owns in one generation): the same walk with N independent
+// dependency chains, so that the scalar loads of a joint's constants, the LDS reads of the gene values and the latency of the
+// polynomial chains are paid once per joint instead of once per joint and child.  Arithmetic per individual is identical
+// to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
+template <int N, class TipFn>
+BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn) {
+    const int tid = p_tid(), nth = p_nthreads();
+    const int n_chain = pb->n_chain_ops;
+    F7 f[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) f[j] = f7_identity();
+    for (int t = 0; t < pb->n_root_tips; t++) {
+        F7 o[N];
+        if (pb->tips[t].has_e) {
+            double e[7];
+            for (int c = 0; c < 7; c++) e[c] = pb->tips[t].e[c];
+#pragma unroll
+            for (int j = 0; j < N; j++) o[j] = f7_load(e);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; j++) o[j] = f[j];
+        }
+        tip_fn(t, o);
+    }
+    for (int k = 0; k < n_chain; k++) {
+        // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
+        // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
+        const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
+        const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+        const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
+        const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
+        const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
+        double xv[N], sn[N], cs[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) xv[j] = x[j](k);
+#pragma unroll
+        for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
+        if (ls >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double* s = slots + (size_t)j * slot_set_stride + (size_t)ls * 7 * nth + tid;
+                f[j] = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
+            }
+        } else if (k > 0 && src < 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) f[j] = f7_identity();
+        }
+        const bool rev = type == BIOIK_OP_REVOLUTE;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
+            const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
+            const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
+            f[j].p = f[j].p + qrot(f[j].q, lp);
+            f[j].q = qmul(f[j].q, lq);
+        }
+        if (ss >= 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double* sl = slots + (size_t)j * slot_set_stride + (size_t)ss * 7 * nth + tid;
+                sl[0] = f[j].p.x;
+                sl[(size_t)nth] = f[j].p.y;
+                sl[(size_t)2 * nth] = f[j].p.z;
+                sl[(size_t)3 * nth] = f[j].q.x;
+                sl[(size_t)4 * nth] = f[j].q.y;
+                sl[(size_t)5 * nth] = f[j].q.z;
+                sl[(size_t)6 * nth] = f[j].q.w;
+            }
+        }
+        for (int t = t0; t < t1; t++) {
+            F7 o[N];
+            if (pb->tips[t].has_e) {
+                double e[7];
+                for (int c2 = 0; c2 < 7; c2++) e[c2] = pb->tips[t].e[c2];
+#pragma unroll
+                for (int j = 0; j < N; j++) o[j] = f7_concat(f[j], f7_load(e));
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; j++) o[j] = f[j];
+            }
+            tip_fn(t, o);
+        }
+    }
+}
+template <int N>
+BIOIK_DEV void eval_exact_primary_n(ProbPtr pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = 0.0;
+    fk_walk_n<N>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
+        // the goals of the tip, each evaluated for the N individuals (per individual: the summation order of tip_goals)
+        const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
+        for (int g = g0; g < g1; g++) {
+            const int type = pb->primary[g].type, var_op = pb->primary[g].var_op, var_seed = pb->primary[g].var_seed, po = pb->primary[g].param_off;
+            const double w = pb->primary[g].weight_sq;
+            const double* P = qc.par + po;
+#pragma unroll
+            for (int j = 0; j < N; j++) out[j] += goal_eval(pb, type, var_op, var_seed, P, f[j], x[j], qc) * w;
+        }
+    });
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -533,6 +663,91 @@ BIOIK_DEV void reproduce_child(ProbPtr pb, uint32_t key, uint32_t ctr1, uint32_t
             }
 }
 
+// N children of one lane at once (same parents, same generation): N x 4 interleaved random streams per trip and the
+// parents' genes / momentum and the joint limits loaded once.  Per child the arithmetic of reproduce_child.
+template <int M>
+BIOIK_DEV void philox2x32_10_xm(uint32_t key, const uint32_t (&c0in)[M], uint32_t c1in, uint32_t (&o0)[M], uint32_t (&o1)[M]) {
+    uint32_t c0[M], c1[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) c0[j] = c0in[j], c1[j] = c1in;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        if (r > 0) key += 0x9E3779B9u;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0[j];
+            uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
+            c0[j] = hi ^ key ^ c1[j];
+            c1[j] = lo;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < M; j++) o0[j] = c0[j], o1[j] = c1[j];
+}
+template <int N>
+BIOIK_DEV void reproduce_children(ProbPtr pb, uint32_t key, uint32_t ctr1, const uint32_t (&child_index)[N], const double* p0g, const double* p0d,
+                                  const double* p1d, double* const (&xo)[N], int xs) {
+    BIOIK_FP_STRICT
+    const int n_ops = pb->n_ops, D = pb->D;
+    double fmix[N], gradient_factor[N], mutation_rate[N];
+    {
+        uint32_t c0[N], r0[N], r1[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) c0[i] = rng_ctr0(child_index[i], RNG_SLOT_RATE);
+        philox2x32_10_xm<N>(key, c0, ctr1, r0, r1);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            fmix[i] = (child_index[i] % 2u == 0u) ? 0.2 : 0.0;
+            gradient_factor[i] = (double)(child_index[i] % 3u);
+            mutation_rate[i] = (double)(1u << (r0[i] & 15u)) * (1.0 / (double)(1 << 23));
+        }
+    }
+    for (int g0 = 0; g0 < D; g0 += 4) {
+        uint32_t c0[4 * N], q0[4 * N], q1[4 * N];
+        int kk[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int g = g0 + j < D ? g0 + j : D - 1;
+            kk[j] = pb->op_of_gene[g];
+#pragma unroll
+            for (int i = 0; i < N; i++) c0[i * 4 + j] = rng_ctr0(child_index[i], (uint32_t)g);
+        }
+        philox2x32_10_xm<4 * N>(key, c0, ctr1, q0, q1);
+        double gene[N][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kk[j];
+            const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
+            const double parent_gene = p0g[k], d0 = p0d[k], d1 = p1d[k];
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                double r = rng_gauss(q0[i * 4 + j], q1[i * 4 + j]);
+                double f = mutation_rate[i] * span;
+                double gn = parent_gene;
+                gn += r * f;
+                double parent_gradient = d0 * (1.0 - fmix[i]) + d1 * fmix[i];
+                double g2 = parent_gradient * gradient_factor[i];
+                gn += g2;
+                gn = fmin(fmax(gn, cmin), cmax);
+                gene[i][j] = gn;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (g0 + j < D) {
+#pragma unroll
+                for (int i = 0; i < N; i++) xo[i][(size_t)kk[j] * xs] = gene[i][j];
+            }
+    }
+    if (D < n_ops)
+        for (int k = 0; k < n_ops; k++)
+            if (pb->ops[k].gene < 0) {
+                const double v = p0g[k];  // inactive op: the seed's value, carried by every elite
+#pragma unroll
+                for (int i = 0; i < N; i++) xo[i][(size_t)k * xs] = v;
+            }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // success test of one tip / of the gene-only primary goals (problem.cpp:259-341)
 // ---------------------------------------------------------------------------------------------------------
@@ -603,6 +818,38 @@ BIOIK_DEV double angle_shortest_path(Q4 a, Q4 b) {  // tf2::Quaternion::angleSho
     return clamped_acos(d / s) * 2.0;
 }
 
+// position / orientation / pose goals (problem.cpp:270-323): one out-of-line copy of the KDL-equivalent twist arithmetic
+// (sqrt, atan2, acos, divisions) for all the success-test sites; values in, value out
+BIOIK_CALL int check_frame_goal(int type, F7 fa, F7 fb, double dpos, double drot, double dtwist) {
+    bool ok = true;
+    if (type == G_POSITION) {
+        if (dpos != BIOIK_DBL_MAX) ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 0; k < 3; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    } else if (type == G_ORIENTATION) {
+        if (drot != BIOIK_DBL_MAX) ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 3; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    } else {
+        if (dpos != BIOIK_DBL_MAX || drot != BIOIK_DBL_MAX) {
+            ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
+            ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
+        }
+        if (dtwist != BIOIK_DBL_MAX) {
+            double tw[6];
+            pose_twist(fa, fb, tw);
+            for (int k = 0; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
+        }
+    }
+    return ok ? 1 : 0;
+}
+
 BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const QueryCtx& qc, double dpos, double drot, double dtwist) {
 #ifdef BIOIK_EXP_POSE_ONLY
     const int type = G_POSE;
@@ -614,32 +861,14 @@ BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const Qu
     if (type == G_POSITION) {
         F7 fa = f7_identity();
         fa.p = v3(P[0], P[1], P[2]);
-        if (dpos != BIOIK_DBL_MAX) ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
-        if (dtwist != BIOIK_DBL_MAX) {
-            double tw[6];
-            pose_twist(fa, fb, tw);
-            for (int k = 0; k < 3; k++) ok = ok && (fabs(tw[k]) < dtwist);
-        }
+        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
     } else if (type == G_ORIENTATION) {
         F7 fa = f7_identity();
         fa.q = Q4{P[0], P[1], P[2], P[3]};
-        if (drot != BIOIK_DBL_MAX) ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
-        if (dtwist != BIOIK_DBL_MAX) {
-            double tw[6];
-            pose_twist(fa, fb, tw);
-            for (int k = 3; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
-        }
+        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
     } else if (type == G_POSE) {
         F7 fa = F7{{P[0], P[1], P[2]}, {P[3], P[4], P[5], P[6]}};
-        if (dpos != BIOIK_DBL_MAX || drot != BIOIK_DBL_MAX) {
-            ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
-            ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
-        }
-        if (dtwist != BIOIK_DBL_MAX) {
-            double tw[6];
-            pose_twist(fa, fb, tw);
-            for (int k = 0; k < 6; k++) ok = ok && (fabs(tw[k]) < dtwist);
-        }
+        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
     } else {
         double dmax = fmin(BIOIK_DBL_MAX, fmin(dpos, dtwist));
         double d = goal_eval(pb, type, pb->primary[g].var_op, pb->primary[g].var_seed, P, fb, x, qc) * pb->primary[g].weight_sq;

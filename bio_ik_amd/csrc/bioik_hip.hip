@@ -206,9 +206,9 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0, child_cols, groups).total * 8;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0, child_cols, groups, slot_sets).total * 8;
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
@@ -230,7 +230,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups) > 48 * 1024) {
         sp.child_cols = 1;
     }
-    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups);
+    // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
+    // trees, a second set of parked frames
+    sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, 2) <= 64 * 1024) ? 1 : 0;
+    if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
+        if (std::atoi(e) == 0) sp.child_pairs = 0;
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
 #if !defined(BIOIK_HOSTSIM)
     if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -25,7 +25,7 @@ struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species g
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
-                               int groups = 1) {
+                               int groups = 1, int slot_sets = 1) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -35,7 +35,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.sol = o, o += m;
     L.state = o, o += 2 * 8 + 4;        // species bookkeeping exchanged between the two species groups + workgroup broadcast slots
     L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
-    L.slots = o, o += n_slots * 7 * nthreads;
+    L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
     int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
     L.xn = g, g += m;
     L.gv = g, g += m;
@@ -157,6 +157,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int tid = p_tid(), nth = p_nthreads(), lane = tid & 63;
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
+    const uint32_t active_mask = pb->active_mask;  // bit k: op k is a gene
     const bool has_sec = pb->n_secondary > 0;
     const bool exact = sp.fk_mode == FK_EXACT;
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
@@ -165,7 +166,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int groups = sp.species_parallel ? 2 : 1;
     const int G = nth / groups;        // lanes per species group (a multiple of 64)
     const int grp = tid / G, gtid = tid - grp * G;
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec, n_cols, groups);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec, n_cols, groups, sp.child_pairs ? 2 : 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -291,20 +292,42 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 double b1f = P_INF, b2f = P_INF;
                 int b1p = 0x7fffffff, b2p = 0x7fffffff;
                 const bool stored = n_cols * G >= lambda;  // every child keeps its own column until selection
-                for (int r = gtid, j = 0; r < n_eval; r += G, j++) {
-                    int c = has_sec ? s_order[r] : r;
-                    double* xc = stored ? xcol + (size_t)j * M * nth : xcol;
-                    const XV xv{xc, nth};
-                    reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xc, nth, nullptr, 0);
-                    PHASE_MARK(PH_REPRODUCE);
-                    double f = exact ? eval_exact_primary(pb, xv, qc, s_slots) : eval_linear_primary(pb, xv, qc, lm);
-                    PHASE_MARK(PH_FITNESS);
-                    int pos = r + 2;
+                auto offer = [&](double f, int pos) {
                     if (cand_better(f, pos, b1f, b1p)) {
                         b2f = b1f, b2p = b1p;
                         b1f = f, b1p = pos;
                     } else if (cand_better(f, pos, b2f, b2p)) {
                         b2f = f, b2p = pos;
+                    }
+                };
+                if (stored && sp.child_pairs && exact) {
+                    // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
+                    for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
+                        const int r1 = r + G;
+                        const bool two = r1 < n_eval;
+                        const int c0 = has_sec ? s_order[r] : r;
+                        const int c1 = two ? (has_sec ? s_order[r1] : r1) : c0;
+                        double* const xc[2] = {xcol + (size_t)j * M * nth, two ? xcol + (size_t)(j + 1) * M * nth : xcol + (size_t)j * M * nth};
+                        const uint32_t ci[2] = {(uint32_t)c0 + 2u, (uint32_t)c1 + 2u};
+                        reproduce_children<2>(pb, key, ctr1, ci, p0g, p0d, p1d, xc, nth);
+                        PHASE_MARK(PH_REPRODUCE);
+                        const XV xv[2] = {XV{xc[0], nth}, XV{xc[1], nth}};
+                        double f[2];
+                        eval_exact_primary_n<2>(pb, xv, qc, s_slots, pb->n_slots * 7 * nth, f);
+                        PHASE_MARK(PH_FITNESS);
+                        offer(f[0], r + 2);
+                        if (two) offer(f[1], r1 + 2);
+                    }
+                } else {
+                    for (int r = gtid, j = 0; r < n_eval; r += G, j++) {
+                        int c = has_sec ? s_order[r] : r;
+                        double* xc = stored ? xcol + (size_t)j * M * nth : xcol;
+                        const XV xv{xc, nth};
+                        reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xc, nth, nullptr, 0);
+                        PHASE_MARK(PH_REPRODUCE);
+                        double f = exact ? eval_exact_primary(pb, xv, qc, s_slots) : eval_linear_primary(pb, xv, qc, lm);
+                        PHASE_MARK(PH_FITNESS);
+                        offer(f, r + 2);
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
@@ -340,7 +363,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         for (int k = gtid; k < n_ops; k += G) {
                             double gene = src[(size_t)k * nth];
                             double mom = 0.0;
-                            if (pb->ops[k].gene >= 0) {
+                            if ((active_mask >> k) & 1u) {
                                 double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
                                 mom = parent_gradient * (1.0 - 0.3) + (gene - p0g[k]) * 0.3;
                             }
@@ -373,6 +396,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     if (rng_uniform(o0, o1) < 0.5) dp = -dp;
                 }
                 const int my_op = gtid < D ? pb->op_of_gene[gtid] : -1;  // lane i of the group differentiates gene i
+                // gradient in op order (zero for the ops that are not genes), next to the gene-ordered copy the L1 norm sums
+                double* s_gop = s_gv;
+                for (int k = gtid; k < n_ops; k += G) s_gop[k] = 0.0;
+                group_sync(G);
+                const double* cand = (lds + L.xcol) + grp * G;  // the line-search candidate: column of the group's lane 0
                 bool live = true;  // still descending; the leading wavefront of the group does the arithmetic
                 for (int it = 0; it < 8; it++) {
                     double f2p = 0.0, fa = 0.0;
@@ -396,23 +424,24 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             fbp += nonlink_primary(pb, xl, qc);
                             double fb = fbp + secondary_fitness(pb, xl, qc);
                             s_grad[gtid] = fb - fa;
+                            s_gop[my_op] = fb - fa;
                         }
                     }
                     group_sync(G);
                     PHASE_MARK(PH_MEM_GRAD);
+                    // From here every lane of the leading wavefront carries the whole line search redundantly in its own
+                    // genotype column (no hand-over through LDS, no rendezvous): L1 norm (:477-482), the two support points
+                    // x-g (even lanes) / x+g (odd lanes) (:485-495), the step (:498-568), the clipped candidate and its fitness.
                     if (live && glead) {
-                        double sum = dp * dp;  // :477-482
+                        double sum = dp * dp;
                         for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
                         const double fnorm = 1.0 / sum * dp;
-                        for (int k = gtid; k < n_ops; k += 64) s_gv[k] = pb->ops[k].gene >= 0 ? s_grad[pb->ops[k].gene] * fnorm : 0.0;
-                    }
-                    group_sync(G);
-                    PHASE_MARK(PH_MEM_NORM);
-                    if (live && glead) {
-                        // support points x-g (even lanes) and x+g (odd lanes), :485-495
+                        PHASE_MARK(PH_MEM_NORM);
                         const double sgn = (lane & 1) ? 1.0 : -1.0;
-                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * s_gv[k];
+                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * (s_gop[k] * fnorm);
+                        PHASE_MARK(22);
                         double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
+                        PHASE_MARK(23);
                         const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
                         double step_size;
                         if (sp.memetic == 'q') {  // :498-539
@@ -423,20 +452,26 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             double cost_diff = (f3 - f1) * 0.5;
                             step_size = -(f2 / cost_diff);
                         }
-                        for (int k = gtid; k < n_ops; k += 64)
-                            s_xn[k] = pb->ops[k].gene >= 0 ? fmin(fmax(el[k] + s_gv[k] * step_size, pb->ops[k].clip_min), pb->ops[k].clip_max) : el[k];
-                    }
-                    group_sync(G);
-                    PHASE_MARK(PH_MEM_LINE);
-                    if (live && glead) {
-                        const double f4p = eval_linear_primary(pb, XV{s_xn, 1}, qc, lm);
+                        for (int k = 0; k < n_ops; k++) {
+                            const double cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
+                            const double e = el[k], gv = s_gop[k] * fnorm;
+                            xcol[(size_t)k * nth] = ((active_mask >> k) & 1u) ? fmin(fmax(e + gv * step_size, cmin), cmax) : e;
+                        }
+                        PHASE_MARK(PH_PRESELECT);
+                        const double f4p = eval_linear_primary(pb, xl, qc, lm);
                         if (!(f4p < f2p)) live = false;  // accept iff the primary fitness improves, else stop (:527-538)
                     }
-                    if (gtid == 0) s_bc[1] = live ? 1.0 : 0.0;
-                    group_sync(G);
-                    live = s_bc[1] != 0.0;
+                    PHASE_MARK(PH_MEM_LINE);
+                    if (G > 64) {  // the other wavefronts of the group learn the verdict
+                        if (gtid == 0) s_bc[1] = live ? 1.0 : 0.0;
+                        p_barrier();
+                        live = s_bc[1] != 0.0;
+                        p_barrier();
+                    } else {
+                        p_wave_sync();  // every lane has read the elite before it is replaced (program order on the device)
+                    }
                     if (live)
-                        for (int k = gtid; k < n_ops; k += G) el[k] = s_xn[k];
+                        for (int k = gtid; k < n_ops; k += G) el[k] = cand[(size_t)k * nth];
                     group_sync(G);
                     PHASE_MARK(PH_MEM_ACCEPT);
                     if ((groups == 1 || G == 64) && !live) break;  // only groups sharing workgroup barriers must keep each other's count

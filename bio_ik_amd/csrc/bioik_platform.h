@@ -17,6 +17,7 @@
 #include <memory>
 #include <vector>
 #define BIOIK_DEV inline
+#define BIOIK_CALL __attribute__((noinline)) inline
 #define BIOIK_CONTRACT_OFF
 typedef const DevProblem* ProbPtr;
 
@@ -62,6 +63,9 @@ BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
 // ------------------------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
 #define BIOIK_DEV __device__ __forceinline__
+// A real function (one copy in the kernel, its own register allocation) for cold, arithmetic-heavy code.  Only for functions
+// whose arguments and results are plain values: ROCm 7.2's gfx950 backend rejects LDS pointers that cross a call boundary.
+#define BIOIK_CALL __device__ __attribute__((noinline))
 // uniform, read-only problem block: the constant address space makes every access a scalar (s_load) candidate
 typedef const DevProblem __attribute__((address_space(4))) * ProbPtr;
 

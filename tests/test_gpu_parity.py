@@ -71,6 +71,7 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_SPECIES_PARALLEL": "0"},  # four wavefronts, species one after the other
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_STORE_CHILDREN": "0"},    # winners re-derived from the RNG
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_CHILD_PAIRS": "0"},       # one child per trip instead of two
 ])
 def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
     """the same solve under every lane <-> work mapping the launcher can choose"""

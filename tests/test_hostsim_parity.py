@@ -69,6 +69,7 @@ def test_trajectory_two_wavefronts_and_islands(sims, oracles, templates, monkeyp
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_STORE_CHILDREN": "0"},   # winners re-derived from the RNG instead of read back
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_SPECIES_PARALLEL": "0"}, # two wavefronts, species one after the other
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_CHILD_PAIRS": "0"},      # one child per trip instead of two
 ])
 def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, env):
     for k, v in env.items():

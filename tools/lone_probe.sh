@@ -7,8 +7,8 @@ for cfg in "1 128" "1 256" "1536 128"; do set -- $cfg
   python - <<PY
 import numpy as np
 a=np.fromfile("/tmp/phase.bin",dtype=np.uint64).reshape(-1,28).astype(np.float64)
-names=["init","reproduce","fitness","selection","memetics","species","check","preselect","sel.top2","sel.xwave","sel.copy","sel.barrier","mem.approx","mem.grad","mem.norm","mem.line","mem.accept","mem.tail","rank","#mem_iter","#steps","linearise"]
-m=a.mean(axis=0); steps=m[20]; tot=m[:19].sum()+m[21]
+names=["init","reproduce","fitness","selection","memetics","species","check","preselect","sel.top2","sel.xwave","sel.copy","sel.barrier","mem.approx","mem.grad","mem.norm","mem.line","mem.accept","mem.tail","rank","#mem_iter","#steps","linearise","mem.support_cols","mem.support_eval"]
+m=a.mean(axis=0); steps=m[20]; tot=m[:19].sum()+m[21]+m[22]+m[23]
 wall=(a[:,25]-a[:,24]).mean()*10.0  # ns
 print("== batch $1 threads $2: %.1f steps, %.1f us/step wall, %.0f shader cycles/step (lane 0 of the workgroup), %.2f memetic iterations per step (both species counted on wave 0 only)" % (steps, wall/1e3/steps, tot/steps, m[19]/steps))
 for i,n in enumerate(names):
