@@ -354,6 +354,12 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.V = nv;
     dev.P = param_count;
     dev.n_slots = n_slots;
+    int n_prefix = 0;
+    while (n_prefix < n_chain && ops[n_prefix].gene < 0 && ops[n_prefix].src == n_prefix - 1 && ops[n_prefix].tip_count == 0 &&
+           ops[n_prefix].save_slot < 0 && ops[n_prefix].load_slot < 0)
+        n_prefix++;
+    if (n_prefix == n_chain) n_prefix = 0;  // nothing left to walk: no point
+    dev.n_prefix = n_prefix;
     for (size_t k = 0; k < ops.size(); k++) {
         dev.ops[k] = ops[k];
         if (ops[k].gene >= 0) dev.active_mask |= 1u << k;

@@ -314,8 +314,10 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) 
 #ifndef BIOIK_FK_BLOCK
 #define BIOIK_FK_BLOCK 1  // measured on MI355X: 1, 2 and 4 are within 3 % (the kernel is not latency-bound here)
 #endif
+//   prefix     LDS or null, [7]: the frame behind ops[0..n_prefix), which is the same for every individual of the query; the
+//              walk then starts at op n_prefix (the kernels that own a query compute it once, fk_prefix)
 template <class TipFn>
-BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn) {
+BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f = f7_identity();
@@ -331,7 +333,12 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
     // BIOIK_FK_BLOCK joints per trip.  Phase A: their values and half-angle trigonometry — independent polynomial
     // chains the scheduler can interleave (sincos is computed for prismatic joints too and discarded: no branch).
     // Phase B: the four rigid transforms, which are inherently sequential.
-    for (int k0 = 0; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
+    int k_begin = 0;
+    if (prefix) {
+        k_begin = pb->n_prefix;
+        if (k_begin > 0) f = f7_load(prefix);
+    }
+    for (int k0 = k_begin; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
         double xv[BIOIK_FK_BLOCK], sn[BIOIK_FK_BLOCK], cs[BIOIK_FK_BLOCK];
 #pragma unroll
         for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
@@ -386,9 +393,30 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
 }
 
 // primary fitness on the exact-FK phenotype (ik_base.h:203-207 semantics, per individual)
-BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, double* slots) {
+// the frame behind the leading run of non-gene joints (DevProblem::n_prefix) at the values x: exactly the frame fk_walk
+// holds after those joints
+BIOIK_DEV F7 fk_prefix(ProbPtr pb, const XV& x) {
+    F7 f = f7_identity();
+    const int n = pb->n_prefix;
+    for (int k = 0; k < n; k++) {
+        double sn, cs;
+        const double xv = x(k);
+        p_sincos(xv * 0.5, &sn, &cs);
+        const bool rev = pb->ops[k].type == BIOIK_OP_REVOLUTE;
+        const double s = rev ? sn : 0.0, c = rev ? cs : 1.0, xp = rev ? 0.0 : xv;
+        const Q4 lq = Q4{BK_FMA(c, pb->ops[k].ca[0], s * pb->ops[k].cb[0]), BK_FMA(c, pb->ops[k].ca[1], s * pb->ops[k].cb[1]),
+                         BK_FMA(c, pb->ops[k].ca[2], s * pb->ops[k].cb[2]), BK_FMA(c, pb->ops[k].ca[3], s * pb->ops[k].cb[3])};
+        const V3 lp = v3(BK_FMA(xp, pb->ops[k].cb[0], pb->ops[k].cpos[0]), BK_FMA(xp, pb->ops[k].cb[1], pb->ops[k].cpos[1]),
+                         BK_FMA(xp, pb->ops[k].cb[2], pb->ops[k].cpos[2]));
+        f.p = f.p + qrot(f.q, lp);
+        f.q = qmul(f.q, lq);
+    }
+    return f;
+}
+
+BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
     double sum = 0.0;
-    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); });
+    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); }, prefix);
     sum += nonlink_primary(pb, x, qc);
     return sum;
 }
@@ -398,7 +426,7 @@ BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc,
 // polynomial chains are paid once per joint instead of once per joint and child.  Arithmetic per individual is identical
 // to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
 template <int N, class TipFn>
-BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn) {
+BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f[N];
@@ -417,7 +445,16 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
         }
         tip_fn(t, o);
     }
-    for (int k = 0; k < n_chain; k++) {
+    int k_begin = 0;
+    if (prefix) {
+        k_begin = pb->n_prefix;
+        if (k_begin > 0) {
+            const F7 f0 = f7_load(prefix);
+#pragma unroll
+            for (int j = 0; j < N; j++) f[j] = f0;
+        }
+    }
+    for (int k = k_begin; k < n_chain; k++) {
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
         const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
@@ -478,7 +515,8 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
     }
 }
 template <int N>
-BIOIK_DEV void eval_exact_primary_n(ProbPtr pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N]) {
+BIOIK_DEV void eval_exact_primary_n(ProbPtr pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
+                                    const double* prefix = nullptr) {
 #pragma unroll
     for (int j = 0; j < N; j++) out[j] = 0.0;
     fk_walk_n<N>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
@@ -491,7 +529,7 @@ BIOIK_DEV void eval_exact_primary_n(ProbPtr pb, const XV (&x)[N], const QueryCtx
 #pragma unroll
             for (int j = 0; j < N; j++) out[j] += goal_eval(pb, type, var_op, var_seed, P, f[j], x[j], qc) * w;
         }
-    });
+    }, prefix);
 #pragma unroll
     for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc);
 }
@@ -887,7 +925,8 @@ struct FitCheck {
     double fitness;
     int ok;
 };
-BIOIK_NOINLINE FitCheck exact_fitness_check(ProbPtr pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check) {
+BIOIK_NOINLINE FitCheck exact_fitness_check(ProbPtr pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check,
+                                            const double* prefix = nullptr) {
     bool good = true;
     double sum = 0.0;
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
@@ -896,7 +935,7 @@ BIOIK_NOINLINE FitCheck exact_fitness_check(ProbPtr pb, XV x, QueryCtx qc, doubl
             const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
             for (int g = g0; g < g1; g++) good = check_goal(pb, g, f, x, qc, dpos, drot, dtwist) && good;
         }
-    });
+    }, prefix);
     sum += nonlink_primary(pb, x, qc);
     if (do_check) {
         const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};

@@ -21,7 +21,7 @@
 #endif
 
 struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species group (stride g_stride)
-    int seed, par, pop, sol, state, xcol, slots, g_first, g_stride, total;
+    int seed, par, pop, sol, prefix, state, xcol, slots, g_first, g_stride, total;
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
@@ -33,6 +33,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.par = o, o += P > 0 ? P : 1;
     L.pop = o, o += 2 * 2 * 2 * 2 * m;  // [species][buffer][individual][genes|momentum][op]
     L.sol = o, o += m;
+    L.prefix = o, o += 8;               // frame behind the leading non-gene joints (DevProblem::n_prefix), per query
     L.state = o, o += 2 * 8 + 4;        // species bookkeeping exchanged between the two species groups + workgroup broadcast slots
     L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
@@ -64,17 +65,24 @@ BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f <
 
 // all-lanes top-2 of (f,pos) over the workgroup: every lane brings its own best two (b1 <= b2); wave64 xor-butterfly
 // merging sorted pairs, then one LDS hop across waves.  Positions are unique, so (f,pos) is a total order.
+// merge another sorted pair (o1 <= o2) into (b1 <= b2); positions are unique, so (f, pos) is a total order and the top-2 of
+// a union does not depend on the order of the merges
+BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o1f, int o1p, double o2f, int o2p) {
+    if (cand_better(o1f, o1p, b1f, b1p)) {
+        if (cand_better(b1f, b1p, o2f, o2p)) b2f = b1f, b2p = b1p; else b2f = o2f, b2p = o2p;
+        b1f = o1f, b1p = o1p;
+    } else if (cand_better(o1f, o1p, b2f, b2p)) {
+        b2f = o1f, b2p = o1p;
+    }
+}
+// wave64 xor-butterfly: afterwards every lane holds the two best of the wavefront.  (A DPP reduction with row broadcasts and
+// scalar read-back was measured 30 % slower than these six ds_bpermute rounds on gfx950.)
 BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         double o1f = p_shfl_xor(b1f, m), o2f = p_shfl_xor(b2f, m);
         int o1p = p_shfl_xor(b1p, m), o2p = p_shfl_xor(b2p, m);
-        if (cand_better(o1f, o1p, b1f, b1p)) {
-            if (cand_better(b1f, b1p, o2f, o2p)) b2f = b1f, b2p = b1p; else b2f = o2f, b2p = o2p;
-            b1f = o1f, b1p = o1p;
-        } else if (cand_better(o1f, o1p, b2f, b2p)) {
-            b2f = o1f, b2p = o1p;
-        }
+        top2_merge(b1f, b1p, b2f, b2p, o1f, o1p, o2f, o2p);
     }
 }
 // rendezvous of one lane group: a single wavefront needs no s_barrier (p_wave_sync), several wavefronts take the workgroup
@@ -112,12 +120,13 @@ BIOIK_DEV void top2_xwave(double& b1f, int& b1p, double& b2f, int& b2p, double* 
 // RobotFK::applyConfiguration + initializeMutationApproximator at the (workgroup-shared) individual x:
 // the joint frames are published to LDS by lane 0 (the per-joint frame chain), then lanes fan out over (tip, op).
 // (gtid, G): index and size of the cooperating lane group (the whole workgroup, or one species group of it)
-BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G) {
+BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G,
+                                       const double* prefix = nullptr) {
     const int n_ops = pb->n_ops, T = pb->T;
     if (gtid < 64)  // one wavefront walks the chain (lane 0 publishes); the others wait at the barrier
         fk_walk(pb, x, slots, gtid == 0 ? s_frames : nullptr, [&](int t, const F7& f) {
             if (gtid == 0) f7_store(s_tips + t * 7, f);
-        });
+        }, prefix);
     for (int k = gtid; k < n_ops; k += G) s_base[k] = x(k);
     group_sync(G);
     for (int idx = gtid; idx < T * n_ops; idx += G) {
@@ -171,6 +180,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
     double* s_sol = lds + L.sol;
+    double* s_prefix = lds + L.prefix;
     double* s_state = lds + L.state;
     double* s_slots = lds + L.slots;
     double* gbase = lds + L.g_first + grp * L.g_stride;  // this group's scratch
@@ -218,7 +228,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     };
     auto wg_check = [&](const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
         FitCheck fc{0.0, 0};
-        if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check);
+        if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);
         if (nth > 64) {
             if (tid == 0) s_wbc[0] = fc.fitness, s_wbc[1] = (double)fc.ok;
             p_barrier();
@@ -241,6 +251,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         s_sol[k] = v;
     }
     p_barrier();
+    if (pb->n_prefix > 0) {  // the joints in front of the first gene see the seed in every individual: walk them once per query
+        if (tid == 0) f7_store(s_prefix, fk_prefix(pb, XV{s_sol, 1}));
+        p_barrier();
+    }
     double sol_fit = wg_check(XV{s_sol, 1}, 0.0, 0.0, 0.0, 0).fitness;
     SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0};
     const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
@@ -256,7 +270,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             if (!exact) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
                 const double* cb = popS + S.cur * BF;
-                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G);
+                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);
                 S.pf0 = group_value([&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
                 S.pf1 = group_value([&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
             }
@@ -313,7 +327,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         PHASE_MARK(PH_REPRODUCE);
                         const XV xv[2] = {XV{xc[0], nth}, XV{xc[1], nth}};
                         double f[2];
-                        eval_exact_primary_n<2>(pb, xv, qc, s_slots, pb->n_slots * 7 * nth, f);
+                        eval_exact_primary_n<2>(pb, xv, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
                         PHASE_MARK(PH_FITNESS);
                         offer(f[0], r + 2);
                         if (two) offer(f[1], r1 + 2);
@@ -325,7 +339,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         const XV xv{xc, nth};
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xc, nth, nullptr, 0);
                         PHASE_MARK(PH_REPRODUCE);
-                        double f = exact ? eval_exact_primary(pb, xv, qc, s_slots) : eval_linear_primary(pb, xv, qc, lm);
+                        double f = exact ? eval_exact_primary(pb, xv, qc, s_slots, s_prefix) : eval_linear_primary(pb, xv, qc, lm);
                         PHASE_MARK(PH_FITNESS);
                         offer(f, r + 2);
                     }
@@ -387,7 +401,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             if (sp.memetic) {
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
-                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G);  // fresh linearisation at the elite
+                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);  // fresh linearisation at the elite
                 PHASE_MARK(PH_MEM_APPROX);
                 double dp = 0.0000001;
                 {
@@ -482,7 +496,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             // species ranking fitness: exact FK of the elite (:607-614)
             {
                 const double* cb = popS + S.cur * BF;
-                double fit = group_value([&]() { return exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0).fitness; });
+                double fit = group_value([&]() { return exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0, s_prefix).fitness; });
                 S.improved = (fit != S.fit) ? 1 : 0;
                 S.fit = fit;
                 S.pf0 = fit;

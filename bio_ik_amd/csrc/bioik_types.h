@@ -69,6 +69,9 @@ struct DevProblem {
     int32_t n_secondary;
     int32_t n_slots;
     uint32_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
+    int32_t n_prefix;      // ops[0..n_prefix): a straight run of joints at the root that are not genes and carry no tip and no
+                           // branch: their frame is the same for every individual of a query (the seed's), computed once
+    int32_t pad0;
     int32_t op_of_gene[BIOIK_MAX_OPS];
     int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
     DevOp ops[BIOIK_MAX_OPS];
