@@ -25,7 +25,13 @@ inline int& trig_mode() {
     static int mode = 0;
     return mode;
 }
+#if defined(ORC_FIXED_ARITH_MODE)
+// timing build (liboracle_ref.so): the mode is a compile-time constant, so the reference-arithmetic code carries no run-time
+// test per multiply-add and vectorises as the reference's own code does
+inline constexpr bool fused() { return ORC_FIXED_ARITH_MODE == 1; }
+#else
 inline bool fused() { return trig_mode() == 1; }
+#endif
 inline double madd(double a, double b, double c) { return fused() ? BK_FMA(a, b, c) : a * b + c; }  // a*b + c
 
 struct Vec3 {

@@ -138,7 +138,7 @@ struct RobotFK {
                 double v = vars[l.first_var];
                 double half_angle = v * 0.5;
                 double fcos, fsin;
-                if (trig_mode() == 1) {
+                if (fused()) {
                     bioik_sincos(half_angle, &fsin, &fcos);
                 } else {
                     fcos = std::cos(half_angle);

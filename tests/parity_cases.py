@@ -66,7 +66,7 @@ def success_check_near_goal(h, o, template, rng, n=64):
 
 def trajectory(h, o, template, n, pop, steps_list, seed=7, exact_bits=True, **kw):
     """Whole solves with identical RNG streams: the device result must equal the oracle's (bit for bit when both sides
-    use bioik_sincos and unfused arithmetic)."""
+    use bioik_sincos and the explicitly fused forms of bioik_fused.h, compiler contraction off)."""
     seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=seed)
     for steps in steps_list:
         p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=11, **kw)

@@ -1,7 +1,7 @@
 """Parity tests proper: the HIP path (libbioik_hip.so on a real MI355X, through the C-ABI) against the CPU oracle.
 
 Three levels: function level (same genes -> same frames / fitness / tables / children / success flags),
-trajectory level (same RNG streams -> the same solution, bit for bit: both sides use bioik_sincos and unfused IEEE
+trajectory level (same RNG streams -> the same solution, bit for bit: both sides use bioik_sincos and the explicitly fused IEEE
 arithmetic), result level at BASELINE.json's full sizes (every reported success reproduces its goal pose under the
 ORACLE's exact FK within 1e-4 m / 1e-3 rad, joints inside their limits, success rate equal to the oracle's on a sample)."""
 import numpy as np

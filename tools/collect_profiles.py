@@ -5,7 +5,8 @@ g = os.path.join(ROOT, "gpurun_out"); p = os.path.join(ROOT, "profiles"); rnd = 
 shutil.copy(os.path.join(g, "prof_r01", "r01_kernel_stats.csv"), os.path.join(p, rnd + "_kernel_stats.csv"))
 shutil.copy(os.path.join(g, "bench_r01.json"), os.path.join(p, rnd + "_bench.json"))
 out = {}
-for f in ("pmc_fetch/f_counter_collection.csv", "pmc_write/w_counter_collection.csv", "pmc_sq/s_counter_collection.csv"):
+for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_collection.csv", "pmc_sq/sq_counter_collection.csv", "pmc_mem/mem_counter_collection.csv", "pmc_ic/ic_counter_collection.csv"):
+    if not os.path.exists(os.path.join(g, f)): continue
     rows = list(csv.DictReader(open(os.path.join(g, f)))); agg = collections.defaultdict(list)
     for r in rows:
         if "k_solve" in r["Kernel_Name"]:
