@@ -6,6 +6,9 @@ right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), 
 `value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
 GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
+Consecutive steps are issued round-robin on two HIP streams (`--in-flight`, config.batches_in_flight): the tail of one
+launch — a handful of queries that use the whole step budget — overlaps the bulk of the next; `one_batch_at_a_time` holds
+the same measurement with strictly one launch after the other.
 
 Extra objects on the JSON line:
   roofline     dominant kernel k_solve against the HBM roofline: ALGORITHMIC bytes per launch (SURVEY.md §8d,
@@ -41,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "2")),
+                    help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other)")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,33 +81,49 @@ def main():
 
     d_seeds = torch.from_numpy(seeds).to(dev)
     d_params = torch.from_numpy(params).to(dev)
-    d_sol = torch.empty((BATCH, V), dtype=torch.float64, device=dev)
-    d_fit = torch.empty(BATCH, dtype=torch.float64, device=dev)
-    d_suc = torch.empty(BATCH, dtype=torch.int32, device=dev)
-    d_steps = torch.empty(BATCH, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    # Consecutive steps go round-robin to `in_flight` HIP streams with their own result buffers: a launch of 4096 queries
+    # ends with a long tail (the few queries that use the whole step budget run ~13 ms each) during
+    # which the chip is nearly empty; with two launches in flight the next batch's bulk fills it.  Every step is a complete
+    # pass of the hot path over one batch and every batch's results are complete when the timed region ends.
+    nfl = max(1, args.in_flight)
+    streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
+    bufs = [(torch.empty((BATCH, V), dtype=torch.float64, device=dev), torch.empty(BATCH, dtype=torch.float64, device=dev),
+             torch.empty(BATCH, dtype=torch.int32, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev)) for _ in range(nfl)]
+    torch.cuda.synchronize(dev)
 
-    def step():
-        h.solve_batch_device(p, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), d_sol.data_ptr(), d_fit.data_ptr(), d_suc.data_ptr(),
-                             d_steps.data_ptr(), stream.cuda_stream)
+    def step(i):
+        o, st = bufs[i % nfl], streams[i % nfl]
+        h.solve_batch_device(p, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                             st.cuda_stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)  # events on the stream the kernel is launched on
-        step()
-        b.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else 0.0
+    def timed(n_steps, n_warm):
+        for i in range(n_warm):
+            step(i)
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+        t0 = time.perf_counter()
+        for i, (a, b) in enumerate(ev):
+            a.record(streams[i % nfl])  # events on the stream the kernel is launched on
+            step(i)
+            b.record(streams[i % nfl])
+        barrier()
+        el = time.perf_counter() - t0
+        return el, (float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else 0.0)
+
+    elapsed, kernel_ms = timed(args.steps, args.warmup)
+    d_sol, d_fit, d_suc, d_steps = bufs[0]
+    identical = all(bool(torch.equal(o[0], d_sol)) and bool(torch.equal(o[2], d_suc)) and bool(torch.equal(o[3], d_steps)) for o in bufs[1:])
+    sequential = None
+    if nfl > 1:  # the same steps strictly one after the other, for the record
+        nfl_saved, nfl = nfl, 1
+        sel, skm = timed(min(args.steps, 10), 1)
+        nfl = nfl_saved
+        sequential = (sel / max(min(args.steps, 10), 1), skm)
 
     suc = d_suc.cpu().numpy()
     steps_q = d_steps.cpu().numpy()
@@ -150,20 +171,28 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
-                   "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective"},
+                   "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective",
+                   "batches_in_flight": nfl},
         "success_rate": float(suc.mean()),
         "mean_steps_per_solve": float(steps_q.mean()),
         "max_pos_err_m_of_successes": pos_err,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "kernel": "k_solve", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6)"},
+                     "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6); "
+                             "kernel_ms is the event-bracketed duration of one launch while %d launches share the chip" % nfl,
+                     "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0},
+        "results_identical_across_streams": identical,
     }
+    if sequential is not None and world == 1:
+        out["one_batch_at_a_time"] = {"value": n_success / sequential[0], "unit": "solves/s", "ms_per_step": sequential[0] * 1e3, "kernel_ms": sequential[1],
+                                      "roofline_frac": alg_bytes / (sequential[1] * 1e-3) / HBM_PEAK if sequential[1] > 0 else 0.0}
 
     # Secondary measurement (north-star layout): the population genotype array resident in HBM, genes [unit][D][pop]
     # (individual index fastest), one launch = exact-FK fitness of every individual.  Reported next to the solver line;
     # it is not what `value` measures.
     if rank == 0 and world == 1 and os.environ.get("BIOIK_BENCH_STREAM", "1") != "0":
         units = 16384
+        stream = torch.cuda.current_stream(dev)
         g = torch.rand((units, D, POP), dtype=torch.float64, device=dev) * 2.0 - 1.0
         f = torch.empty((units, POP), dtype=torch.float64, device=dev)
         us = d_seeds[torch.arange(units, device=dev) % BATCH].contiguous()
