@@ -8,4 +8,5 @@ from . import abi  # noqa: F401
 from .goals import *  # noqa: F401,F403
 from .problem import ProblemTemplate  # noqa: F401
 from .robot import RobotModel, JointModelGroup, pr2_like, snake  # noqa: F401
+from .urdf import load_urdf  # noqa: F401
 from .plugin import BioIKKinematicsPlugin, KinematicsQueryOptions, MoveItErrorCodes  # noqa: F401

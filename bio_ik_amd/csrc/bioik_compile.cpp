@@ -93,6 +93,9 @@ HostModel::HostModel(const bioik_model_desc& d) {
         l.first_var = d.joint_first_variable[i];
         l.var_count = joint_var_count(l.type);
         l.mimic = d.joint_mimic ? d.joint_mimic[i] : -1;
+        l.mimic_factor = (l.mimic >= 0 && d.joint_mimic_factor) ? d.joint_mimic_factor[i] : 1.0;
+        l.mimic_offset = (l.mimic >= 0 && d.joint_mimic_offset) ? d.joint_mimic_offset[i] : 0.0;
+        if (l.mimic >= (int)d.n_links || l.mimic == (int)i) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "mimic joint index out of range");
         if (l.var_count > 0) {
             if (l.first_var < 0 || l.first_var + l.var_count > (int)d.n_variables) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "joint variable index out of range");
             for (int v = 0; v < l.var_count; v++) var_joint[l.first_var + v] = (int)i;
@@ -213,7 +216,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     std::vector<DevOp> ops;
     for (int l : schedule) {
         const HostModel::Link& L = m->links[l];
-        if (L.mimic >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "mimic joints have no device implementation in this version");
+        if (L.mimic >= 0 && m->links[L.mimic].mimic >= 0)
+            throw Error(BIOIK_ERR_UNSUPPORTED, "chains of mimic joints (a mimic of a mimic) have no device implementation in this version");
         int base_src = L.parent >= 0 ? src_of[L.parent] : -1;
         Frame base_c = L.parent >= 0 ? c_of[L.parent] : identity();
         Frame C = concat(base_c, L.origin);
@@ -231,6 +235,12 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         op.gene = gene_of_var[L.first_var];
         op.src = base_src;
         op.load_slot = op.save_slot = -1;
+        op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+        if (L.mimic >= 0) {  // resolved to an op index below, once every op exists
+            op.gene = -1;
+            op.mimic_src = -2 - L.mimic;
+            op.mimic_factor = L.mimic_factor, op.mimic_offset = L.mimic_offset;
+        }
         for (int c = 0; c < 3; c++) op.cpos[c] = C.p[c], op.axis[c] = L.axis[c];
         for (int c = 0; c < 4; c++) op.ca[c] = C.q[c];
         if (op.type == BIOIK_OP_REVOLUTE) {
@@ -259,7 +269,38 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         op.var = v;
         op.gene = i;
         op.src = op.load_slot = op.save_slot = -1;
+        op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
         ops.push_back(op);
+    }
+    // mimic joints read the value of the joint they follow: resolve it to an op (a followed joint that is on no goal chain
+    // gets a value-only op; it is not a gene then, so it carries the seed's value)
+    std::vector<int> value_op_of_var(nv, -1);
+    for (size_t k = 0; k < ops.size(); k++)
+        if (ops[k].mimic_src == -1) value_op_of_var[ops[k].var] = (int)k;
+    for (int k = 0; k < n_chain; k++) {
+        if (ops[k].mimic_src >= -1) continue;
+        const int src_link = -2 - ops[k].mimic_src;
+        const int sv = m->links[src_link].first_var;
+        if (sv < 0 || m->links[src_link].var_count != 1) throw Error(BIOIK_ERR_UNSUPPORTED, "mimic of a joint without exactly one variable");
+        if (value_op_of_var[sv] < 0) {
+            DevOp op;
+            std::memset(&op, 0, sizeof(op));
+            op.type = BIOIK_OP_NONE;
+            op.var = sv;
+            op.gene = gene_of_var[sv];
+            op.src = op.load_slot = op.save_slot = -1;
+            op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+            if (op.gene >= 0) {
+                const HostModel::Var& vi = m->vars[sv];
+                op.clip_min = vi.clip_min, op.clip_max = vi.clip_max, op.span = vi.span, op.vmin = vi.vmin, op.vmax = vi.vmax;
+                op.unbounded = vi.clip_max == DBL_MAX;
+                op.vw = vw[op.gene];
+                dev.op_of_gene[op.gene] = (int)ops.size();
+            }
+            value_op_of_var[sv] = (int)ops.size();
+            ops.push_back(op);
+        }
+        ops[k].mimic_src = value_op_of_var[sv];
     }
     if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 32 moving joints on the goal chains");
     if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 8 tip links");
@@ -355,14 +396,15 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.P = param_count;
     dev.n_slots = n_slots;
     int n_prefix = 0;
-    while (n_prefix < n_chain && ops[n_prefix].gene < 0 && ops[n_prefix].src == n_prefix - 1 && ops[n_prefix].tip_count == 0 &&
-           ops[n_prefix].save_slot < 0 && ops[n_prefix].load_slot < 0)
+    while (n_prefix < n_chain && ops[n_prefix].gene < 0 && ops[n_prefix].mimic_src < 0 && ops[n_prefix].src == n_prefix - 1 &&
+           ops[n_prefix].tip_count == 0 && ops[n_prefix].save_slot < 0 && ops[n_prefix].load_slot < 0)
         n_prefix++;
     if (n_prefix == n_chain) n_prefix = 0;  // nothing left to walk: no point
     dev.n_prefix = n_prefix;
     for (size_t k = 0; k < ops.size(); k++) {
         dev.ops[k] = ops[k];
         if (ops[k].gene >= 0) dev.active_mask |= 1u << k;
+        if ((int)k < n_chain && ops[k].mimic_src >= 0) dev.mimic_followers[ops[k].mimic_src] |= 1u << k;
     }
 }
 

@@ -26,6 +26,7 @@ struct HostModel {
         int parent, type, first_var, var_count, mimic;
         Frame origin;
         double axis[3];
+        double mimic_factor, mimic_offset;
     };
     struct Var {
         double clip_min, clip_max, span, vmin, vmax, max_velocity_rcp;

@@ -311,6 +311,15 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) 
 //   tip_fn(t, frame): called with device tip index t as soon as the tip's frame is complete
 // The loop trip count and every constant are wave-uniform: control flow is scalar, constants arrive in SGPRs.
 // ---------------------------------------------------------------------------------------------------------
+// value of the joint of op k in the individual x: its own entry, or for a mimic joint factor * (entry of the joint it
+// follows) + offset (RobotFK_Fast_Base::updateMimic, forward_kinematics.h:230-246; a plain multiply and add)
+BIOIK_DEV double joint_value(const XV& x, int k, int mimic_src, double mimic_factor, double mimic_offset) {
+    BIOIK_FP_STRICT
+    double v = x(k);
+    if (mimic_src >= 0) v = x(mimic_src) * mimic_factor + mimic_offset;
+    return v;
+}
+
 #ifndef BIOIK_FK_BLOCK
 #define BIOIK_FK_BLOCK 1  // measured on MI355X: 1, 2 and 4 are within 3 % (the kernel is not latency-bound here)
 #endif
@@ -343,7 +352,7 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
 #pragma unroll
         for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
             const int kk = k0 + j < n_chain ? k0 + j : n_chain - 1;
-            xv[j] = x(kk);
+            xv[j] = joint_value(x, kk, pb->ops[kk].mimic_src, pb->ops[kk].mimic_factor, pb->ops[kk].mimic_offset);
         }
 #pragma unroll
         for (int j = 0; j < BIOIK_FK_BLOCK; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
@@ -459,12 +468,14 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
         const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
         const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+        const int msrc = pb->ops[k].mimic_src;
+        const double mf = pb->ops[k].mimic_factor, mo = pb->ops[k].mimic_offset;
         const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
         const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
         const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
         double xv[N], sn[N], cs[N];
 #pragma unroll
-        for (int j = 0; j < N; j++) xv[j] = x[j](k);
+        for (int j = 0; j < N; j++) xv[j] = joint_value(x[j], k, msrc, mf, mo);
 #pragma unroll
         for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
         if (ls >= 0) {
@@ -588,29 +599,46 @@ BIOIK_DEV double eval_linear_primary(ProbPtr pb, const XV& x, const QueryCtx& qc
 
 // One (tip, op) entry of the approximator tables from the published joint frames:
 // tip-local Jacobian column (forward_kinematics.h:639-693) -> world delta frame (:827-852).
-BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames, const double* tips, double* out7) {
-    bool dep = ((pb->tips[t].dep_mask >> k) & 1u) != 0 && pb->ops[k].gene >= 0 && k < pb->n_chain_ops;
-    if (!dep) {
-        for (int c = 0; c < 7; c++) out7[c] = 0.0;
-        return;
-    }
-    F7 lf = f7_load(frames + k * 7);
-    F7 tf = f7_load(tips + t * 7);
-    V3 axis = v3(pb->ops[k].axis[0], pb->ops[k].axis[1], pb->ops[k].axis[2]);
+// tip-local Jacobian column of ONE joint (op m) for tip t: linear and angular part (forward_kinematics.h:639-693)
+BIOIK_DEV void jacobian_column(ProbPtr pb, int m, const F7& lf, const F7& tf, V3& vel, V3& om) {
+    V3 axis = v3(pb->ops[m].axis[0], pb->ops[m].axis[1], pb->ops[m].axis[2]);
     // tf2 Quaternion product inverse(link.rot) * tip.rot, then inverse
     Q4 a = qinv(lf.q), b = tf.q;
     Q4 q = Q4{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
               a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
     q = qinv(q);
     V3 rot = qrot(q, axis);
-    V3 vel, om;
-    if (pb->ops[k].type == BIOIK_OP_REVOLUTE) {
+    if (pb->ops[m].type == BIOIK_OP_REVOLUTE) {
         V3 d = qrot(qinv(tf.q), lf.p - tf.p);
         vel = cross3(d, rot);
         om = rot;
     } else {
         vel = rot;
         om = v3(0.0, 0.0, 0.0);
+    }
+}
+BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames, const double* tips, double* out7) {
+    BIOIK_FP_STRICT
+    const uint32_t dep_mask = pb->tips[t].dep_mask;
+    const int n_chain = pb->n_chain_ops;
+    const bool gene = pb->ops[k].gene >= 0;
+    const bool own = gene && k < n_chain && ((dep_mask >> k) & 1u) != 0;
+    const uint32_t followers = gene ? pb->mimic_followers[k] & dep_mask : 0u;  // mimic joints of this gene on the tip's chain
+    if (!own && followers == 0u) {
+        for (int c = 0; c < 7; c++) out7[c] = 0.0;
+        return;
+    }
+    F7 tf = f7_load(tips + t * 7);
+    V3 vel = v3(0.0, 0.0, 0.0), om = v3(0.0, 0.0, 0.0);
+    if (own) jacobian_column(pb, k, f7_load(frames + k * 7), tf, vel, om);
+    // the joints that mimic this one move with it: their columns, scaled (joint_dependencies, forward_kinematics.h:623-636)
+    for (uint32_t rest = followers; rest != 0u; rest &= rest - 1u) {
+        const int m = __builtin_ctz(rest);
+        V3 v2, o2;
+        jacobian_column(pb, m, f7_load(frames + m * 7), tf, v2, o2);
+        const double scale = pb->ops[m].mimic_factor;
+        vel = v3(vel.x + v2.x * scale, vel.y + v2.y * scale, vel.z + v2.z * scale);
+        om = v3(om.x + o2.x * scale, om.y + o2.y * scale, om.z + o2.z * scale);
     }
     V3 dp = qrot(tf.q, vel);
     Q4 dq = qmul(tf.q, Q4{om.x * 0.5, om.y * 0.5, om.z * 0.5, 1.0});

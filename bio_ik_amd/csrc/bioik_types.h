@@ -26,6 +26,7 @@ struct DevOp {
     double clip_min, clip_max, span; // RobotInfo (include/bio_ik/robot_info.h:70-106) of the variable
     double vmin, vmax;               // variable bounds (random re-initialisation, ik_evolution_2.cpp:626-631)
     double vw;                       // minimal_displacement_factors (src/problem.cpp:207-225)
+    double mimic_factor, mimic_offset;  // mimic joint: value = x(mimic_src) * factor + offset (forward_kinematics.h:230-246)
     int32_t type;                    // BIOIK_OP_*
     int32_t var;                     // robot variable index
     int32_t gene;                    // index into Problem::active_variables, or -1 (inactive: value comes from the seed)
@@ -34,7 +35,7 @@ struct DevOp {
     int32_t save_slot;               // >=0: output frame is parked in this LDS slot for a later branch
     int32_t tip_first, tip_count;    // device tips whose frame is F_out o E (evaluated right after this op)
     int32_t unbounded;               // clip_max == DBL_MAX (goal_types.h:394,419)
-    int32_t pad;
+    int32_t mimic_src;               // op whose value this joint mimics, -1: the joint has its own value x(k)
 };
 
 struct DevTip {
@@ -72,6 +73,7 @@ struct DevProblem {
     int32_t n_prefix;      // ops[0..n_prefix): a straight run of joints at the root that are not genes and carry no tip and no
                            // branch: their frame is the same for every individual of a query (the seed's), computed once
     int32_t pad0;
+    uint32_t mimic_followers[BIOIK_MAX_OPS];  // bit m: chain op m is a mimic joint following op k
     int32_t op_of_gene[BIOIK_MAX_OPS];
     int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
     DevOp ops[BIOIK_MAX_OPS];

@@ -78,6 +78,28 @@ def gnarly():
     return gnarly_robot()
 
 
+def mimic_robot():
+    """Axis-aligned 6-joint arm (test fixture only) with two mimic joints (MoveIt JointModel::getMimic): the second elbow
+    follows the shoulder pitch (a gene), and a finger on the tip's chain follows a finger that is on no goal chain (so the
+    followed joint is not a gene and keeps the seed's value, reference problem.cpp:191-204)."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("mimic_arm")
+    m.add_link("base")
+    m.add_link("l1", "base", "s1", "revolute", xyz=(0.0, 0.0, 0.3), axis=(0, 0, 1), lower=-2.5, upper=2.5, velocity=2.0)
+    m.add_link("l2", "l1", "s2", "revolute", xyz=(0.0, 0.1, 0.0), axis=(0, 1, 0), lower=-1.8, upper=1.8, velocity=2.0)
+    m.add_link("l3", "l2", "e1", "revolute", xyz=(0.35, 0.0, 0.0), axis=(0, 1, 0), lower=-2.2, upper=2.2, velocity=2.5)
+    m.add_link("l4", "l3", "e2", "revolute", xyz=(0.25, 0.0, 0.0), axis=(0, 1, 0), lower=-3.0, upper=3.0, velocity=2.5, mimic=("s2", -0.5, 0.1))
+    m.add_link("l5", "l4", "w1", "revolute", xyz=(0.2, 0.0, 0.0), axis=(1, 0, 0), lower=-3.0, upper=3.0, velocity=3.0)
+    m.add_link("l6", "l5", "w2", "revolute", xyz=(0.1, 0.0, 0.0), axis=(0, 1, 0), lower=-2.0, upper=2.0, velocity=3.0)
+    m.add_link("tool", "l6", "tool_joint", "fixed", xyz=(0.08, 0.0, 0.0))
+    m.add_link("finger_l", "l6", "finger_l_joint", "prismatic", xyz=(0.05, 0.03, 0.0), axis=(0, 1, 0), lower=0.0, upper=0.04, velocity=0.1)
+    m.add_link("finger_r", "l6", "finger_r_joint", "prismatic", xyz=(0.05, -0.03, 0.0), axis=(0, -1, 0), lower=0.0, upper=0.04, velocity=0.1,
+               mimic=("finger_l_joint", 1.0, 0.0))
+    m.add_link("finger_r_tip", "finger_r", "finger_r_tip_joint", "fixed", xyz=(0.04, 0.0, 0.0))
+    m.add_group("arm", joints=["s1", "s2", "e1", "e2", "w1", "w2", "finger_l_joint", "finger_r_joint"], tips=["tool", "finger_r_tip"])
+    return m
+
+
 def gnarly_goals():
     """one goal of every device opcode, spread over four tips (one of them the joint-less `plate`)"""
     from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, ConeGoal, DirectionGoal, JointVariableGoal, LineGoal, LookAtGoal,

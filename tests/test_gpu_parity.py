@@ -45,6 +45,26 @@ def test_function_level_gnarly(gnarly):
     pc.function_level(HipSolver(t2), orc.Oracle(t2), gnarly, np.random.default_rng(3), n=2000)
 
 
+def test_mimic_joints():
+    """a joint that follows a gene and a joint that follows a joint outside every goal chain (MoveIt mimic joints,
+    forward_kinematics.h:230-246, 623-636): function level, and whole solves bit for bit"""
+    from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
+    from bio_ik_amd.solver import HipSolver
+    from conftest import mimic_robot
+    m = mimic_robot()
+    sec = MinimalDisplacementGoal(weight=0.5)
+    sec.secondary_ = True
+    t = ProblemTemplate(m, "arm", [PoseGoal("tool"), PositionGoal("finger_r_tip", weight=0.3), sec])
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == 5
+    pc.function_level(h, o, m, np.random.default_rng(5), n=500)
+    t2 = ProblemTemplate(m, "arm", [PoseGoal("tool"), sec])
+    h2, o2 = HipSolver(t2), orc.Oracle(t2)
+    pc.function_level(h2, o2, m, np.random.default_rng(6), n=500, exact_bits=True)
+    pc.trajectory(h2, o2, t2, n=16, pop=128, steps_list=(1, 6))
+    pc.trajectory(h2, o2, t2, n=8, pop=70, steps_list=(3,), fk_mode=abi.FK_LINEAR)
+
+
 def test_success_check_near_threshold(gpus, oracles, templates):
     pc.success_check_near_goal(gpus["c2"], oracles["c2"], templates["c2"], np.random.default_rng(4), n=64)
 

@@ -94,3 +94,23 @@ def test_edge_cases(sims, oracles, templates):
     p = abi.default_solve_params(population=16, max_steps=5)
     sol, fit, suc, steps = h.solve_batch(p, s2, p2)
     assert suc.all() and np.all(steps == 1)
+
+
+
+def test_mimic_joints(hostsim_lib):
+    """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
+    from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
+    from conftest import mimic_robot
+    m = mimic_robot()
+    sec = MinimalDisplacementGoal(weight=0.5)
+    sec.secondary_ = True
+    t = ProblemTemplate(m, "arm", [PoseGoal("tool"), PositionGoal("finger_r_tip", weight=0.3), sec])
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    assert h.D == o.D == 5  # s1 s2 e1 w1 w2: the mimic joints and the off-chain finger are not genes
+    pc.function_level(h, o, m, np.random.default_rng(5), n=60)  # 1e-12: the folded prismatic finger rounds differently
+    # whole solves, bit for bit, on the revolute part (the elbow that follows the shoulder)
+    t2 = ProblemTemplate(m, "arm", [PoseGoal("tool"), sec])
+    h2, o2 = HipSolver(t2, lib=hostsim_lib), orc.Oracle(t2)
+    pc.function_level(h2, o2, m, np.random.default_rng(6), n=60, exact_bits=True)
+    pc.trajectory(h2, o2, t2, n=2, pop=16, steps_list=(1, 3))
+    pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)

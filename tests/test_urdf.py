@@ -1,0 +1,81 @@
+"""bio_ik_amd.urdf: the URDF/SRDF reader produces exactly the model a hand-built RobotModel describes (indices in MoveIt's
+depth-first order, mimic joints resolved although the followed joint comes later in the file, SRDF chains / joint lists /
+sub-groups / end effectors), and the oracle solves on it."""
+import numpy as np
+import pytest
+
+from bio_ik_amd import PoseGoal, ProblemTemplate, abi
+from bio_ik_amd.urdf import load_urdf
+from conftest import mimic_robot
+
+URDF = """<?xml version="1.0"?>
+<robot name="mimic_arm">
+  <link name="base"/> <link name="l1"/> <link name="l2"/> <link name="l3"/> <link name="l4"/> <link name="l5"/> <link name="l6"/>
+  <link name="tool"/> <link name="finger_l"/> <link name="finger_r"/> <link name="finger_r_tip"/>
+  <joint name="e2" type="revolute"><parent link="l3"/><child link="l4"/><origin xyz="0.25 0 0"/><axis xyz="0 1 0"/>
+    <limit lower="-3.0" upper="3.0" velocity="2.5" effort="1"/><mimic joint="s2" multiplier="-0.5" offset="0.1"/></joint>
+  <joint name="s1" type="revolute"><parent link="base"/><child link="l1"/><origin xyz="0 0 0.3" rpy="0 0 0"/><axis xyz="0 0 1"/>
+    <limit lower="-2.5" upper="2.5" velocity="2.0" effort="1"/></joint>
+  <joint name="s2" type="revolute"><parent link="l1"/><child link="l2"/><origin xyz="0 0.1 0"/><axis xyz="0 1 0"/>
+    <limit lower="-1.8" upper="1.8" velocity="2.0" effort="1"/></joint>
+  <joint name="e1" type="revolute"><parent link="l2"/><child link="l3"/><origin xyz="0.35 0 0"/><axis xyz="0 1 0"/>
+    <limit lower="-2.2" upper="2.2" velocity="2.5" effort="1"/></joint>
+  <joint name="w1" type="revolute"><parent link="l4"/><child link="l5"/><origin xyz="0.2 0 0"/>
+    <limit lower="-3.0" upper="3.0" velocity="3.0" effort="1"/></joint>
+  <joint name="w2" type="revolute"><parent link="l5"/><child link="l6"/><origin xyz="0.1 0 0"/><axis xyz="0 2 0"/>
+    <limit lower="-2.0" upper="2.0" velocity="3.0" effort="1"/></joint>
+  <joint name="tool_joint" type="fixed"><parent link="l6"/><child link="tool"/><origin xyz="0.08 0 0"/></joint>
+  <joint name="finger_l_joint" type="prismatic"><parent link="l6"/><child link="finger_l"/><origin xyz="0.05 0.03 0"/><axis xyz="0 1 0"/>
+    <limit lower="0" upper="0.04" velocity="0.1" effort="1"/></joint>
+  <joint name="finger_r_joint" type="prismatic"><parent link="l6"/><child link="finger_r"/><origin xyz="0.05 -0.03 0"/><axis xyz="0 -1 0"/>
+    <limit lower="0" upper="0.04" velocity="0.1" effort="1"/><mimic joint="finger_l_joint"/></joint>
+  <joint name="finger_r_tip_joint" type="fixed"><parent link="finger_r"/><child link="finger_r_tip"/><origin xyz="0.04 0 0"/></joint>
+</robot>"""
+
+SRDF = """<robot name="mimic_arm">
+  <group name="arm_chain"><chain base_link="base" tip_link="tool"/></group>
+  <group name="gripper"><joint name="finger_l_joint"/><joint name="finger_r_joint"/></group>
+  <group name="arm"><group name="arm_chain"/><group name="gripper"/></group>
+  <group name="wrist"><link name="l5"/><link name="l6"/></group>
+  <end_effector name="hand" parent_link="tool" group="gripper" parent_group="wrist"/>
+</robot>"""
+
+
+def test_urdf_equals_hand_built_model():
+    a, b = load_urdf(URDF, SRDF), mimic_robot()
+    assert a.link_names == b.link_names and a.joint_names == b.joint_names and a.variable_names == b.variable_names
+    for f in ("link_parent", "joint_type", "joint_first_variable", "joint_mimic", "var_bounded"):
+        assert list(getattr(a, f)) == list(getattr(b, f)), f
+    for f in ("link_origin", "joint_mimic_factor", "joint_mimic_offset", "var_min", "var_max", "var_max_velocity"):
+        assert np.array_equal(np.asarray(getattr(a, f), dtype=float), np.asarray(getattr(b, f), dtype=float)), f
+    moving = np.asarray(a.joint_type) != abi.JOINT_FIXED  # a fixed joint's axis means nothing (URDF default 1 0 0)
+    assert np.array_equal(np.asarray(a.joint_axis)[moving], np.asarray(b.joint_axis)[moving])
+    # groups: chain, joint list, nested groups (tips from the chain), link list with the end effector's parent link as tip
+    g = a.groups
+    assert [a.joint_names[i] for i in g["arm_chain"].active_joints] == ["s1", "s2", "e1", "w1", "w2"]  # e2 follows s2: not active
+    assert [a.link_names[i] for i in g["arm_chain"].tips] == ["tool"]
+    assert [a.joint_names[i] for i in g["gripper"].active_joints] == ["finger_l_joint"]
+    assert [a.link_names[i] for i in g["gripper"].tips] == ["finger_l", "finger_r"]
+    assert [a.joint_names[i] for i in g["arm"].active_joints] == ["s1", "s2", "e1", "w1", "w2", "finger_l_joint"]
+    assert [a.link_names[i] for i in g["wrist"].tips] == ["tool"]
+
+
+def test_urdf_model_solves_with_the_oracle():
+    from oracle import orc
+    from bio_ik_amd.workload import make_queries
+    m = load_urdf(URDF, SRDF)
+    t = ProblemTemplate(m, "arm_chain", [PoseGoal("tool")])
+    o = orc.Oracle(t)
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 8, seed=3)
+    p = abi.default_solve_params(population=32, max_steps=64, random_seed=2)
+    sol, fit, suc, steps = o.solve_batch(p, orc.RNG_COUNTER, seeds, params)
+    assert suc.mean() >= 0.75
+    tips = o.fk(sol[suc == 1])
+    assert np.abs(tips[:, 0, :3] - params[suc == 1][:, :3]).max() < 1e-4
+
+
+def test_urdf_errors():
+    with pytest.raises(ValueError):
+        load_urdf("<robot><link name='a'/><link name='b'/></robot>")  # two roots
+    with pytest.raises(ValueError):
+        load_urdf("<robot><link name='a'/><link name='b'/><joint name='j' type='screw'><parent link='a'/><child link='b'/></joint></robot>")
