@@ -213,6 +213,17 @@ def main():
                                    "achieved_GBps": sbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": sbytes / (ms * 1e-3) / HBM_PEAK,
                                    "layout": "genes [unit][D][pop] f64 in HBM, 512-byte segments per wavefront load"}
 
+    if rank == 0 and world == 1:
+        # the host-pointer entry point (what the plugin calls): staging into page-locked memory, one DMA each way, the launch
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            hs = h.solve_batch(p, seeds, params)
+            ts.append(time.perf_counter() - t1)
+        out["host_pointer_entry"] = {"ms_per_call": min(ts) * 1e3, "solves_per_s": float(hs[2].sum()) / min(ts),
+                                     "results_identical_to_device_entry": bool(np.array_equal(hs[0], sol) and np.array_equal(hs[2], suc)),
+                                     "note": "bioik_solve_batch: host arrays in and out (PCIe-inclusive), one launch at a time; never `value`"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc, ref
         ns = min(args.cpu_sample, BATCH)

@@ -41,6 +41,8 @@ static int be_device_count() { return 1; }
 static void be_set_device(int) {}
 static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 static void be_free(void* p) { std::free(p); }
+static void* be_alloc_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+static void be_free_pinned(void* p) { std::free(p); }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
 static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
 static void be_sync(stream_t) {}
@@ -84,6 +86,14 @@ static void* be_alloc(size_t bytes) {
 }
 static void be_free(void* p) {
     if (p) (void)hipFree(p);
+}
+static void* be_alloc_pinned(size_t bytes) {  // page-locked host memory: hipMemcpyAsync from / to it is one DMA, no staging copy
+    void* p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
+    return p;
+}
+static void be_free_pinned(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t s) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
@@ -153,6 +163,11 @@ struct bioik_problem {
     // grow-only device workspace for the island results of solve_batch_device
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // grow-only device arena + page-locked host mirror for the host-pointer entry point (bioik_solve_batch): one allocation
+    // for the life of the handle, one DMA in and one DMA out per call
+    void* io_dev = nullptr;
+    void* io_host = nullptr;
+    size_t io_bytes = 0;
     uint64_t first_query = 0;
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
@@ -348,6 +363,8 @@ void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
     be_free(p->ws);
+    be_free(p->io_dev);
+    be_free_pinned(p->io_host);
     delete p;
 }
 
@@ -394,16 +411,33 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
     std::lock_guard<std::mutex> lock(p->mtx);
     be_set_device(p->model->device);
     const size_t V = p->host.dev.V, P = p->host.dev.P;
-    DevBuf ds(n * V * 8), dg(n * P * 8), dsol(n * V * 8), df(n * 8), dsu(n * 4), dst(n * 4);
-    be_h2d(ds.p, seeds, n * V * 8, 0);
-    be_h2d(dg.p, goal_params, n * P * 8, 0);
+    // arena layout: [seeds | goal_params] in, [solutions | fitness | success | steps] out, every block 64-byte aligned
+    auto up = [](size_t b) { return (b + 63) / 64 * 64; };
+    const size_t o_seeds = 0, o_par = o_seeds + up(n * V * 8), in_bytes = o_par + up(n * P * 8);
+    const size_t o_sol = in_bytes, o_fit = o_sol + up(n * V * 8), o_suc = o_fit + up(n * 8), o_steps = o_suc + up(n * 4), total = o_steps + up(n * 4);
+    if (p->io_bytes < total) {
+        be_free(p->io_dev);
+        be_free_pinned(p->io_host);
+        p->io_dev = p->io_host = nullptr, p->io_bytes = 0;
+        const size_t cap = total + total / 4;
+        p->io_dev = be_alloc(cap);
+        p->io_host = be_alloc_pinned(cap);
+        p->io_bytes = cap;
+    }
+    char* hd = (char*)p->io_host;
+    char* dd = (char*)p->io_dev;
+    std::memcpy(hd + o_seeds, seeds, n * V * 8);
+    if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
+    be_h2d(dd, hd, in_bytes, 0);
     DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
-    launch_solve(p, sp, n, ds.as<double>(), dg.as<double>(), dsol.as<double>(), df.as<double>(), dsu.as<int32_t>(), dst.as<int32_t>(), 0);
-    be_d2h(solutions, dsol.p, n * V * 8, 0);
-    be_d2h(fitness, df.p, n * 8, 0);
-    be_d2h(success, dsu.p, n * 4, 0);
-    be_d2h(steps, dst.p, n * 4, 0);
+    launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(dd + o_sol), (double*)(dd + o_fit), (int32_t*)(dd + o_suc),
+                 (int32_t*)(dd + o_steps), 0);
+    be_d2h(hd + o_sol, dd + o_sol, total - in_bytes, 0);
     be_sync(0);
+    std::memcpy(solutions, hd + o_sol, n * V * 8);
+    std::memcpy(fitness, hd + o_fit, n * 8);
+    std::memcpy(success, hd + o_suc, n * 4);
+    std::memcpy(steps, hd + o_steps, n * 4);
     API_END
 }
 
