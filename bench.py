@@ -177,7 +177,7 @@ def main():
         "mean_steps_per_solve": float(steps_q.mean()),
         "max_pos_err_m_of_successes": pos_err,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "kernel": "k_solve", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel": "k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6); "
                              "kernel_ms is the event-bracketed duration of one launch while %d launches share the chip" % nfl,
                      "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0},

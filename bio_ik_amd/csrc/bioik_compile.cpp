@@ -126,6 +126,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     if (d.struct_size != sizeof(bioik_problem_desc)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_problem_desc: struct_size mismatch");
     const int nl = (int)m->links.size(), nv = (int)m->vars.size();
     std::memset(&dev, 0, sizeof(dev));
+    dev.multi_op = -1;
 
     // ---- Problem::initialize, problem.cpp:72-228 ----
     std::vector<char> group_variable(nv, 0), fixed_joint(nl, 0);
@@ -226,16 +227,30 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             c_of[l] = C;
             continue;
         }
-        if (L.type != BIOIK_JOINT_REVOLUTE && L.type != BIOIK_JOINT_PRISMATIC)
-            throw Error(BIOIK_ERR_UNSUPPORTED, "floating / planar joints have no device implementation in this version");
+        if (L.mimic >= 0 && L.type != BIOIK_JOINT_REVOLUTE && L.type != BIOIK_JOINT_PRISMATIC)
+            throw Error(BIOIK_ERR_UNSUPPORTED, "floating / planar mimic joints have no device implementation in this version");
         DevOp op;
         std::memset(&op, 0, sizeof(op));
-        op.type = L.type == BIOIK_JOINT_REVOLUTE ? BIOIK_OP_REVOLUTE : BIOIK_OP_PRISMATIC;
+        op.type = L.type == BIOIK_JOINT_REVOLUTE ? BIOIK_OP_REVOLUTE : L.type == BIOIK_JOINT_PRISMATIC ? BIOIK_OP_PRISMATIC :
+                  L.type == BIOIK_JOINT_FLOATING ? BIOIK_OP_FLOATING : BIOIK_OP_PLANAR;
         op.var = L.first_var;
         op.gene = gene_of_var[L.first_var];
         op.src = base_src;
         op.load_slot = op.save_slot = -1;
         op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+        op.val_first = op.joint_op = -1;
+        bool multi = op.type >= BIOIK_OP_FLOATING;
+        if (multi) {
+            // The joint's variables are value ops of their own (below).  Its frame is applied in front of the chain walk by
+            // one out-of-line call and parked in an LDS slot; inside the walk the op only fetches that slot (zero constants).
+            if (base_src >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "a floating / planar joint behind a moving joint has no device implementation in this version");
+            if (dev.multi_op >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "more than one floating / planar joint on the goal chains");
+            op.gene = -1;
+            dev.multi_op = (int)ops.size();
+            for (int c = 0; c < 3; c++) dev.multi_c[c] = C.p[c];
+            for (int c = 0; c < 4; c++) dev.multi_c[3 + c] = C.q[c];
+            C = identity();
+        }
         if (L.mimic >= 0) {  // resolved to an op index below, once every op exists
             op.gene = -1;
             op.mimic_src = -2 - L.mimic;
@@ -243,7 +258,9 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         }
         for (int c = 0; c < 3; c++) op.cpos[c] = C.p[c], op.axis[c] = L.axis[c];
         for (int c = 0; c < 4; c++) op.ca[c] = C.q[c];
-        if (op.type == BIOIK_OP_REVOLUTE) {
+        if (multi) {
+            for (int c = 0; c < 4; c++) op.cb[c] = 0.0;
+        } else if (op.type == BIOIK_OP_REVOLUTE) {
             double aq[4] = {L.axis[0], L.axis[1], L.axis[2], 0.0};
             qmul(C.q, aq, op.cb);
         } else {
@@ -257,12 +274,41 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         c_of[l] = identity();
     }
     const int n_chain = (int)ops.size();
+    // floating / planar joints: one value-only op per variable (7 / 3 consecutive), genes where the variable is active
+    std::vector<char> var_has_op(nv, 0);
+    for (int k = 0; k < n_chain; k++) {
+        if (ops[k].type < BIOIK_OP_FLOATING) {
+            var_has_op[ops[k].var] = 1;
+            continue;
+        }
+        const int cnt = ops[k].type == BIOIK_OP_FLOATING ? 7 : 3;
+        ops[k].val_first = (int)ops.size();
+        for (int c = 0; c < cnt; c++) {
+            DevOp op;
+            std::memset(&op, 0, sizeof(op));
+            op.type = BIOIK_OP_NONE;
+            op.var = ops[k].var + c;
+            op.gene = gene_of_var[op.var];
+            op.src = op.load_slot = op.save_slot = -1;
+            op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+            op.val_first = -1, op.joint_op = k;
+            var_has_op[op.var] = 1;
+            ops.push_back(op);
+        }
+        if (ops[k].type == BIOIK_OP_FLOATING && gene_of_var[ops[k].var + 3] >= 0) {  // ik_evolution_2.cpp:203-215
+            for (int c = 4; c < 7; c++)
+                if (gene_of_var[ops[k].var + c] != gene_of_var[ops[k].var + 3] + (c - 3))
+                    throw Error(BIOIK_ERR_UNSUPPORTED, "the four orientation variables of a floating joint must be consecutive genes");
+            if (dev.n_quat >= 4) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 4 floating joints with active orientation");
+            dev.quat_op[dev.n_quat++] = ops[k].val_first + 3;
+        }
+    }
     for (int i = 0; i < D; i++) {  // active variables that move no scheduled link (goal variables off the chains)
         int v = active_variables[i];
+        if (var_has_op[v]) continue;
         int j = m->vars[v].joint;
-        if (j >= 0 && op_of_link[j] >= 0) continue;
         if (j >= 0 && (m->links[j].type != BIOIK_JOINT_REVOLUTE && m->links[j].type != BIOIK_JOINT_PRISMATIC))
-            throw Error(BIOIK_ERR_UNSUPPORTED, "floating / planar joints have no device implementation in this version");
+            throw Error(BIOIK_ERR_UNSUPPORTED, "variables of floating / planar joints outside the goal chains have no device implementation in this version");
         DevOp op;
         std::memset(&op, 0, sizeof(op));
         op.type = BIOIK_OP_NONE;
@@ -270,6 +316,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         op.gene = i;
         op.src = op.load_slot = op.save_slot = -1;
         op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+        op.val_first = op.joint_op = -1;
+        var_has_op[v] = 1;
         ops.push_back(op);
     }
     // mimic joints read the value of the joint they follow: resolve it to an op (a followed joint that is on no goal chain
@@ -290,6 +338,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             op.gene = gene_of_var[sv];
             op.src = op.load_slot = op.save_slot = -1;
             op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
+            op.val_first = op.joint_op = -1;
             if (op.gene >= 0) {
                 const HostModel::Var& vi = m->vars[sv];
                 op.clip_min = vi.clip_min, op.clip_max = vi.clip_max, op.span = vi.span, op.vmin = vi.vmin, op.vmax = vi.vmax;
@@ -314,6 +363,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
     // branch frames: an op whose parent frame is not the running frame fetches it from an LDS slot
     int n_slots = 0;
+    if (dev.multi_op >= 0) ops[dev.multi_op].load_slot = n_slots++;
     for (int k = 0; k < n_chain; k++) {
         int s = ops[k].src;
         if (s >= 0 && s != k - 1) {
@@ -396,11 +446,15 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.P = param_count;
     dev.n_slots = n_slots;
     int n_prefix = 0;
-    while (n_prefix < n_chain && ops[n_prefix].gene < 0 && ops[n_prefix].mimic_src < 0 && ops[n_prefix].src == n_prefix - 1 &&
+    while (n_prefix < n_chain && ops[n_prefix].gene < 0 && ops[n_prefix].mimic_src < 0 && ops[n_prefix].type < BIOIK_OP_FLOATING &&
+           ops[n_prefix].src == n_prefix - 1 &&
            ops[n_prefix].tip_count == 0 && ops[n_prefix].save_slot < 0 && ops[n_prefix].load_slot < 0)
         n_prefix++;
     if (n_prefix == n_chain) n_prefix = 0;  // nothing left to walk: no point
     dev.n_prefix = n_prefix;
+    dev.genes_follow_ops = 1;
+    for (int i = 1; i < D; i++)
+        if (dev.op_of_gene[i] <= dev.op_of_gene[i - 1]) dev.genes_follow_ops = 0;
     for (size_t k = 0; k < ops.size(); k++) {
         dev.ops[k] = ops[k];
         if (ops[k].gene >= 0) dev.active_mask |= 1u << k;

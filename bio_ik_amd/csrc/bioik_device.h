@@ -311,6 +311,49 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) 
 //   tip_fn(t, frame): called with device tip index t as soon as the tip's frame is complete
 // The loop trip count and every constant are wave-uniform: control flow is scalar, constants arrive in SGPRs.
 // ---------------------------------------------------------------------------------------------------------
+// frame.h:189-209
+BIOIK_DEV F7 f7_invert(const F7& a) {
+    const Q4 qi = qinv(a.q);
+    return F7{qrot(qi, v3(-a.p.x, -a.p.y, -a.p.z)), qi};
+}
+// Floating / planar joints (RobotJointEvaluator::getJointFrame, forward_kinematics.h:120-135): the joint's 7 / 3 values travel
+// as an F7 (floating: translation, quaternion; planar: x, y, theta in p), and the arithmetic -- normalisation of the quaternion
+// (sqrt, four divisions) or sincos, two frame concatenations -- is ONE out-of-line value function: these joints are rare, and
+// every inlined copy would weigh on the instruction cache of the robots that have none.
+BIOIK_DEV F7 multi_joint_values(int type, const XV& x, int val_first) {
+    F7 v = F7{{x(val_first), x(val_first + 1), x(val_first + 2)}, {0.0, 0.0, 0.0, 0.0}};
+    if (type == BIOIK_OP_FLOATING) v.q = Q4{x(val_first + 3), x(val_first + 4), x(val_first + 5), x(val_first + 6)};
+    return v;
+}
+BIOIK_DEV void multi_joint_bump(F7& v, int i, double step) {  // variable i += step (forward difference of the Jacobian, :695-726)
+    double* p = i < 3 ? (i == 0 ? &v.p.x : i == 1 ? &v.p.y : &v.p.z) : (i == 3 ? &v.q.x : i == 4 ? &v.q.y : i == 5 ? &v.q.z : &v.q.w);
+    *p = *p + step;
+}
+BIOIK_DEV F7 multi_joint_frame(int type, const F7& v) {
+    if (type == BIOIK_OP_FLOATING) {
+        const double l = sqrt(qdot(v.q, v.q));
+        return F7{v.p, {v.q.x / l, v.q.y / l, v.q.z / l, v.q.w / l}};
+    }
+    double sn, cs;
+    p_sincos(v.p.z * 0.5, &sn, &cs);  // planar: Translation(x, y, 0) * AngleAxis(theta, Z)
+    return F7{{v.p.x, v.p.y, 0.0}, {0.0, 0.0, sn, cs}};
+}
+// constant o joint frame
+BIOIK_CALL F7 multi_joint_apply(int type, F7 c, F7 values) { return f7_concat(c, multi_joint_frame(type, values)); }
+// In front of a chain walk: the frame behind the root-level floating / planar joint of individual x goes to this lane's slot
+// (the op itself then only fetches it: load_slot, zero constants -- nothing of this is inside the joint loop).
+BIOIK_DEV void multi_joint_prologue(ProbPtr pb, const XV& x, double* slots_of_child) {
+    const int mo = pb->multi_op;
+    if (mo < 0) return;
+    const int tid = p_tid(), nth = p_nthreads();
+    const int type = pb->ops[mo].type;
+    const F7 c = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
+    const F7 f = multi_joint_apply(type, c, multi_joint_values(type, x, pb->ops[mo].val_first));
+    double* sl = slots_of_child + (size_t)pb->ops[mo].load_slot * 7 * nth + tid;
+    sl[0] = f.p.x, sl[(size_t)nth] = f.p.y, sl[(size_t)2 * nth] = f.p.z;
+    sl[(size_t)3 * nth] = f.q.x, sl[(size_t)4 * nth] = f.q.y, sl[(size_t)5 * nth] = f.q.z, sl[(size_t)6 * nth] = f.q.w;
+}
+
 // value of the joint of op k in the individual x: its own entry, or for a mimic joint factor * (entry of the joint it
 // follows) + offset (RobotFK_Fast_Base::updateMimic, forward_kinematics.h:230-246; a plain multiply and add)
 BIOIK_DEV double joint_value(const XV& x, int k, int mimic_src, double mimic_factor, double mimic_offset) {
@@ -325,8 +368,8 @@ BIOIK_DEV double joint_value(const XV& x, int k, int mimic_src, double mimic_fac
 #endif
 //   prefix     LDS or null, [7]: the frame behind ops[0..n_prefix), which is the same for every individual of the query; the
 //              walk then starts at op n_prefix (the kernels that own a query compute it once, fk_prefix)
-template <class TipFn>
-BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
+template <class PB, class TipFn>
+BIOIK_DEV void fk_walk(PB pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f = f7_identity();
@@ -347,6 +390,7 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
         k_begin = pb->n_prefix;
         if (k_begin > 0) f = f7_load(prefix);
     }
+    if constexpr (pb_flavour<PB>::general) multi_joint_prologue(pb, x, slots);
     for (int k0 = k_begin; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
         double xv[BIOIK_FK_BLOCK], sn[BIOIK_FK_BLOCK], cs[BIOIK_FK_BLOCK];
 #pragma unroll
@@ -371,12 +415,14 @@ BIOIK_DEV void fk_walk(ProbPtr pb, const XV& x, double* slots, double* frames_ou
             } else if (k > 0 && src < 0) {
                 f = f7_identity();
             }
-            const bool rev = type == BIOIK_OP_REVOLUTE;
-            const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
-            const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
-            const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
-            f.p = f.p + qrot(f.q, lp);
-            f.q = qmul(f.q, lq);
+            {
+                const bool rev = type == BIOIK_OP_REVOLUTE;
+                const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
+                const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
+                const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
+                f.p = f.p + qrot(f.q, lp);
+                f.q = qmul(f.q, lq);
+            }
             if (ss >= 0) {
                 double* sl = slots + (size_t)ss * 7 * nth + tid;
                 sl[0] = f.p.x;
@@ -423,7 +469,8 @@ BIOIK_DEV F7 fk_prefix(ProbPtr pb, const XV& x) {
     return f;
 }
 
-BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
+template <class PB>
+BIOIK_DEV double eval_exact_primary(PB pb, const XV& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
     double sum = 0.0;
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); }, prefix);
     sum += nonlink_primary(pb, x, qc);
@@ -434,8 +481,8 @@ BIOIK_DEV double eval_exact_primary(ProbPtr pb, const XV& x, const QueryCtx& qc,
 // dependency chains, so that the scalar loads of a joint's constants, the LDS reads of the gene values and the latency of the
 // polynomial chains are paid once per joint instead of once per joint and child.  Arithmetic per individual is identical
 // to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
-template <int N, class TipFn>
-BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
+template <int N, class PB, class TipFn>
+BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f[N];
@@ -463,6 +510,8 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
             for (int j = 0; j < N; j++) f[j] = f0;
         }
     }
+    if constexpr (pb_flavour<PB>::general)
+        for (int j = 0; j < N; j++) multi_joint_prologue(pb, x[j], slots + (size_t)j * slot_set_stride);
     for (int k = k_begin; k < n_chain; k++) {
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
@@ -488,14 +537,16 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
 #pragma unroll
             for (int j = 0; j < N; j++) f[j] = f7_identity();
         }
-        const bool rev = type == BIOIK_OP_REVOLUTE;
+        {
+            const bool rev = type == BIOIK_OP_REVOLUTE;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
-            const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
-            const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
-            f[j].p = f[j].p + qrot(f[j].q, lp);
-            f[j].q = qmul(f[j].q, lq);
+            for (int j = 0; j < N; j++) {
+                const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
+                const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
+                const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
+                f[j].p = f[j].p + qrot(f[j].q, lp);
+                f[j].q = qmul(f[j].q, lq);
+            }
         }
         if (ss >= 0) {
 #pragma unroll
@@ -525,8 +576,8 @@ BIOIK_DEV void fk_walk_n(ProbPtr pb, const XV (&x)[N], double* slots, int slot_s
         }
     }
 }
-template <int N>
-BIOIK_DEV void eval_exact_primary_n(ProbPtr pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
+template <int N, class PB>
+BIOIK_DEV void eval_exact_primary_n(PB pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
                                     const double* prefix = nullptr) {
 #pragma unroll
     for (int j = 0; j < N; j++) out[j] = 0.0;
@@ -556,19 +607,26 @@ struct LinModel {
     const double* base;
 };
 
-// forward_kinematics.h:1186-1231 (no renormalisation of the quaternion).  Four joints per trip: their 4 + 28 LDS
-// operands are requested together and waited for once; inactive / padding joints contribute d * 0.0 (exact no-op).
-BIOIK_DEV F7 linear_tip(ProbPtr pb, int t, const XV& x, const LinModel& lm) {
+// forward_kinematics.h:1186-1231 (no renormalisation of the quaternion).  The sum runs over the GENES in gene order, as the
+// reference's does (approx_map holds gene indices in ascending order; a gene that does not move the tip contributes d * dv with
+// d = 0, an exact no-op).  Where the ops meet the genes in that same order (DevProblem::genes_follow_ops: every robot without
+// floating / planar joints so far) the walk is over the ops and needs no gene -> op look-up; otherwise over op_of_gene.
+// Four entries per trip: their 4 + 4 + 28 LDS operands are requested together and waited for once; padding contributes d * 0.0.
+template <class PB>
+BIOIK_DEV F7 linear_tip(PB pb, int t, const XV& x, const LinModel& lm) {
     const int n_ops = pb->n_ops;
+    const bool by_op = pb_flavour<PB>::general ? pb->genes_follow_ops != 0 : true;
+    const int cnt = by_op ? n_ops : pb->D;
     const uint32_t active = pb->active_mask;
     const double* tb = lm.tipbase + t * 7;
     double px = tb[0], py = tb[1], pz = tb[2], rx = tb[3], ry = tb[4], rz = tb[5], rw = tb[6];
-    for (int k0 = 0; k0 < n_ops; k0 += 4) {
+    for (int g0 = 0; g0 < cnt; g0 += 4) {
         double dv[4], d[4][7];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int kk = k0 + j < n_ops ? k0 + j : n_ops - 1;
-            const bool on = k0 + j < n_ops && ((active >> kk) & 1u);
+            const int idx = g0 + j < cnt ? g0 + j : cnt - 1;
+            const int kk = by_op ? idx : pb->op_of_gene[idx];
+            const bool on = g0 + j < cnt && ((active >> kk) & 1u);
             const double xv = x(kk), bv = lm.base[kk];
             dv[j] = on ? xv - bv : 0.0;
             const double* dp = lm.delta + ((size_t)t * n_ops + kk) * 7;
@@ -589,7 +647,8 @@ BIOIK_DEV F7 linear_tip(ProbPtr pb, int t, const XV& x, const LinModel& lm) {
     return F7{{px, py, pz}, {rx, ry, rz, rw}};
 }
 
-BIOIK_DEV double eval_linear_primary(ProbPtr pb, const XV& x, const QueryCtx& qc, const LinModel& lm) {
+template <class PB>
+BIOIK_DEV double eval_linear_primary(PB pb, const XV& x, const QueryCtx& qc, const LinModel& lm) {
     double sum = 0.0;
     const int T = pb->T;
     for (int t = 0; t < T; t++) sum += tip_goals(pb, t, linear_tip(pb, t, x, lm), x, qc);
@@ -617,11 +676,63 @@ BIOIK_DEV void jacobian_column(ProbPtr pb, int m, const F7& lf, const F7& tf, V3
         om = v3(0.0, 0.0, 0.0);
     }
 }
-BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames, const double* tips, double* out7) {
+// frame.h:240-259: twist of b seen from a (translation, rotation vector), tf2 getAngle / getAxis semantics
+BIOIK_DEV void frame_twist(const F7& a, const F7& b, V3& lin, V3& ang) {
+    const F7 f = f7_concat(f7_invert(a), b);
+    lin = f.p;
+    double ra = 2.0 * clamped_acos(f.q.w);
+    if (ra > +BIOIK_PI) ra -= 2 * BIOIK_PI;
+    const double s_squared = 1.0 - f.q.w * f.q.w;
+    V3 axis = v3(1.0, 0.0, 0.0);
+    if (!(s_squared < 10.0 * 2.220446049250313e-16)) {
+        const double s = 1.0 / sqrt(s_squared);
+        axis = v3(f.q.x * s, f.q.y * s, f.q.z * s);
+    }
+    ang = axis * ra;
+}
+// Jacobian column of ONE variable of a floating / planar joint by forward difference (forward_kinematics.h:695-726):
+// values in, values out, one out-of-line copy.  parent_c = (frame of the parent op) o (constant frame in front of the joint).
+struct Twist6 {
+    double v[6];
+};
+BIOIK_CALL Twist6 jacobian_numeric(int type, F7 parent_c, F7 values_2, F7 link_frame_1, F7 tip_frame_1) {
+    const double inv_step_size = 1.0 / 0.00001;
+    const F7 link_frame_2 = f7_concat(parent_c, multi_joint_frame(type, values_2));
+    const F7 tip_frame_2 = f7_concat(f7_concat(link_frame_2, f7_invert(link_frame_1)), tip_frame_1);  // change(), frame.h:203-209
+    V3 lin, ang;
+    frame_twist(tip_frame_1, tip_frame_2, lin, ang);
+    Twist6 t;
+    t.v[0] = lin.x * inv_step_size, t.v[1] = lin.y * inv_step_size, t.v[2] = lin.z * inv_step_size;
+    t.v[3] = ang.x * inv_step_size, t.v[4] = ang.y * inv_step_size, t.v[5] = ang.z * inv_step_size;
+    return t;
+}
+//   base   LDS, [n_ops]: the op values of the configuration the frames were published for
+//   prefix LDS or null: see fk_walk (the frames of ops[0..n_prefix) are then not published; their last one is *prefix)
+template <class PB>
+BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, const double* tips, double* out7, const double* base = nullptr,
+                                  const double* prefix = nullptr) {
     BIOIK_FP_STRICT
     const uint32_t dep_mask = pb->tips[t].dep_mask;
     const int n_chain = pb->n_chain_ops;
     const bool gene = pb->ops[k].gene >= 0;
+    const int jop = pb_flavour<PB>::general ? pb->ops[k].joint_op : -1;
+    if (jop >= 0) {  // a variable of a floating / planar joint
+        if (!gene || ((dep_mask >> jop) & 1u) == 0 || base == nullptr) {
+            for (int c = 0; c < 7; c++) out7[c] = 0.0;
+            return;
+        }
+        const int type = pb->ops[jop].type, vf = pb->ops[jop].val_first;  // root-level joint: the parent frame is the model root
+        const F7 cf = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
+        const F7 tf = f7_load(tips + t * 7);
+        F7 values_2 = multi_joint_values(type, XV{base, 1}, vf);
+        multi_joint_bump(values_2, k - vf, 0.00001);
+        const Twist6 tw = jacobian_numeric(type, cf, values_2, f7_load(frames + jop * 7), tf);
+        const V3 dp = qrot(tf.q, v3(tw.v[0], tw.v[1], tw.v[2]));
+        const Q4 dq = qmul(tf.q, Q4{tw.v[3] * 0.5, tw.v[4] * 0.5, tw.v[5] * 0.5, 1.0});
+        out7[0] = dp.x, out7[1] = dp.y, out7[2] = dp.z;
+        out7[3] = dq.x - tf.q.x, out7[4] = dq.y - tf.q.y, out7[5] = dq.z - tf.q.z, out7[6] = dq.w - tf.q.w;
+        return;
+    }
     const bool own = gene && k < n_chain && ((dep_mask >> k) & 1u) != 0;
     const uint32_t followers = gene ? pb->mimic_followers[k] & dep_mask : 0u;  // mimic joints of this gene on the tip's chain
     if (!own && followers == 0u) {
@@ -656,6 +767,18 @@ BIOIK_DEV void approximator_entry(ProbPtr pb, int t, int k, const double* frames
 //   p0g / p0d / p1d: LDS, op-indexed genes of parent 0 and momentum ("gradients") of parents 0 and 1
 //   xo / go (stride xs / gs): where the child's genes / momentum go; go may be null
 // ---------------------------------------------------------------------------------------------------------
+// ik_evolution_2.cpp:320-324: the orientation genes of floating joints are pulled back towards unit length after the
+// mutation (normalizeFast, frame.h:231-238: one Newton step); the momentum keeps the un-normalised difference
+BIOIK_DEV void renormalize_quaternion_genes(ProbPtr pb, double* xo, int xs) {
+    const int nq = pb->n_quat;
+    for (int i = 0; i < nq; i++) {
+        const int k = pb->quat_op[i];
+        const Q4 q = Q4{xo[(size_t)k * xs], xo[(size_t)(k + 1) * xs], xo[(size_t)(k + 2) * xs], xo[(size_t)(k + 3) * xs]};
+        const double f = (3.0 - qdot(q, q)) * 0.5;
+        xo[(size_t)k * xs] = q.x * f, xo[(size_t)(k + 1) * xs] = q.y * f, xo[(size_t)(k + 2) * xs] = q.z * f, xo[(size_t)(k + 3) * xs] = q.w * f;
+    }
+}
+
 // four independent Philox2x32-10 streams advanced in lock step: the ten rounds of one stream are a dependent chain of
 // 32x32->64 multiplies, so interleaving four of them gives the in-order wavefront something to issue every cycle
 BIOIK_DEV void philox2x32_10_x4(uint32_t key, const uint32_t (&c0in)[4], uint32_t c1in, uint32_t (&o0)[4], uint32_t (&o1)[4]) {
@@ -677,7 +800,8 @@ BIOIK_DEV void philox2x32_10_x4(uint32_t key, const uint32_t (&c0in)[4], uint32_
     for (int j = 0; j < 4; j++) o0[j] = c0[j], o1[j] = c1[j];
 }
 
-BIOIK_DEV void reproduce_child(ProbPtr pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
+template <class PB>
+BIOIK_DEV void reproduce_child(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
                                double* xo, int xs, double* go, int gs) {
     BIOIK_FP_STRICT
     const int n_ops = pb->n_ops, D = pb->D;
@@ -727,6 +851,7 @@ BIOIK_DEV void reproduce_child(ProbPtr pb, uint32_t key, uint32_t ctr1, uint32_t
                 xo[(size_t)k * xs] = p0g[k];  // inactive op: the seed's value, carried by every elite
                 if (go) go[(size_t)k * gs] = 0.0;
             }
+    if constexpr (pb_flavour<PB>::general) renormalize_quaternion_genes(pb, xo, xs);
 }
 
 // N children of one lane at once (same parents, same generation): N x 4 interleaved random streams per trip and the
@@ -750,8 +875,8 @@ BIOIK_DEV void philox2x32_10_xm(uint32_t key, const uint32_t (&c0in)[M], uint32_
 #pragma unroll
     for (int j = 0; j < M; j++) o0[j] = c0[j], o1[j] = c1[j];
 }
-template <int N>
-BIOIK_DEV void reproduce_children(ProbPtr pb, uint32_t key, uint32_t ctr1, const uint32_t (&child_index)[N], const double* p0g, const double* p0d,
+template <int N, class PB>
+BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint32_t (&child_index)[N], const double* p0g, const double* p0d,
                                   const double* p1d, double* const (&xo)[N], int xs) {
     BIOIK_FP_STRICT
     const int n_ops = pb->n_ops, D = pb->D;
@@ -812,6 +937,8 @@ BIOIK_DEV void reproduce_children(ProbPtr pb, uint32_t key, uint32_t ctr1, const
 #pragma unroll
                 for (int i = 0; i < N; i++) xo[i][(size_t)k * xs] = v;
             }
+    if constexpr (pb_flavour<PB>::general)
+        for (int i = 0; i < N; i++) renormalize_quaternion_genes(pb, xo[i], xs);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -953,7 +1080,8 @@ struct FitCheck {
     double fitness;
     int ok;
 };
-BIOIK_NOINLINE FitCheck exact_fitness_check(ProbPtr pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check,
+template <class PB>
+BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check,
                                             const double* prefix = nullptr) {
     bool good = true;
     double sum = 0.0;

@@ -106,9 +106,15 @@ static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3
 #endif
+// two flavours of the solver (bioik_platform.h, pb_flavour): k_solve_lean for problems without floating / planar joints whose ops
+// meet the genes in gene order (every BASELINE.json configuration), k_solve for everything
 __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve(SolveArgs a) {
     extern __shared__ double lds[];
-    solve_body(a, blockIdx.x, lds);
+    solve_body<false>(a, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true>(a, blockIdx.x, lds);
 }
 __global__ void k_select(SelectArgs a) { select_body(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void __launch_bounds__(256) k_eval_fk(EvalArgs a) {
@@ -240,7 +246,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && nth % 128 == 0) ? 1 : 0;
     const int groups = sp.species_parallel ? 2 : 1, G = nth / groups;
     sp.child_cols = (sp.lambda + G - 1) / G;
-    if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
+    if (dp.n_quat > 0) {
+        sp.child_cols = 1;  // winners are re-derived: their momentum is taken before the quaternion genes are renormalised (:299 vs :320)
+    } else if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
         if (std::atoi(e) == 0) sp.child_cols = 1;
     } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups) > 48 * 1024) {
         sp.child_cols = 1;
@@ -253,8 +261,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
 #if !defined(BIOIK_HOSTSIM)
-    if (lds > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
 #endif
+    bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0;
+    if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
+        if (std::atoi(e) != 0) lean = false;
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;
@@ -283,7 +297,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         a.success = (int32_t*)w, w += units * 4;
         a.steps = (int32_t*)w;
     }
-    LAUNCH(k_solve, solve_body(a, b_, l_), units, nth, lds, stream, a);
+    if (lean)
+        LAUNCH(k_solve_lean, solve_body<true>(a, b_, l_), units, nth, lds, stream, a);
+    else
+        LAUNCH(k_solve, solve_body<false>(a, b_, l_), units, nth, lds, stream, a);
 #if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
         std::vector<unsigned long long> h(units * PHASE_SLOTS);

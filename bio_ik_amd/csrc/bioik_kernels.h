@@ -12,6 +12,8 @@
 // Reference behaviour restated here: src/ik_evolution_2.cpp:111-230 (initialize), :328-646 (step),
 // src/ik_parallel.h:148-190 (island loop, budget form), :220-269 (best island).
 #pragma once
+#include <type_traits>
+
 #include "bioik_device.h"
 
 #if defined(BIOIK_HOSTSIM)
@@ -120,7 +122,8 @@ BIOIK_DEV void top2_xwave(double& b1f, int& b1p, double& b2f, int& b2p, double* 
 // RobotFK::applyConfiguration + initializeMutationApproximator at the (workgroup-shared) individual x:
 // the joint frames are published to LDS by lane 0 (the per-joint frame chain), then lanes fan out over (tip, op).
 // (gtid, G): index and size of the cooperating lane group (the whole workgroup, or one species group of it)
-BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G,
+template <class PB>
+BIOIK_NOINLINE void build_approximator(PB pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G,
                                        const double* prefix = nullptr) {
     const int n_ops = pb->n_ops, T = pb->T;
     if (gtid < 64)  // one wavefront walks the chain (lane 0 publishes); the others wait at the barrier
@@ -132,7 +135,7 @@ BIOIK_NOINLINE void build_approximator(ProbPtr pb, XV x, double* slots, double* 
     for (int idx = gtid; idx < T * n_ops; idx += G) {
         int t = idx / n_ops, k = idx - t * n_ops;
         double o[7];
-        approximator_entry(pb, t, k, s_frames, s_tips, o);
+        approximator_entry(pb, t, k, s_frames, s_tips, o, s_base, prefix);
         double* d = s_delta + ((size_t)t * n_ops + k) * 7;
         for (int c = 0; c < 7; c++) d[c] = o[c];
     }
@@ -160,8 +163,11 @@ struct SpeciesState {
     int improved;
 };
 
+// LEAN: the flavour without floating / planar joints (see pb_flavour); the launcher picks it whenever the problem allows
+template <bool LEAN>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
-    ProbPtr pb = a.pb;
+    typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
+    const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
     const int tid = p_tid(), nth = p_nthreads(), lane = tid & 63;
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
@@ -305,7 +311,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 // genotype -> phenotype -> fitness (:391-407): lane r of the group scores the child at sorted position r
                 double b1f = P_INF, b2f = P_INF;
                 int b1p = 0x7fffffff, b2p = 0x7fffffff;
-                const bool stored = n_cols * G >= lambda;  // every child keeps its own column until selection
+                // every child keeps its own column until selection; not with quaternion genes: a winner's momentum is taken from the
+                // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
+                const bool stored = n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) {
                     if (cand_better(f, pos, b1f, b1p)) {
                         b2f = b1f, b2p = b1p;

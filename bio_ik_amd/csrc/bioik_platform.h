@@ -20,6 +20,7 @@
 #define BIOIK_CALL __attribute__((noinline)) inline
 #define BIOIK_CONTRACT_OFF
 typedef const DevProblem* ProbPtr;
+typedef const DevProblemLean* LeanProbPtr;
 
 namespace sim {
 struct Block {
@@ -68,6 +69,7 @@ BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
 #define BIOIK_CALL __device__ __attribute__((noinline))
 // uniform, read-only problem block: the constant address space makes every access a scalar (s_load) candidate
 typedef const DevProblem __attribute__((address_space(4))) * ProbPtr;
+typedef const DevProblemLean __attribute__((address_space(4))) * LeanProbPtr;
 
 BIOIK_DEV int p_tid() { return (int)threadIdx.x; }
 BIOIK_DEV int p_nthreads() { return (int)blockDim.x; }
@@ -87,6 +89,18 @@ BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 #define P_INF (__builtin_inf())
 #endif
+
+// Kernel flavour, carried by the TYPE of the problem pointer so that it reaches every device function by argument deduction:
+// a LeanProbPtr promises "no floating / planar joint, no quaternion genes, the ops meet the genes in gene order" and the code for
+// those cases is not instantiated (k_solve_lean: the robots of BASELINE.json); a plain ProbPtr keeps everything (k_solve).
+template <class PB>
+struct pb_flavour {
+    static constexpr bool general = true;
+};
+template <>
+struct pb_flavour<LeanProbPtr> {
+    static constexpr bool general = false;
+};
 
 // Phase profiler (the reference's BLOCKPROFILER taxonomy, src/ik_evolution_2.cpp:330-437,605): compiled in only with
 // -DBIOIK_PHASE_TIMING; lane 0 of the workgroup accumulates shader-clock cycles per phase.

@@ -11,7 +11,7 @@
 #define BIOIK_MAX_TIPS 8
 #define BIOIK_MAX_GOALS 24  // per class (primary / secondary)
 
-enum { BIOIK_OP_NONE = 0, BIOIK_OP_REVOLUTE = 1, BIOIK_OP_PRISMATIC = 2 };
+enum { BIOIK_OP_NONE = 0, BIOIK_OP_REVOLUTE = 1, BIOIK_OP_PRISMATIC = 2, BIOIK_OP_FLOATING = 3, BIOIK_OP_PLANAR = 4 };
 
 // One moving joint of the link schedule (reference src/forward_kinematics.h:268-282).  The fixed links between the
 // previous moving joint and this one are folded into the constant frame C on the host, so one op is
@@ -36,6 +36,8 @@ struct DevOp {
     int32_t tip_first, tip_count;    // device tips whose frame is F_out o E (evaluated right after this op)
     int32_t unbounded;               // clip_max == DBL_MAX (goal_types.h:394,419)
     int32_t mimic_src;               // op whose value this joint mimics, -1: the joint has its own value x(k)
+    int32_t val_first;               // FLOATING / PLANAR chain op: first of its 7 / 3 consecutive value ops (type NONE), else -1
+    int32_t joint_op;                // value op of a FLOATING / PLANAR joint: the chain op it belongs to, else -1
 };
 
 struct DevTip {
@@ -58,21 +60,27 @@ struct DevGoal {
 };
 
 struct DevProblem {
+    // the scalars one code site reads together sit in one 16-byte group, so that they arrive with one scalar load
     int32_t n_ops;        // ops[0..n_chain_ops) walk the kinematic tree; [n_chain_ops..n_ops) are off-chain goal variables
-    int32_t n_chain_ops;
     int32_t D;            // Problem::active_variables.size()
+    int32_t n_quat;       // floating joints whose orientation is four genes: renormalised after reproduction (ik_evolution_2.cpp:320-324)
+    int32_t genes_follow_ops;  // 1: op_of_gene is increasing, so a walk over the ops meets the genes in gene order
+    int32_t n_chain_ops;
+    int32_t n_prefix;     // ops[0..n_prefix): a straight run of joints at the root that are not genes and carry no tip and no
+                          // branch: their frame is the same for every individual of a query (the seed's), computed once
+    int32_t multi_op;     // chain op of the (single, root-level) floating / planar joint, -1 none: its frame is computed in
+                          // front of the walk and parked in LDS slot ops[multi_op].load_slot; inside the walk the op is a no-op
+    int32_t n_root_tips;  // tips[0..n_root_tips) hang off the model root without any moving joint
     int32_t T;            // Problem::tip_link_indices.size()
     int32_t V;            // robot variables
     int32_t P;            // doubles per query in goal_params
-    int32_t n_root_tips;  // tips[0..n_root_tips) hang off the model root without any moving joint
+    int32_t n_slots;
     int32_t n_link_primary;  // primary[0..n_link_primary) are link goals grouped by tip; the rest read genes only
     int32_t n_primary;
     int32_t n_secondary;
-    int32_t n_slots;
     uint32_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
-    int32_t n_prefix;      // ops[0..n_prefix): a straight run of joints at the root that are not genes and carry no tip and no
-                           // branch: their frame is the same for every individual of a query (the seed's), computed once
-    int32_t pad0;
+    double multi_c[7];     // constant frame in front of the floating / planar joint
+    int32_t quat_op[4];    // op index of the first of the four orientation value ops
     uint32_t mimic_followers[BIOIK_MAX_OPS];  // bit m: chain op m is a mimic joint following op k
     int32_t op_of_gene[BIOIK_MAX_OPS];
     int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
@@ -81,6 +89,10 @@ struct DevProblem {
     DevGoal primary[BIOIK_MAX_GOALS];
     DevGoal secondary[BIOIK_MAX_GOALS];
 };
+
+// Same block, read by the lean kernel flavour (bioik_platform.h: pb_flavour): the host hands it out only for problems without
+// floating / planar joints (multi_op < 0, n_quat == 0) whose ops meet the genes in gene order (genes_follow_ops).
+struct DevProblemLean : DevProblem {};
 
 // solver parameters as the kernels see them (bioik_solve_params after normalisation, problem.cpp:90-95)
 struct DevSolveParams {

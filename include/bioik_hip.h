@@ -52,8 +52,8 @@ enum {
     BIOIK_JOINT_FIXED = 0,
     BIOIK_JOINT_REVOLUTE = 1,  /* also URDF "continuous" (unbounded revolute) */
     BIOIK_JOINT_PRISMATIC = 2,
-    BIOIK_JOINT_FLOATING = 3,  /* 7 variables x y z qx qy qz qw; oracle only (device: BIOIK_ERR_UNSUPPORTED) */
-    BIOIK_JOINT_PLANAR = 4     /* 3 variables x y theta;          oracle only (device: BIOIK_ERR_UNSUPPORTED) */
+    BIOIK_JOINT_FLOATING = 3,  /* 7 variables x y z qx qy qz qw; device: one such joint, attached to the model root through fixed joints only */
+    BIOIK_JOINT_PLANAR = 4     /* 3 variables x y theta;          device: as FLOATING (the virtual joint of a mobile base)             */
 };
 
 /* ---- goal opcodes: one per closed-form class of reference include/bio_ik/goal_types.h.

@@ -162,8 +162,14 @@ struct RobotFK {
                 // :128-135 JointModel::computeTransform; MoveIt PlanarJointModel: Translation(x,y,0)*AngleAxis(theta,Z)
                 const double* vv = vars + l.first_var;
                 double h = vv[2] * 0.5;
+                double hs, hc;
+                if (fused()) {
+                    bioik_sincos(h, &hs, &hc);
+                } else {
+                    hs = std::sin(h), hc = std::cos(h);
+                }
                 frame.pos = {vv[0], vv[1], 0.0};
-                frame.rot = {0.0, 0.0, std::sin(h), std::cos(h)};
+                frame.rot = {0.0, 0.0, hs, hc};
                 return;
             }
         }

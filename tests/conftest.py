@@ -78,6 +78,26 @@ def gnarly():
     return gnarly_robot()
 
 
+def mobile_robot(base="floating", reach=1.0):
+    """A 3-joint arm on a free base (test fixture only): the base joint is a MoveIt floating joint (7 variables: translation +
+    quaternion) or a planar joint (x, y, theta); its variables are genes like any other (forward_kinematics.h:120-135).
+    The translation variables are bounded to +-reach, as a joint_limits.yaml of a MoveIt configuration would do."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("mobile_" + base)
+    m.add_link("world")
+    m.add_link("base", "world", "base_joint", base, xyz=(0.0, 0.0, 0.1), velocity=1.0)
+    m.add_link("l1", "base", "j1", "revolute", xyz=(0.1, 0.0, 0.2), axis=(0, 0, 1), lower=-2.5, upper=2.5, velocity=2.0)
+    m.add_link("l2", "l1", "j2", "revolute", xyz=(0.0, 0.0, 0.1), axis=(0, 1, 0), lower=-1.8, upper=1.8, velocity=2.0)
+    m.add_link("l3", "l2", "j3", "revolute", xyz=(0.3, 0.0, 0.0), axis=(0, 1, 0), lower=-2.2, upper=2.2, velocity=2.5)
+    m.add_link("tool", "l3", "tool_joint", "fixed", xyz=(0.25, 0.0, 0.0))
+    m.add_group("whole", joints=["base_joint", "j1", "j2", "j3"], tips=["tool", "base"])
+    for i, name in enumerate(m.variable_names):
+        if name.startswith("base_joint/") and name.split("/")[1] in ("trans_x", "trans_y", "trans_z", "x", "y"):
+            m.var_min[i], m.var_max[i], m.var_bounded[i] = -reach, reach, 1
+    m._keep = None
+    return m
+
+
 def mimic_robot():
     """Axis-aligned 6-joint arm (test fixture only) with two mimic joints (MoveIt JointModel::getMimic): the second elbow
     follows the shoulder pitch (a gene), and a finger on the tip's chain follows a finger that is on no goal chain (so the

@@ -65,6 +65,32 @@ def test_mimic_joints():
     pc.trajectory(h2, o2, t2, n=8, pop=70, steps_list=(3,), fk_mode=abi.FK_LINEAR)
 
 
+@pytest.mark.parametrize("base", ["floating", "planar"])
+def test_floating_and_planar_joints(base):
+    """a free base in front of the arm (forward_kinematics.h:120-135, 695-726; ik_evolution_2.cpp:203-215, 320-324).  The Jacobian
+    columns of these joints come from a forward difference through acos / sqrt (frame.h:240-259), which the device math library
+    and libm round differently: the tables agree to 1e-9, plain `bio2` solves bit for bit, memetic solves at result level."""
+    from bio_ik_amd import PoseGoal, PositionGoal
+    from bio_ik_amd.solver import HipSolver
+    from conftest import mobile_robot
+    m = mobile_robot(base)
+    t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("base", weight=0.2)])
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == (10 if base == "floating" else 6)
+    pc.function_level(h, o, m, np.random.default_rng(8), n=500, frame_tol=1e-9, fit_rtol=1e-9)
+    pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 5), mode="bio2")
+    # result level on the tool pose alone (the two-goal problem converges slowly: a low-weight goal against dtwist = 1e-5)
+    t1 = ProblemTemplate(m, "whole", [PoseGoal("tool")])
+    h1, o1 = HipSolver(t1), orc.Oracle(t1)
+    seeds, params, _ = make_queries(t1, o1.active_variables, o1.fk_genes, 256, seed=21)
+    p = abi.default_solve_params(population=64, max_steps=48, random_seed=3)
+    sol, fit, suc, steps = h1.solve_batch(p, seeds, params)
+    so = o1.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=8)
+    assert suc.mean() >= so[2].mean() - 0.03 and suc.mean() > 0.9
+    perr, rerr = pc.pose_errors(o1, sol, params, tip=0, off=0)
+    assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+
+
 def test_success_check_near_threshold(gpus, oracles, templates):
     pc.success_check_near_goal(gpus["c2"], oracles["c2"], templates["c2"], np.random.default_rng(4), n=64)
 
@@ -92,6 +118,7 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_STORE_CHILDREN": "0"},    # winners re-derived from the RNG
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_CHILD_PAIRS": "0"},       # one child per trip instead of two
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_GENERAL": "1"},           # the kernel flavour that also carries floating / planar joints
 ])
 def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
     """the same solve under every lane <-> work mapping the launcher can choose"""
@@ -198,10 +225,11 @@ def test_error_conventions(pr2):
     """status codes instead of exceptions/aborts (include/bioik_hip.h)"""
     from bio_ik_amd import PoseGoal, RobotModel
     from bio_ik_amd.solver import BioIKError, HipSolver
-    m = RobotModel("float")
+    m = RobotModel("float")  # a floating joint behind a moving joint: only the root-level virtual joint runs on the device
     m.add_link("base")
-    m.add_link("body", "base", "fj", "floating")
-    m.add_group("g", joints=["fj"], tips=["body"])
+    m.add_link("turret", "base", "yaw", "revolute", axis=(0, 0, 1), lower=-1.0, upper=1.0, velocity=1.0)
+    m.add_link("body", "turret", "fj", "floating")
+    m.add_group("g", joints=["yaw", "fj"], tips=["body"])
     with pytest.raises(BioIKError) as e:
         HipSolver(ProblemTemplate(m, "g", [PoseGoal("body")]))
     assert e.value.code == abi.ERR_UNSUPPORTED

@@ -3,6 +3,8 @@ the oracle.  Same source as the gfx950 kernels, so the solver logic (selection o
 species management, pre-selection by secondary goals, multi-wave reductions) is stepped against the reference
 restatement on a machine without a GPU.  The GPU suite (test_gpu_parity.py) repeats these cases through
 libbioik_hip.so at larger sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -70,6 +72,7 @@ def test_trajectory_two_wavefronts_and_islands(sims, oracles, templates, monkeyp
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_SPECIES_PARALLEL": "0"}, # two wavefronts, species one after the other
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_CHILD_PAIRS": "0"},      # one child per trip instead of two
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_GENERAL": "1"},           # the kernel flavour that also carries floating / planar joints
 ])
 def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, env):
     for k, v in env.items():
@@ -114,3 +117,27 @@ def test_mimic_joints(hostsim_lib):
     pc.function_level(h2, o2, m, np.random.default_rng(6), n=60, exact_bits=True)
     pc.trajectory(h2, o2, t2, n=2, pop=16, steps_list=(1, 3))
     pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+
+
+
+@pytest.mark.parametrize("base", ["floating", "planar"])
+def test_floating_and_planar_joints(hostsim_lib, base):
+    """a free base in front of the arm: 7 (translation + quaternion) or 3 (x, y, theta) genes for one joint, Jacobian columns by
+    forward difference, quaternion genes renormalised after reproduction (forward_kinematics.h:120-135, 695-726,
+    ik_evolution_2.cpp:203-215, 320-324)"""
+    from bio_ik_amd import PoseGoal, PositionGoal
+    from conftest import mobile_robot
+    m = mobile_robot(base)
+    t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("base", weight=0.2)])
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    assert h.D == o.D == (10 if base == "floating" else 6)
+    pc.function_level(h, o, m, np.random.default_rng(8), n=60, exact_bits=True)
+    pc.trajectory(h, o, t, n=2, pop=16, steps_list=(1, 3))
+    pc.trajectory(h, o, t, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+    monkey = {"BIOIK_SOLVE_THREADS": "128"}
+    os.environ.update(monkey)
+    try:
+        pc.trajectory(h, o, t, n=1, pop=130, steps_list=(2,))
+    finally:
+        for k in monkey:
+            os.environ.pop(k, None)
