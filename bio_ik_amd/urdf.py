@@ -7,7 +7,9 @@ src/kinematics_plugin.cpp:167-189) is built here from the robot description itse
   * joints: fixed | revolute | continuous | prismatic | floating | planar, <origin xyz rpy>, <axis> (URDF default 1 0 0),
     <limit lower upper velocity>, <mimic joint multiplier offset>;
   * SRDF <group>: <chain base_link tip_link>, <joint name>, <link name> (= its parent joint), nested <group name>;
-    <end_effector parent_link parent_group> supplies the tips of a group without a chain.
+    <end_effector parent_link parent_group> supplies the tips of a group without a chain;
+    <virtual_joint name type parent_frame child_link> (fixed | floating | planar) puts a new root link `parent_frame` in front of
+    the URDF's root, as MoveIt does for a mobile or free-flying base.
 Not read: inertials (BalanceGoal), collision / visual geometry, transmissions, <safety_controller>, xacro macros."""
 import xml.etree.ElementTree as ET
 
@@ -61,7 +63,22 @@ def load_urdf(urdf_xml, srdf_xml=None):
     if len(roots) != 1:
         raise ValueError("a URDF tree has exactly one root link, found %r" % roots)
     m = RobotModel(root.get("name", "robot"))
-    m.add_link(roots[0])
+    virtual = None
+    if srdf_xml is not None:
+        vj = ET.fromstring(srdf_xml).findall("virtual_joint")
+        if len(vj) > 1:
+            raise ValueError("more than one <virtual_joint>")
+        if vj:
+            virtual = vj[0]
+            if virtual.get("child_link") != roots[0]:
+                raise ValueError("<virtual_joint> child_link %r is not the root link %r" % (virtual.get("child_link"), roots[0]))
+            if virtual.get("type") not in ("fixed", "floating", "planar"):
+                raise ValueError("<virtual_joint> type %r" % virtual.get("type"))
+    if virtual is not None:
+        m.add_link(virtual.get("parent_frame"))
+        m.add_link(roots[0], virtual.get("parent_frame"), virtual.get("name"), virtual.get("type"))
+    else:
+        m.add_link(roots[0])
     stack = [iter(children[roots[0]])]
     while stack:  # depth first, children in file order (RobotModel::buildRecursive)
         j = next(stack[-1], None)

@@ -74,6 +74,20 @@ def test_urdf_model_solves_with_the_oracle():
     assert np.abs(tips[:, 0, :3] - params[suc == 1][:, :3]).max() < 1e-4
 
 
+def test_srdf_virtual_joint():
+    """a planar virtual joint in front of the URDF root: three more variables, the base is a gene-bearing joint of the group"""
+    srdf = SRDF.replace('<group name="arm_chain">', '<virtual_joint name="world_joint" type="planar" parent_frame="odom" child_link="base"/>'
+                        '<group name="mobile"><joint name="world_joint"/><group name="arm_chain"/></group><group name="arm_chain">')
+    m = load_urdf(URDF, srdf)
+    assert m.link_names[:2] == ["odom", "base"] and m.joint_type[1] == abi.JOINT_PLANAR
+    assert m.variable_names[:3] == ["world_joint/x", "world_joint/y", "world_joint/theta"]
+    g = m.groups["mobile"]
+    assert [m.joint_names[i] for i in g.active_joints] == ["world_joint", "s1", "s2", "e1", "w1", "w2"]
+    t = ProblemTemplate(m, "mobile", [PoseGoal("tool")])
+    from oracle import orc
+    assert orc.Oracle(t).D == 8
+
+
 def test_urdf_errors():
     with pytest.raises(ValueError):
         load_urdf("<robot><link name='a'/><link name='b'/></robot>")  # two roots
