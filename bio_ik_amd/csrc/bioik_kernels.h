@@ -70,12 +70,14 @@ BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f <
 // merge another sorted pair (o1 <= o2) into (b1 <= b2); positions are unique, so (f, pos) is a total order and the top-2 of
 // a union does not depend on the order of the merges
 BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o1f, int o1p, double o2f, int o2p) {
-    if (cand_better(o1f, o1p, b1f, b1p)) {
-        if (cand_better(b1f, b1p, o2f, o2p)) b2f = b1f, b2p = b1p; else b2f = o2f, b2p = o2p;
-        b1f = o1f, b1p = o1p;
-    } else if (cand_better(o1f, o1p, b2f, b2p)) {
-        b2f = o1f, b2p = o1p;
-    }
+    const bool w1 = cand_better(o1f, o1p, b1f, b1p);            // the other pair's best beats ours
+    const bool k2 = cand_better(b1f, b1p, o2f, o2p);            // then our best against their second
+    const bool w2 = cand_better(o1f, o1p, b2f, b2p);            // else their best against our second
+    const double n2f = w1 ? (k2 ? b1f : o2f) : (w2 ? o1f : b2f);
+    const int n2p = w1 ? (k2 ? b1p : o2p) : (w2 ? o1p : b2p);
+    b1f = w1 ? o1f : b1f;
+    b1p = w1 ? o1p : b1p;
+    b2f = n2f, b2p = n2p;
 }
 // wave64 xor-butterfly: afterwards every lane holds the two best of the wavefront.  (A DPP reduction with row broadcasts and
 // scalar read-back was measured 30 % slower than these six ds_bpermute rounds on gfx950.)
@@ -314,13 +316,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 // every child keeps its own column until selection; not with quaternion genes: a winner's momentum is taken from the
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
+                // the lane's best two so far; selects, no branches: as conditional stores the compiler turned b1 / b2 into an
+                // address select and kept them in scratch memory (two scratch round trips per child in the hottest loop)
                 auto offer = [&](double f, int pos) {
-                    if (cand_better(f, pos, b1f, b1p)) {
-                        b2f = b1f, b2p = b1p;
-                        b1f = f, b1p = pos;
-                    } else if (cand_better(f, pos, b2f, b2p)) {
-                        b2f = f, b2p = pos;
-                    }
+                    const bool w1 = cand_better(f, pos, b1f, b1p), w2 = cand_better(f, pos, b2f, b2p);
+                    b2f = w1 ? b1f : (w2 ? f : b2f);
+                    b2p = w1 ? b1p : (w2 ? pos : b2p);
+                    b1f = w1 ? f : b1f;
+                    b1p = w1 ? pos : b1p;
                 };
                 if (stored && sp.child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
