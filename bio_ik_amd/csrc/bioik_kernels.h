@@ -69,6 +69,15 @@ BIOIK_DEV bool cand_better(double f, int pos, double of, int opos) { return (f <
 // merging sorted pairs, then one LDS hop across waves.  Positions are unique, so (f,pos) is a total order.
 // merge another sorted pair (o1 <= o2) into (b1 <= b2); positions are unique, so (f, pos) is a total order and the top-2 of
 // a union does not depend on the order of the merges
+// one more candidate into the sorted pair (b1 <= b2).  Selects, no branches: written as conditional stores the compiler turns b1 / b2
+// into an address select and keeps them in scratch memory (two scratch round trips per child in the hottest loop).
+BIOIK_DEV void top2_insert(double& b1f, int& b1p, double& b2f, int& b2p, double f, int pos) {
+    const bool w1 = cand_better(f, pos, b1f, b1p), w2 = cand_better(f, pos, b2f, b2p);
+    b2f = w1 ? b1f : (w2 ? f : b2f);
+    b2p = w1 ? b1p : (w2 ? pos : b2p);
+    b1f = w1 ? f : b1f;
+    b1p = w1 ? pos : b1p;
+}
 BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o1f, int o1p, double o2f, int o2p) {
     const bool w1 = cand_better(o1f, o1p, b1f, b1p);            // the other pair's best beats ours
     const bool k2 = cand_better(b1f, b1p, o2f, o2p);            // then our best against their second
@@ -109,12 +118,7 @@ BIOIK_DEV void top2_xwave(double& b1f, int& b1p, double& b2f, int& b2p, double* 
             for (int i = 0; i < 2; i++) {
                 double of = d[2 * i];
                 int op = (int)d[2 * i + 1];
-                if (cand_better(of, op, b1f, b1p)) {
-                    b2f = b1f, b2p = b1p;
-                    b1f = of, b1p = op;
-                } else if (cand_better(of, op, b2f, b2p)) {
-                    b2f = of, b2p = op;
-                }
+                top2_insert(b1f, b1p, b2f, b2p, of, op);
             }
         }
         p_barrier();
@@ -316,15 +320,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 // every child keeps its own column until selection; not with quaternion genes: a winner's momentum is taken from the
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
-                // the lane's best two so far; selects, no branches: as conditional stores the compiler turned b1 / b2 into an
-                // address select and kept them in scratch memory (two scratch round trips per child in the hottest loop)
-                auto offer = [&](double f, int pos) {
-                    const bool w1 = cand_better(f, pos, b1f, b1p), w2 = cand_better(f, pos, b2f, b2p);
-                    b2f = w1 ? b1f : (w2 ? f : b2f);
-                    b2p = w1 ? b1p : (w2 ? pos : b2p);
-                    b1f = w1 ? f : b1f;
-                    b1p = w1 ? pos : b1p;
-                };
+                auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
                 if (stored && sp.child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
                     for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
