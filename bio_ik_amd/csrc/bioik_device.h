@@ -189,36 +189,12 @@ BIOIK_CALL double goal_eval_link_rare(int type, GoalPar gp, F7 fb) {
     }
     return 0.0;
 }
-BIOIK_DEV int goal_param_count(int type) {  // include/bioik_hip.h bioik_goal_param_count
-    switch (type) {
-        case G_LOOK_AT: case G_LINE: case G_PLANE: case G_SIDE: case G_DIRECTION: return 6;
-        case G_MAX_DISTANCE: case G_MIN_DISTANCE: return 4;
-        case G_CONE: return 11;
-    }
-    return 0;
-}
-
-BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
+// The goals over the joint values (goal_types.h:387-498): one out-of-line copy; x and the seed are LDS pointers that cross the
+// call with their address space spelled out.
+BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
     const int n_ops = pb->n_ops;
-#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
-    type = G_POSE;
-#endif
+    auto x = [&](int k) -> double { return xp[(size_t)k * xs]; };
     switch (type) {
-        case G_POSITION:  // goal_types.h:96
-            return dist2(fb.p, v3(P[0], P[1], P[2]));
-        case G_ORIENTATION: {  // :115-124
-            const Q4 d = Q4{P[0] - fb.q.x, P[1] - fb.q.y, P[2] - fb.q.z, P[3] - fb.q.w};
-            const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
-            return fmin(qdot(d, d), qdot(a, a));
-        }
-        case G_POSE: {  // :149-180
-            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
-            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
-            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
-            double rs = P[7];
-            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
-            return e;
-        }
         case G_AVOID_JOINT_LIMITS: {  // :387-401
             double sum = 0.0;
             for (int k = 0; k < n_ops; k++)
@@ -244,7 +220,7 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             double sum = 0.0;
             for (int k = 0; k < n_ops; k++)
                 if (pb->ops[k].gene >= 0) {
-                    double d = x(k) - qc.seed[pb->ops[k].var];
+                    double d = x(k) - seed[pb->ops[k].var];
                     sum += d * d;
                 }
             return sum;
@@ -253,17 +229,64 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             double sum = 0.0;
             for (int k = 0; k < n_ops; k++)
                 if (pb->ops[k].gene >= 0) {
-                    double d = x(k) - qc.seed[pb->ops[k].var];
+                    double d = x(k) - seed[pb->ops[k].var];
                     d *= pb->ops[k].vw;
                     sum += d * d;
                 }
             return sum;
         }
         case G_JOINT_VARIABLE: {  // :494-498 + goal.h:70-77
-            double v = var_op >= 0 ? x(var_op) : qc.seed[var_seed];
-            double d = P[0] - v;
+            double v = var_op >= 0 ? x(var_op) : seed[var_seed];
+            double d = p0 - v;
             return d * d;
         }
+    }
+    return 0.0;
+}
+
+BIOIK_CALL double goal_eval_joint_set(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
+    return goal_eval_joint_set_inl(pb, type, var_op, var_seed, p0, xp, xs, seed);
+}
+BIOIK_DEV int goal_param_count(int type) {  // include/bioik_hip.h bioik_goal_param_count
+    switch (type) {
+        case G_LOOK_AT: case G_LINE: case G_PLANE: case G_SIDE: case G_DIRECTION: return 6;
+        case G_MAX_DISTANCE: case G_MIN_DISTANCE: return 4;
+        case G_CONE: return 11;
+    }
+    return 0;
+}
+
+// JS_INLINE: the goals over the joint values are inlined (the one hot site: secondary fitness of every child in the pre-selection)
+template <bool JS_INLINE = false>
+BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
+    const int n_ops = pb->n_ops;
+#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
+    type = G_POSE;
+#endif
+    switch (type) {
+        case G_POSITION:  // goal_types.h:96
+            return dist2(fb.p, v3(P[0], P[1], P[2]));
+        case G_ORIENTATION: {  // :115-124
+            const Q4 d = Q4{P[0] - fb.q.x, P[1] - fb.q.y, P[2] - fb.q.z, P[3] - fb.q.w};
+            const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
+            return fmin(qdot(d, d), qdot(a, a));
+        }
+        case G_POSE: {  // :149-180
+            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
+            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
+            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
+            double rs = P[7];
+            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
+            return e;
+        }
+        case G_AVOID_JOINT_LIMITS:
+        case G_CENTER_JOINTS:
+        case G_REGULARIZATION:
+        case G_MINIMAL_DISPLACEMENT:
+        case G_JOINT_VARIABLE:
+            if (JS_INLINE)
+                return goal_eval_joint_set_inl(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
+            return goal_eval_joint_set(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
         default: {  // the remaining link goals
             GoalPar gp;
             const int np = goal_param_count(type);
@@ -294,11 +317,12 @@ BIOIK_DEV double nonlink_primary(ProbPtr pb, const XV& x, const QueryCtx& qc) {
     return sum;
 }
 // secondary goals see genes only; link goals marked secondary read null frames (ik_base.h:163)
+template <bool JS_INLINE = false>
 BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) {
     double sum = 0.0;
     const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     for (int g = 0; g < pb->n_secondary; g++)
-        sum += goal_eval(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
+        sum += goal_eval<JS_INLINE>(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
                pb->secondary[g].weight_sq;
     return sum;
 }

@@ -296,7 +296,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
                     for (int c = gtid; c < lambda; c += G) {
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
-                        s_sec[c] = secondary_fitness(pb, xl, qc);
+                        s_sec[c] = secondary_fitness<true>(pb, xl, qc);
                     }
                     group_sync(G);
                     for (int c = gtid; c < lambda; c += G) {

@@ -18,6 +18,7 @@
 #include <vector>
 #define BIOIK_DEV inline
 #define BIOIK_CALL __attribute__((noinline)) inline
+typedef double lds_f64;
 #define BIOIK_CONTRACT_OFF
 typedef const DevProblem* ProbPtr;
 typedef const DevProblemLean* LeanProbPtr;
@@ -67,6 +68,9 @@ BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
 // A real function (one copy in the kernel, its own register allocation) for cold, arithmetic-heavy code.  Only for functions
 // whose arguments and results are plain values: ROCm 7.2's gfx950 backend rejects LDS pointers that cross a call boundary.
 #define BIOIK_CALL __device__ __attribute__((noinline))
+// LDS pointers that do cross a call boundary are passed with their address space spelled out (a GENERIC pointer to LDS crossing
+// a call trips a backend bug of this toolchain)
+typedef __attribute__((address_space(3))) double lds_f64;
 // uniform, read-only problem block: the constant address space makes every access a scalar (s_load) candidate
 typedef const DevProblem __attribute__((address_space(4))) * ProbPtr;
 typedef const DevProblemLean __attribute__((address_space(4))) * LeanProbPtr;
