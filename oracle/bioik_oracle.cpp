@@ -49,6 +49,9 @@ extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
 void orc_set_trig_mode(int mode) { trig_mode() = mode ? 1 : 0; }
+void orc_shared_sincos(size_t n, const double* x, double* s, double* c) {
+    for (size_t i = 0; i < n; i++) bioik_sincos(x[i], s + i, c + i);
+}
 int orc_get_trig_mode(void) { return trig_mode(); }
 void orc_set_quirk_mode(int mode) { quirk_mode() = mode ? 1 : 0; }
 

@@ -39,6 +39,8 @@ enum {
 const char* orc_last_error(void);
 /* 0: libm sin/cos as in the reference (default); 1: bioik_sincos shared bit-for-bit with the device (orc_model.h) */
 void orc_set_trig_mode(int mode);
+/* the sincos shared with the device kernels (bio_ik_amd/csrc/bioik_sincos.h), exposed for its accuracy test */
+void orc_shared_sincos(size_t n, const double* x, double* s, double* c);
 int orc_get_trig_mode(void);
 /* 0: quirks Q1 (stale masked tips) and Q4 (unstable pre-selection sort) fixed, as on the device (default);
  * 1: literal reference behaviour, for the trajectory comparison against oracle/_ref (orc_model.h) */

@@ -52,6 +52,14 @@ def set_trig_mode(mode, kind="strict"):
     lib(kind).orc_set_trig_mode(C.c_int(mode))
 
 
+def shared_sincos(x, kind="strict"):
+    """bioik_sincos (the implementation shared with the device kernels) of an array"""
+    x = _f64(x).ravel()
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    lib(kind).orc_shared_sincos(C.c_size_t(x.size), _d(x), _d(s), _d(c))
+    return s, c
+
+
 def set_quirk_mode(mode, kind="strict"):
     """0 = reference quirks Q1/Q4 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
     lib(kind).orc_set_quirk_mode(C.c_int(mode))
