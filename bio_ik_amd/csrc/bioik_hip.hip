@@ -239,25 +239,61 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const DevProblem& dp = p->host.dev;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
+    // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
+    // and evaluated in pairs / kept / re-derived from the RNG, or 64 lanes (one wavefront, the species one after the other).  A CU
+    // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
+    // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
+    // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
     int nth = solve_threads(sp, units);
-    while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
-    // keep every child of a generation in LDS (winners are then read, not re-derived) when that costs <= 32 KiB
-    sp.species_parallel = (nth % 128 == 0) ? 1 : 0;
-    if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && nth % 128 == 0) ? 1 : 0;
-    const int groups = sp.species_parallel ? 2 : 1, G = nth / groups;
-    sp.child_cols = (sp.lambda + G - 1) / G;
-    if (dp.n_quat > 0) {
-        sp.child_cols = 1;  // winners are re-derived: their momentum is taken before the quaternion genes are renormalised (:299 vs :320)
-    } else if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
-        if (std::atoi(e) == 0) sp.child_cols = 1;
-    } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups) > 48 * 1024) {
-        sp.child_cols = 1;
+    const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
+    const bool manual = std::getenv("BIOIK_SOLVE_THREADS") || std::getenv("BIOIK_SOLVE_STORE_CHILDREN") || std::getenv("BIOIK_SOLVE_CHILD_PAIRS") ||
+                        std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL");
+    if (!manual && nth == 128) {
+        struct Cand {
+            int nth, store, pairs;
+        };
+        const Cand cands[] = {{128, 1, 1}, {128, 1, 0}, {128, 0, 0}, {64, 0, 0}};
+        int best = -1, best_waves = -1;
+        for (int i = 0; i < 4; i++) {
+            const Cand& c = cands[i];
+            if ((c.store || c.pairs) && quat) continue;
+            if (c.pairs && sp.fk_mode != BIOIK_FK_EXACT) continue;
+            const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
+            const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : 1;
+            if (c.pairs && cols < 2) continue;
+            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1);
+            if (bytes > 160 * 1024) continue;
+            int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
+            if (waves > 12) waves = 12;
+            // full CU: first (richest) candidate wins; LDS-limited: a later (leaner) candidate wins ties
+            if (waves > best_waves || (waves == best_waves && waves < 12)) best = i, best_waves = waves;
+        }
+        if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+        nth = cands[best].nth;
+        sp.species_parallel = nth % 128 == 0 ? 1 : 0;
+        const int G_b = nth / (sp.species_parallel ? 2 : 1);
+        sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
+        sp.child_pairs = cands[best].pairs;
+    } else {
+        while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
+        sp.species_parallel = (nth % 128 == 0) ? 1 : 0;
+        if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && nth % 128 == 0) ? 1 : 0;
+        const int groups_m = sp.species_parallel ? 2 : 1, G_m = nth / groups_m;
+        sp.child_cols = (sp.lambda + G_m - 1) / G_m;
+        if (quat) {
+            sp.child_cols = 1;
+        } else if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
+            if (std::atoi(e) == 0) sp.child_cols = 1;
+        } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m) > 48 * 1024) {
+            sp.child_cols = 1;
+        }
+        // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
+        // trees, a second set of parked frames
+        sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2) <= 64 * 1024) ? 1 : 0;
+        if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
+            if (std::atoi(e) == 0) sp.child_pairs = 0;
     }
-    // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
-    // trees, a second set of parked frames
-    sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, 2) <= 64 * 1024) ? 1 : 0;
-    if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
-        if (std::atoi(e) == 0) sp.child_pairs = 0;
+    const int groups = sp.species_parallel ? 2 : 1;
     const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
 #if !defined(BIOIK_HOSTSIM)
