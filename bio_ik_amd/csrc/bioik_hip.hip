@@ -43,6 +43,8 @@ static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 static void be_free(void* p) { std::free(p); }
 static void* be_alloc_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 static void be_free_pinned(void* p) { std::free(p); }
+static void* be_alloc_async(size_t bytes, stream_t) { return std::malloc(bytes ? bytes : 1); }
+static void be_free_async(void* p, stream_t) { std::free(p); }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
 static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
 static void be_sync(stream_t) {}
@@ -94,6 +96,15 @@ static void* be_alloc_pinned(size_t bytes) {  // page-locked host memory: hipMem
 }
 static void be_free_pinned(void* p) {
     if (p) (void)hipHostFree(p);
+}
+// stream-ordered scratch: launches of one problem handle on different streams never share it
+static void* be_alloc_async(size_t bytes, stream_t s) {
+    void* p = nullptr;
+    HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 8, s));
+    return p;
+}
+static void be_free_async(void* p, stream_t s) {
+    if (p) (void)hipFreeAsync(p, s);
 }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t s) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
@@ -166,9 +177,6 @@ struct bioik_problem {
     bioik_model* model;
     bioik::HostProblem host;
     DevProblem* d_pb = nullptr;
-    // grow-only device workspace for the island results of solve_batch_device
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
     // grow-only device arena + page-locked host mirror for the host-pointer entry point (bioik_solve_batch): one allocation
     // for the life of the handle, one DMA in and one DMA out per call
     void* io_dev = nullptr;
@@ -305,6 +313,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0;
     if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
         if (std::atoi(e) != 0) lean = false;
+    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;
@@ -321,13 +330,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     } else {
         size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
         size_t need = units * per + 64;
-        if (p->ws_bytes < need) {
-            be_free(p->ws);
-            p->ws = nullptr, p->ws_bytes = 0;
-            p->ws = be_alloc(need);
-            p->ws_bytes = need;
-        }
-        char* w = (char*)p->ws;
+        island_ws = be_alloc_async(need, stream);
+        char* w = (char*)island_ws;
         a.solutions = (double*)w, w += units * dp.V * 8;
         a.fitness = (double*)w, w += units * 8;
         a.success = (int32_t*)w, w += units * 4;
@@ -359,6 +363,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         hipLaunchKernelGGL(k_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s);
         HIP_CHECK(hipGetLastError());
 #endif
+        be_free_async(island_ws, stream);
     }
 }
 
@@ -415,7 +420,6 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
 void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
-    be_free(p->ws);
     be_free(p->io_dev);
     be_free_pinned(p->io_host);
     delete p;

@@ -211,7 +211,10 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
                       int32_t* steps);
 
 /* Device-pointer variant: all arrays already resident in HBM on the problem's device; enqueues on
- * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising. */
+ * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising.
+ * Launches of ONE problem handle on different streams may be in flight together (their result arrays must differ, the
+ * island scratch is stream-ordered): keeping two batches in flight hides the slow tail of each launch behind the bulk
+ * of the next. */
 int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds,
                              const double* d_goal_params, double* d_solutions, double* d_fitness,
                              int32_t* d_success, int32_t* d_steps, void* hip_stream);

@@ -221,6 +221,30 @@ def test_device_pointer_entry_and_streamed_fitness(gpus, oracles, templates):
         assert np.array_equal(got[u], want)
 
 
+def test_two_launches_in_flight(gpus, templates):
+    """one problem handle, two HIP streams, launches in flight together (islands > 1 use stream-ordered scratch): every launch
+    returns what a lone launch returns"""
+    import torch
+    h, t = gpus["c2"], templates["c2"]
+    dev = torch.device("cuda", 0)
+    n = 512
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=77)
+    for islands in (1, 2):
+        p = abi.default_solve_params(population=64, max_steps=16, random_seed=5, islands=islands)
+        ref = h.solve_batch(p, seeds, params)
+        ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        outs = [(torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+                 torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(4)]
+        torch.cuda.synchronize(dev)
+        for i, o in enumerate(outs):
+            h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                                 streams[i % 2].cuda_stream)
+        torch.cuda.synchronize(dev)
+        for o in outs:
+            assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3])
+
+
 def test_error_conventions(pr2):
     """status codes instead of exceptions/aborts (include/bioik_hip.h)"""
     from bio_ik_amd import PoseGoal, RobotModel
