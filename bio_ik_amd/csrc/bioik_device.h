@@ -47,9 +47,9 @@ BIOIK_DEV double dot3(V3 a, V3 b) { return bk_dot3(a.x, a.y, a.z, b.x, b.y, b.z)
 BIOIK_DEV V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 BIOIK_DEV double len2(V3 a) { return dot3(a, a); }
 BIOIK_DEV double dist2(V3 a, V3 b) { return len2(b - a); }
-BIOIK_DEV V3 normalized3(V3 a) {
-    double l = sqrt(len2(a));
-    return V3{a.x / l, a.y / l, a.z / l};
+BIOIK_DEV V3 normalized3(V3 a) {  // tf2: v * (1 / length)
+    const double inv = 1.0 / sqrt(len2(a));
+    return V3{a.x * inv, a.y * inv, a.z * inv};
 }
 BIOIK_DEV double qdot(Q4 a, Q4 b) { return bk_dot4(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
 BIOIK_DEV Q4 qinv(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
@@ -355,8 +355,8 @@ BIOIK_DEV void multi_joint_bump(F7& v, int i, double step) {  // variable i += s
 }
 BIOIK_DEV F7 multi_joint_frame(int type, const F7& v) {
     if (type == BIOIK_OP_FLOATING) {
-        const double l = sqrt(qdot(v.q, v.q));
-        return F7{v.p, {v.q.x / l, v.q.y / l, v.q.z / l, v.q.w / l}};
+        const double inv = 1.0 / sqrt(qdot(v.q, v.q));  // tf2 Quaternion::normalized: q * (1 / length)
+        return F7{v.p, {v.q.x * inv, v.q.y * inv, v.q.z * inv, v.q.w * inv}};
     }
     double sn, cs;
     p_sincos(v.p.z * 0.5, &sn, &cs);  // planar: Translation(x, y, 0) * AngleAxis(theta, Z)

@@ -64,9 +64,9 @@ inline double distance(const Vec3& a, const Vec3& b) { return length(b - a); }
 inline Vec3 cross(const Vec3& a, const Vec3& b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-inline Vec3 normalized(const Vec3& a) {  // tf2: *this / length()
-    double l = length(a);
-    return {a.x / l, a.y / l, a.z / l};
+inline Vec3 normalized(const Vec3& a) {  // tf2: *this / length(), and tf2's operator/ multiplies by the reciprocal
+    double inv = 1.0 / length(a);
+    return {a.x * inv, a.y * inv, a.z * inv};
 }
 inline double tf2_acos(double x) {  // tf2Acos clamps its argument (tf2/LinearMath/Scalar.h)
     if (x < -1.0) x = -1.0;
@@ -87,9 +87,9 @@ inline double length2(const Quat& a) { return dot(a, a); }
 inline Quat operator+(const Quat& a, const Quat& b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 inline Quat operator-(const Quat& a, const Quat& b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
 inline Quat operator-(const Quat& a) { return {-a.x, -a.y, -a.z, -a.w}; }
-inline Quat normalized(const Quat& a) {
-    double l = std::sqrt(length2(a));
-    return {a.x / l, a.y / l, a.z / l, a.w / l};
+inline Quat normalized(const Quat& a) {  // tf2: *this / length() = *this * (1 / length())
+    double inv = 1.0 / std::sqrt(length2(a));
+    return {a.x * inv, a.y * inv, a.z * inv, a.w * inv};
 }
 inline Quat inverse(const Quat& q) { return {-q.x, -q.y, -q.z, q.w}; }  // tf2::Quaternion::inverse
 // tf2 operator*(Quaternion, Quaternion): Hamilton product
