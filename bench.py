@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the warm-up and the K timed steps (no one-at-a-time leg, no secondary measurements): what the rocprofv3 kernel "
+                         "statistics in profiles/ are taken over, so that their average duration is that of the timed launches")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "2")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other)")
@@ -119,7 +122,7 @@ def main():
     d_sol, d_fit, d_suc, d_steps = bufs[0]
     identical = all(bool(torch.equal(o[0], d_sol)) and bool(torch.equal(o[2], d_suc)) and bool(torch.equal(o[3], d_steps)) for o in bufs[1:])
     sequential = None
-    if nfl > 1:  # the same steps strictly one after the other, for the record
+    if nfl > 1 and not args.timed_only:  # the same steps strictly one after the other, for the record
         nfl_saved, nfl = nfl, 1
         sel, skm = timed(min(args.steps, 10), 1)
         nfl = nfl_saved
@@ -190,7 +193,7 @@ def main():
     # Secondary measurement (north-star layout): the population genotype array resident in HBM, genes [unit][D][pop]
     # (individual index fastest), one launch = exact-FK fitness of every individual.  Reported next to the solver line;
     # it is not what `value` measures.
-    if rank == 0 and world == 1 and os.environ.get("BIOIK_BENCH_STREAM", "1") != "0":
+    if rank == 0 and world == 1 and os.environ.get("BIOIK_BENCH_STREAM", "1") != "0" and not args.timed_only:
         units = 16384
         stream = torch.cuda.current_stream(dev)
         g = torch.rand((units, D, POP), dtype=torch.float64, device=dev) * 2.0 - 1.0
@@ -213,7 +216,7 @@ def main():
                                    "achieved_GBps": sbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": sbytes / (ms * 1e-3) / HBM_PEAK,
                                    "layout": "genes [unit][D][pop] f64 in HBM, 512-byte segments per wavefront load"}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.timed_only:
         # the host-pointer entry point (what the plugin calls): staging into page-locked memory, one DMA each way, the launch
         ts = []
         for _ in range(3):
@@ -224,7 +227,7 @@ def main():
                                      "results_identical_to_device_entry": bool(np.array_equal(hs[0], sol) and np.array_equal(hs[2], suc)),
                                      "note": "bioik_solve_batch: host arrays in and out (PCIe-inclusive), one launch at a time; never `value`"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle import orc, ref
         ns = min(args.cpu_sample, BATCH)
         # (1) the oracle (a port of the reference algorithm, reference Release flags, libm) with the SAME parameters as the
