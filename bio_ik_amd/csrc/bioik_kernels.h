@@ -167,6 +167,7 @@ struct SpeciesState {
     int slot;         // LDS slot of the species' elites
     int cur;          // which of the two LDS buffers holds the elites
     int improved;
+    int ok;           // success test of the first elite (it is what becomes the solution when the species leads)
 };
 
 // LEAN: the flavour without floating / planar joints (see pb_flavour); the launcher picks it whenever the problem allows
@@ -238,6 +239,18 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         }
         return v;
     };
+    auto group_check = [&](const XV& x) -> FitCheck {  // exact fitness + success test of a group's vector, known to the whole group
+        FitCheck fc{0.0, 0};
+        if (glead) fc = exact_fitness_check(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
+        if (G > 64) {
+            if (gtid == 0) s_bc[0] = fc.fitness, s_bc[2] = (double)fc.ok;
+            p_barrier();
+            fc.fitness = s_bc[0];
+            fc.ok = (int)s_bc[2];
+            p_barrier();
+        }
+        return fc;
+    };
     auto wg_check = [&](const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
         FitCheck fc{0.0, 0};
         if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);
@@ -267,8 +280,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         if (tid == 0) f7_store(s_prefix, fk_prefix(pb, XV{s_sol, 1}));
         p_barrier();
     }
-    double sol_fit = wg_check(XV{s_sol, 1}, 0.0, 0.0, 0.0, 0).fitness;
-    SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0};
+    // the seed is the first solution; whether it already satisfies the goals is what the first success test will find
+    const FitCheck fc0 = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
+    double sol_fit = fc0.fitness;
+    int sol_ok = fc0.ok;
+    SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0, 0};
     const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
     PHASE_MARK(PH_INIT);
 
@@ -500,13 +516,16 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 group_sync(G);
                 PHASE_MARK(PH_MEM_TAIL);
             }
-            // species ranking fitness: exact FK of the elite (:607-614)
+            // species ranking fitness: exact FK of the elite (:607-614).  The same walk decides whether that elite satisfies the goals
+            // (problem.cpp:259-341): if the species leads and improves on the solution, this elite IS the new solution, so the
+            // island loop's success test (ik_parallel.h:173-181) needs no walk of its own.
             {
                 const double* cb = popS + S.cur * BF;
-                double fit = group_value([&]() { return exact_fitness_check(pb, XV{cb, 1}, qc, s_slots, 0.0, 0.0, 0.0, 0, s_prefix).fitness; });
-                S.improved = (fit != S.fit) ? 1 : 0;
-                S.fit = fit;
-                S.pf0 = fit;
+                const FitCheck fc = group_check(XV{cb, 1});
+                S.improved = (fc.fitness != S.fit) ? 1 : 0;
+                S.fit = fc.fitness;
+                S.pf0 = fc.fitness;
+                S.ok = fc.ok;
                 PHASE_MARK(PH_RANK);
             }
             if (rank == 0) A = S; else B = S;
@@ -515,11 +534,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             if (gtid == 0) {
                 const SpeciesState& S = grp == 0 ? A : B;
                 double* d = s_state + grp * 8;
-                d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved;
+                d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved, d[7] = (double)S.ok;
             }
             p_barrier();
-            A = SpeciesState{s_state[0], s_state[1], s_state[2], (int)s_state[3], (int)s_state[4], (int)s_state[5], (int)s_state[6]};
-            B = SpeciesState{s_state[8], s_state[9], s_state[10], (int)s_state[11], (int)s_state[12], (int)s_state[13], (int)s_state[14]};
+            A = SpeciesState{s_state[0], s_state[1], s_state[2], (int)s_state[3], (int)s_state[4], (int)s_state[5], (int)s_state[6], (int)s_state[7]};
+            B = SpeciesState{s_state[8], s_state[9], s_state[10], (int)s_state[11], (int)s_state[12], (int)s_state[13], (int)s_state[14], (int)s_state[15]};
             p_barrier();
         }
 
@@ -561,12 +580,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
             p_barrier();
             for (int k = tid; k < n_ops; k += nth) s_sol[k] = cb[k];
             sol_fit = A.fit;
+            sol_ok = A.ok;
             p_barrier();
         }
-        // ik_parallel.h:173-181: exact FK of the solution, success test, fitness
-        FitCheck fc = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
-        final_fit = fc.fitness;
-        success = fc.ok != 0;
+        // ik_parallel.h:173-181: fitness and success test of the solution = those of the elite it was copied from (or of the seed)
+        final_fit = sol_fit;
+        success = sol_ok != 0;
         PHASE_MARK(PH_CHECK);
         if (success) break;
     }
