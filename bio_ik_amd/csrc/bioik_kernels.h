@@ -89,14 +89,27 @@ BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o
     b2f = n2f, b2p = n2p;
 }
 // wave64 xor-butterfly: afterwards every lane holds the two best of the wavefront.  (A DPP reduction with row broadcasts and
-// scalar read-back was measured 30 % slower than these six ds_bpermute rounds on gfx950.)
+// scalar read-back was measured 30 % slower than ds_bpermute rounds on gfx950; the two steps inside a quad are DPP moves.)
 BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = 32; m >= 16; m >>= 1) {  // across the four rows of 16 lanes: LDS-crossbar permutes
         double o1f = p_shfl_xor(b1f, m), o2f = p_shfl_xor(b2f, m);
         int o1p = p_shfl_xor(b1p, m), o2p = p_shfl_xor(b2p, m);
         top2_merge(b1f, b1p, b2f, b2p, o1f, o1p, o2f, o2p);
     }
+    // inside a row: DPP moves (mirror of the row, mirror of the half row, then the two quad permutations) -- every lane has met
+    // every other lane's pair after these four steps
+#define TOP2_DPP_STEP(MOVE)                                          \
+    {                                                                \
+        const double o1f = MOVE(b1f), o2f = MOVE(b2f);               \
+        const int o1p = MOVE(b1p), o2p = MOVE(b2p);                  \
+        top2_merge(b1f, b1p, b2f, b2p, o1f, o1p, o2f, o2p);          \
+    }
+    TOP2_DPP_STEP(p_row_mirror<0>)
+    TOP2_DPP_STEP(p_row_mirror<1>)
+    TOP2_DPP_STEP(p_quad_xor<2>)
+    TOP2_DPP_STEP(p_quad_xor<1>)
+#undef TOP2_DPP_STEP
 }
 // rendezvous of one lane group: a single wavefront needs no s_barrier (p_wave_sync), several wavefronts take the workgroup
 // barrier -- every group of the workgroup then executes the same number of them

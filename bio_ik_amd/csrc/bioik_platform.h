@@ -57,6 +57,13 @@ BIOIK_DEV T p_shfl(T v, int src_lane) {
 }
 template <class T>
 BIOIK_DEV T p_shfl_xor(T v, int mask) { return p_shfl(v, (sim::tid & 63) ^ mask); }
+template <int MASK, class T>
+BIOIK_DEV T p_quad_xor(T v) { return p_shfl_xor(v, MASK); }
+template <int HALF, class T>  // lane i <-> 15 - i of its row of 16 (HALF = 0) or 7 - i of its half row (HALF = 1)
+BIOIK_DEV T p_row_mirror(T v) {
+    const int l = sim::tid & 63;
+    return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))));
+}
 BIOIK_DEV int p_uniform(int v) { return v; }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
 #define P_INF (__builtin_inf())
@@ -89,6 +96,26 @@ template <class T>
 BIOIK_DEV T p_shfl(T v, int src_lane) { return __shfl(v, src_lane, 64); }
 template <class T>
 BIOIK_DEV T p_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+// lane ^ 1 / lane ^ 2 inside a quad as a DPP move (quad_perm): no LDS crossbar round trip
+template <int MASK>
+BIOIK_DEV int p_quad_xor(int v) {
+    static_assert(MASK == 1 || MASK == 2, "quad_perm covers xor 1 and xor 2");
+    return __builtin_amdgcn_mov_dpp(v, MASK == 1 ? 0xB1 : 0x4E, 0xf, 0xf, true);  // [1,0,3,2] / [2,3,0,1]
+}
+template <int HALF>
+BIOIK_DEV int p_row_mirror(int v) { return __builtin_amdgcn_mov_dpp(v, HALF ? 0x141 : 0x140, 0xf, 0xf, true); }  // row_half_mirror / row_mirror
+template <int HALF>
+BIOIK_DEV double p_row_mirror(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = p_row_mirror<HALF>((int)b), hi = p_row_mirror<HALF>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int MASK>
+BIOIK_DEV double p_quad_xor(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = p_quad_xor<MASK>((int)b), hi = p_quad_xor<MASK>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 #define P_INF (__builtin_inf())
