@@ -395,13 +395,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 if (first.id != 1 && (second.id < 0 || cand_better(S.pf1, 1, second.f, second.pos))) second = Cand{S.pf1, 1, 1};
                 if (second.id < 0 || cand_better(c2f, c2p, second.f, second.pos)) second = Cand{c2f, c2p, c2p};
                 // the winners become the elites (written to the species' other buffer)
+                // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its op k (at most 32 ops)
                 double* nb = popS + (S.cur ^ 1) * BF;
-                for (int i = 0; i < 2; i++) {
+                if (gtid < 64) {
+                    const int i = gtid >> 5, k = gtid & 31;
                     const int id = i == 0 ? first.id : second.id;
                     double* dst = nb + i * 2 * M;
                     if (id < 2) {
                         const double* src = cb + id * 2 * M;
-                        for (int k = gtid; k < 2 * M; k += G) dst[k] = src[k];
+                        if (k < M) dst[k] = src[k], dst[M + k] = src[M + k];
                     } else if (stored) {
                         // the winner's genes are still in its owner's column; its momentum follows from the genes
                         // (ik_evolution_2.cpp:299: gradient = mix(parent_gradient, gene - parent_gene, 0.3))
@@ -410,7 +412,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         const int c = has_sec ? s_order[r] : r;
                         const double fmix = (((uint32_t)c + 2u) % 2u == 0u) ? 0.2 : 0.0;
                         const double* src = (lds + L.xcol) + (size_t)(r / G) * M * nth + (grp * G + r % G);
-                        for (int k = gtid; k < n_ops; k += G) {
+                        if (k < n_ops) {
                             double gene = src[(size_t)k * nth];
                             double mom = 0.0;
                             if ((active_mask >> k) & 1u) {
@@ -419,7 +421,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             }
                             dst[k] = gene, dst[M + k] = mom;
                         }
-                    } else if (gtid == 0) {  // not stored: re-derive the child from the counter RNG
+                    } else if (k == 0) {  // not stored: re-derive the child from the counter RNG
                         int c = has_sec ? s_order[id - 2] : id - 2;
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, dst, 1, dst + M, 1);
                     }
