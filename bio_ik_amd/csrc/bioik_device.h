@@ -260,9 +260,6 @@ BIOIK_DEV int goal_param_count(int type) {  // include/bioik_hip.h bioik_goal_pa
 template <bool JS_INLINE = false>
 BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
     const int n_ops = pb->n_ops;
-#ifdef BIOIK_EXP_POSE_ONLY  // experiment: code-size sensitivity (only valid for PoseGoal-only problems)
-    type = G_POSE;
-#endif
     switch (type) {
         case G_POSITION:  // goal_types.h:96
             return dist2(fb.p, v3(P[0], P[1], P[2]));
@@ -1068,11 +1065,7 @@ BIOIK_CALL int check_frame_goal(int type, F7 fa, F7 fb, double dpos, double drot
 }
 
 BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const QueryCtx& qc, double dpos, double drot, double dtwist) {
-#ifdef BIOIK_EXP_POSE_ONLY
-    const int type = G_POSE;
-#else
     const int type = pb->primary[g].type;
-#endif
     const double* P = qc.par + pb->primary[g].param_off;
     bool ok = true;
     if (type == G_POSITION) {

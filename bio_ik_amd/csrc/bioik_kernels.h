@@ -491,9 +491,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         PHASE_MARK(PH_MEM_NORM);
                         const double sgn = (lane & 1) ? 1.0 : -1.0;
                         for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * (s_gop[k] * fnorm);
-                        PHASE_MARK(22);
+                        PHASE_MARK(PH_MEM_SUPPORT_COLS);
                         double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
-                        PHASE_MARK(23);
+                        PHASE_MARK(PH_MEM_SUPPORT_EVAL);
                         const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
                         double step_size;
                         if (sp.memetic == 'q') {  // :498-539
@@ -509,7 +509,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             const double e = el[k], gv = s_gop[k] * fnorm;
                             xcol[(size_t)k * nth] = ((active_mask >> k) & 1u) ? fmin(fmax(e + gv * step_size, cmin), cmax) : e;
                         }
-                        PHASE_MARK(PH_PRESELECT);
+                        PHASE_MARK(PH_MEM_CANDIDATE);
                         const double f4p = eval_linear_primary(pb, xl, qc, lm);
                         if (!(f4p < f2p)) live = false;  // accept iff the primary fitness improves, else stop (:527-538)
                     }

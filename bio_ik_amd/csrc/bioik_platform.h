@@ -167,7 +167,8 @@ enum { PH_INIT = 0, PH_REPRODUCE = 1, PH_FITNESS = 2, PH_SELECTION = 3, PH_MEMET
        // finer marks of the profiling build: selection = top-2 butterfly / cross-wave hop / winner copy / closing barrier;
        // memetics = linearisation / gradient / normalisation / line search / acceptance; counters of iterations
        PH_SEL_TOP2 = 8, PH_SEL_XWAVE = 9, PH_SEL_COPY = 10, PH_SEL_BAR = 11, PH_MEM_APPROX = 12, PH_MEM_GRAD = 13, PH_MEM_NORM = 14,
-       PH_MEM_LINE = 15, PH_MEM_ACCEPT = 16, PH_MEM_TAIL = 17, PH_RANK = 18, PH_N_MEM_ITER = 19, PH_N_STEPS = 20, PH_LINEARISE = 21 };
+       PH_MEM_LINE = 15, PH_MEM_ACCEPT = 16, PH_MEM_TAIL = 17, PH_RANK = 18, PH_N_MEM_ITER = 19, PH_N_STEPS = 20, PH_LINEARISE = 21,
+       PH_MEM_SUPPORT_COLS = 22, PH_MEM_SUPPORT_EVAL = 23, PH_MEM_CANDIDATE = 7 /* shares the slot of PH_PRESELECT */ };
 
 // sin/cos of the joint half angles: the shared bit-reproducible implementation (bioik_sincos.h)
 #define BIOIK_SINCOS_FN BIOIK_DEV
