@@ -90,9 +90,11 @@ BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o
 }
 // wave64 xor-butterfly: afterwards every lane holds the two best of the wavefront.  (A DPP reduction with row broadcasts and
 // scalar read-back was measured 30 % slower than ds_bpermute rounds on gfx950; the two steps inside a quad are DPP moves.)
-BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p) {
+// G: lanes of the group that is reduced (>= 64: the whole wavefront; 32: one half of it, the other half is the other species)
+BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p, int G) {
 #pragma unroll
-    for (int m = 32; m >= 16; m >>= 1) {  // across the four rows of 16 lanes: LDS-crossbar permutes
+    for (int m = 32; m >= 16; m >>= 1) {  // across the rows of 16 lanes: LDS-crossbar permutes
+        if (m >= G) continue;
         double o1f = p_shfl_xor(b1f, m), o2f = p_shfl_xor(b2f, m);
         int o1p = p_shfl_xor(b1p, m), o2p = p_shfl_xor(b2p, m);
         top2_merge(b1f, b1p, b2f, b2p, o1f, o1p, o2f, o2p);
@@ -381,7 +383,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
-                top2_wave(b1f, b1p, b2f, b2p);
+                top2_wave(b1f, b1p, b2f, b2p, G);
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 PHASE_MARK(PH_SEL_XWAVE);
@@ -397,8 +399,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 // the winners become the elites (written to the species' other buffer)
                 // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its op k (at most 32 ops)
                 double* nb = popS + (S.cur ^ 1) * BF;
-                if (gtid < 64) {
-                    const int i = gtid >> 5, k = gtid & 31;
+                for (int pass = 0; pass < (G >= 64 ? 1 : 2); pass++) {  // a half-wave group has 32 lanes: one winner per pass
+                    if (gtid >= 64) break;
+                    const int i = G >= 64 ? gtid >> 5 : pass, k = gtid & 31;
                     const int id = i == 0 ? first.id : second.id;
                     double* dst = nb + i * 2 * M;
                     if (id < 2) {
@@ -484,17 +487,27 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     // From here every lane of the leading wavefront carries the whole line search redundantly in its own
                     // genotype column (no hand-over through LDS, no rendezvous): L1 norm (:477-482), the two support points
                     // x-g (even lanes) / x+g (odd lanes) (:485-495), the step (:498-568), the clipped candidate and its fitness.
+                    double fnorm = 0.0, fl = 0.0;
                     if (live && glead) {
                         double sum = dp * dp;
                         for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
-                        const double fnorm = 1.0 / sum * dp;
+                        fnorm = 1.0 / sum * dp;
                         PHASE_MARK(PH_MEM_NORM);
                         const double sgn = (lane & 1) ? 1.0 : -1.0;
                         for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * (s_gop[k] * fnorm);
                         PHASE_MARK(PH_MEM_SUPPORT_COLS);
-                        double fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
+                        fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
                         PHASE_MARK(PH_MEM_SUPPORT_EVAL);
-                        const double f1 = p_shfl(fl, 0), f3 = p_shfl(fl, 1), f2 = fa;
+                    }
+                    // f(x-g) and f(x+g) sit in the group's first two lanes.  A half-wave group shares its wavefront with the other
+                    // species, which may have stopped descending: there every lane of the wavefront executes the shuffle.
+                    double f1 = 0.0, f3 = 0.0;
+                    if (G < 64 || (live && glead)) {
+                        const int lane0 = G < 64 ? (lane & ~(G - 1)) : 0;
+                        f1 = p_shfl(fl, lane0), f3 = p_shfl(fl, lane0 + 1);
+                    }
+                    if (live && glead) {
+                        const double f2 = fa;
                         double step_size;
                         if (sp.memetic == 'q') {  // :498-539
                             double v1 = f2 - f1, v2 = f3 - f2;
