@@ -70,6 +70,40 @@ __global__ void k_mulhi_ind4(double* out, unsigned long long* t, unsigned a) {
     out[threadIdx.x + blockIdx.x * blockDim.x] = x0 + x1 + x2 + x3;
     if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0, t[1] = c1 - c0;
 }
+// one Philox round both ways: 64-bit product as v_mad_u64_u32, or as v_mul_hi_u32 + v_mul_lo_u32
+__global__ void k_philox_mad64(double* out, unsigned long long* t, unsigned key) {
+    unsigned c0 = (unsigned)out[threadIdx.x] + threadIdx.x, c1 = c0 * 7u + 1u;
+    unsigned long long t0 = wall_clock64(), cc0 = __builtin_readcyclecounter();
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            unsigned long long p = (unsigned long long)0xD256D193u * (unsigned long long)c0;
+            unsigned hi = (unsigned)(p >> 32), lo = (unsigned)p;
+            c0 = hi ^ key ^ c1;
+            c1 = lo;
+        }
+    }
+    unsigned long long cc1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    out[threadIdx.x + blockIdx.x * blockDim.x] = c0 + c1;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0, t[1] = cc1 - cc0;
+}
+__global__ void k_philox_hilo(double* out, unsigned long long* t, unsigned key) {
+    unsigned c0 = (unsigned)out[threadIdx.x] + threadIdx.x, c1 = c0 * 7u + 1u;
+    unsigned long long t0 = wall_clock64(), cc0 = __builtin_readcyclecounter();
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            unsigned hi, lo;
+            asm volatile("v_mul_hi_u32 %0, %1, %2" : "=v"(hi) : "v"(c0), "v"(0xD256D193u));
+            asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(lo) : "v"(c0), "v"(0xD256D193u));
+            c0 = hi ^ key ^ c1;
+            c1 = lo;
+        }
+    }
+    unsigned long long cc1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    out[threadIdx.x + blockIdx.x * blockDim.x] = c0 + c1;
+    if (threadIdx.x == 0 && blockIdx.x == 0) t[0] = t1 - t0, t[1] = cc1 - cc0;
+}
 __global__ void k_lds_chase(double* out, unsigned long long* t) {
     __shared__ int next[1024];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) next[i] = (i * 17 + 64) & 1023;
@@ -151,6 +185,10 @@ int main() {
             if (rep) report("mulhi_dep", N * 16, b, th);
             hipLaunchKernelGGL(k_mulhi_ind4, dim3(b), dim3(th), 0, 0, out, t, 0xD256D193u);
             if (rep) report("mulhi_ind4", N * 16, b, th);
+            hipLaunchKernelGGL(k_philox_mad64, dim3(b), dim3(th), 0, 0, out, t, 0x9E3779B9u);
+            if (rep) report("philox_mad64", N * 16, b, th);
+            hipLaunchKernelGGL(k_philox_hilo, dim3(b), dim3(th), 0, 0, out, t, 0x9E3779B9u);
+            if (rep) report("philox_hilo", N * 16, b, th);
             hipLaunchKernelGGL(k_div_dep, dim3(b), dim3(th), 0, 0, out, t, 1.7);
             if (rep) report("div_dep", N * 16, b, th);
             hipLaunchKernelGGL(k_sqrt_dep, dim3(b), dim3(th), 0, 0, out, t, 1.7);
