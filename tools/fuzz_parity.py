@@ -1,0 +1,93 @@
+"""Randomised parity soak on a GPU box: many (fixture, population, mode, phenotype model, islands, mapping) combinations, whole solves
+compared bit for bit with the CPU oracle run on the same random streams.  Not part of the test suite (minutes of oracle time);
+prints one line per case and a summary, exit code 1 on any mismatch.  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, PositionGoal, ProblemTemplate, abi, pr2_like, snake  # noqa: E402
+from bio_ik_amd.solver import HipSolver  # noqa: E402
+from bio_ik_amd.workload import make_queries  # noqa: E402
+from conftest import mimic_robot, mobile_robot  # noqa: E402
+from oracle import orc  # noqa: E402
+
+
+def templates():
+    pr2 = pr2_like()
+    out = {
+        "c2": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")]),
+        "c2+pos": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), PositionGoal("r_elbow_flex_link", weight=0.1)]),
+        "c3": ProblemTemplate(pr2, "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]),
+        "c4": ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]),
+        "snake12": ProblemTemplate(snake(12), "snake", [PoseGoal("tip")]),
+        "mimic": ProblemTemplate(mimic_robot(), "arm", [PoseGoal("tool"), MinimalDisplacementGoal(weight=0.5)]),
+        "floating": ProblemTemplate(mobile_robot("floating"), "whole", [PoseGoal("tool"), PositionGoal("base", weight=0.2)]),
+        "planar": ProblemTemplate(mobile_robot("planar"), "whole", [PoseGoal("tool"), PositionGoal("base", weight=0.2)]),
+    }
+    return out
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    orc.set_trig_mode(1)
+    T = templates()
+    H = {k: HipSolver(t, device=0) for k, t in T.items()}
+    O = {k: orc.Oracle(t) for k, t in T.items()}
+    bad = 0
+    t_start = time.time()
+    for case in range(n_cases):
+        name = rng.choice(list(T))
+        t, h, o = T[name], H[name], O[name]
+        pop = int(rng.choice([8, 16, 24, 33, 64, 70, 128, 200]))
+        mode = str(rng.choice(["bio2", "bio2_memetic", "bio2_memetic_l"]))
+        fk = int(rng.choice([abi.FK_EXACT, abi.FK_LINEAR]))
+        if name in ("floating", "planar") and mode != "bio2":
+            mode = "bio2"  # their Jacobian columns go through acos / sqrt of two different math libraries: bit-exact only without them
+            fk = abi.FK_EXACT
+        islands = int(rng.choice([1, 1, 2, 3]))
+        steps = int(rng.choice([1, 2, 5, 9]))
+        n = int(rng.choice([3, 17, 40]))
+        env = {}
+        r = rng.random()
+        if r < 0.15:
+            env = {"BIOIK_SOLVE_THREADS": "64"}
+        elif r < 0.3:
+            env = {"BIOIK_SOLVE_THREADS": "128"}
+        elif r < 0.4:
+            env = {"BIOIK_SOLVE_THREADS": "256"}
+        elif r < 0.5:
+            env = {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1"}
+        elif r < 0.6:
+            env = {"BIOIK_SOLVE_GENERAL": "1"}
+        if rng.random() < 0.2:
+            env["BIOIK_SOLVE_STORE_CHILDREN"] = "0"
+        kw = {"no_wipeout": int(rng.random() < 0.2)}
+        seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=int(rng.integers(1 << 30)), kind=str(rng.choice(["global", "tracking"])))
+        p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=int(rng.integers(1 << 30)), mode=mode, fk_mode=fk, islands=islands, **kw)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            sb = h.solve_batch(p, seeds, params)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        sa = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=8)
+        ok = np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1]) and np.array_equal(sa[2], sb[2]) and np.array_equal(sa[3], sb[3])
+        bad += 0 if ok else 1
+        print("%-3d %-9s pop=%-3d %-15s fk=%d islands=%d steps=%d n=%-2d %-60s %s" %
+              (case, name, pop, mode, fk, islands, steps, n, str(env), "ok" if ok else "MISMATCH max|dx|=%g" % np.abs(sa[0] - sb[0]).max()), flush=True)
+    print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
