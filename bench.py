@@ -19,6 +19,8 @@ Extra objects on the JSON line:
   cpu_baseline the reference's own CPU code (oracle/_ref: the reference sources compiled unmodified, Release flags) when the
                prebuilt library is present, else the oracle port; timed on this host, rank 0, N=1 only, one thread, on a
                bounded sample of the same queries.  The port at the GPU run's own parameters is reported beside it.
+  reference_parameters  the GPU on the same queries at the reference's own parameters (its population, its linearised
+               phenotypes): the like-for-like figure next to cpu_baseline.value.
 """
 import argparse
 import json
@@ -227,6 +229,26 @@ def main():
                                      "results_identical_to_device_entry": bool(np.array_equal(hs[0], sol) and np.array_equal(hs[2], suc)),
                                      "note": "bioik_solve_batch: host arrays in and out (PCIe-inclusive), one launch at a time; never `value`"}
 
+    if rank == 0 and world == 1 and not args.timed_only:
+        # The same queries at the REFERENCE'S OWN parameters (2 species x (2 elites + 16 children), linearised phenotypes, budget
+        # 512 steps as in the cpu_baseline leg): the like-for-like figure next to cpu_baseline.value; never `value`.
+        pr = abi.default_solve_params(population=16, max_steps=512, random_seed=1, fk_mode=abi.FK_LINEAR)
+        for i in range(2):
+            o = bufs[i % nfl]
+            h.solve_batch_device(pr, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+        torch.cuda.synchronize(dev)
+        kr = 8
+        t1 = time.perf_counter()
+        for i in range(kr):
+            o = bufs[i % nfl]
+            h.solve_batch_device(pr, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+        torch.cuda.synchronize(dev)
+        dtr = (time.perf_counter() - t1) / kr
+        rsuc = bufs[0][2].cpu().numpy()
+        out["reference_parameters"] = {"value": float(rsuc.sum()) / dtr, "unit": "solves/s", "ms_per_step": dtr * 1e3, "success_rate": float(rsuc.mean()),
+                                       "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "population": 16, "fk": "linear", "max_steps": 512,
+                                       "batches_in_flight": nfl}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle import orc, ref
         ns = min(args.cpu_sample, BATCH)
@@ -264,6 +286,8 @@ def main():
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"] if cb["value"] > 0 else None
         out["speedup_vs_port_same_parameters_1thread"] = out["value"] / port["value"] if port["value"] > 0 else None
+        if "reference_parameters" in out and cb.get("kind") == "reference" and cb["value"] > 0:
+            out["speedup_at_reference_parameters_vs_cpu_1thread"] = out["reference_parameters"]["value"] / cb["value"]
 
     if rank == 0:
         print(json.dumps(out))
