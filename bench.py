@@ -147,6 +147,7 @@ def main():
     ok_idx = np.nonzero(suc)[0][:256]
     tips = np.stack([h.fk_genes(sol[i], sol[i][h.active_variables][None, :])[0] for i in ok_idx]) if len(ok_idx) else np.zeros((0, T, 7))
     pos_err = float(np.linalg.norm(tips[:, 0, :3] - params[ok_idx, :3], axis=1).max()) if len(ok_idx) else 0.0
+    rot_err = float((2.0 * np.arccos(np.minimum(1.0, np.abs(np.einsum("ij,ij->i", tips[:, 0, 3:], params[ok_idx, 3:7]))))).max()) if len(ok_idx) else 0.0
 
     # algorithmic bytes of one launch
     gens_per_step = 2 * (8 if p.mode != abi.MODE_BIO2 else 16)
@@ -181,6 +182,7 @@ def main():
         "success_rate": float(suc.mean()),
         "mean_steps_per_solve": float(steps_q.mean()),
         "max_pos_err_m_of_successes": pos_err,
+        "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "kernel": "k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6); "
