@@ -287,8 +287,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
         // (small populations, <= 32 children per species: +65..80 % measured, tools/halfwave_sweep.sh; at 64 and more children
         // per species the sequential single wavefront or the two-wavefront mapping is as good or better)
-        sp.species_parallel = (nth % 128 == 0 || (nth == 64 && sp.lambda <= 32)) ? 1 : 0;
-        if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && (nth % 128 == 0 || nth == 64)) ? 1 : 0;
+        sp.species_parallel = (nth % 128 == 0 || (nth == 64 && sp.lambda <= 32 && dp.D < 32)) ? 1 : 0;  // (the memetic phase wants lane D of a group)
+        if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && (nth % 128 == 0 || (nth == 64 && dp.D < 32))) ? 1 : 0;
         const int groups_m = sp.species_parallel ? 2 : 1, G_m = nth / groups_m;
         sp.child_cols = (sp.lambda + G_m - 1) / G_m;
         if (quat) {

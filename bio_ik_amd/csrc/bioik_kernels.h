@@ -457,30 +457,39 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 group_sync(G);
                 const double* cand = (lds + L.xcol) + grp * G;  // the line-search candidate: column of the group's lane 0
                 bool live = true;  // still descending; the leading wavefront of the group does the arithmetic
+                const int lane0 = G < 64 ? (lane & ~(G - 1)) : 0;  // first lane of the group inside its wavefront
                 for (int it = 0; it < 8; it++) {
                     double f2p = 0.0, fa = 0.0;
                     if (live) PHASE_COUNT(PH_N_MEM_ITER);
+                    // One evaluation per lane: lane i < D scores the elite with gene i advanced by dp (computeApproximateMutation1 on the
+                    // tip frames), every other lane the elite itself (its column is the unperturbed elite, its delta zero); the base
+                    // values are then taken from lane D of the group.
+                    double vprim = 0.0, vall = 0.0;
                     if (live && glead) {
                         for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
-                        double fbp = 0.0;
+                        double acc = 0.0;
                         for (int t = 0; t < T; t++) {
-                            F7 f = linear_tip(pb, t, xe, lm);
-                            f2p += tip_goals(pb, t, f, xe, qc);
+                            const F7 f = linear_tip(pb, t, xe, lm);
+                            double d[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                             if (my_op >= 0) {
-                                const double* d = s_delta + ((size_t)t * n_ops + my_op) * 7;  // computeApproximateMutation1
-                                F7 f3 = F7{{BK_FMA(d[0], dp, f.p.x), BK_FMA(d[1], dp, f.p.y), BK_FMA(d[2], dp, f.p.z)},
-                                           {BK_FMA(d[3], dp, f.q.x), BK_FMA(d[4], dp, f.q.y), BK_FMA(d[5], dp, f.q.z), BK_FMA(d[6], dp, f.q.w)}};
-                                fbp += tip_goals(pb, t, f3, xl, qc);
+                                const double* dl = s_delta + ((size_t)t * n_ops + my_op) * 7;
+                                for (int c = 0; c < 7; c++) d[c] = dl[c];
                             }
+                            const F7 f3 = F7{{BK_FMA(d[0], dp, f.p.x), BK_FMA(d[1], dp, f.p.y), BK_FMA(d[2], dp, f.p.z)},
+                                             {BK_FMA(d[3], dp, f.q.x), BK_FMA(d[4], dp, f.q.y), BK_FMA(d[5], dp, f.q.z), BK_FMA(d[6], dp, f.q.w)}};
+                            acc += tip_goals(pb, t, f3, xl, qc);
                         }
-                        f2p += nonlink_primary(pb, xe, qc);
-                        fa = f2p + secondary_fitness(pb, xe, qc);
-                        if (my_op >= 0) {
-                            fbp += nonlink_primary(pb, xl, qc);
-                            double fb = fbp + secondary_fitness(pb, xl, qc);
-                            s_grad[gtid] = fb - fa;
-                            s_gop[my_op] = fb - fa;
-                        }
+                        acc += nonlink_primary(pb, xl, qc);
+                        vprim = acc;
+                        vall = acc + secondary_fitness(pb, xl, qc);
+                    }
+                    if (G < 64 || (live && glead)) {  // (a half-wave group shares its wavefront: every lane executes the shuffle)
+                        f2p = p_shfl(vprim, lane0 + D);
+                        fa = p_shfl(vall, lane0 + D);
+                    }
+                    if (live && glead && my_op >= 0) {
+                        s_grad[gtid] = vall - fa;
+                        s_gop[my_op] = vall - fa;
                     }
                     group_sync(G);
                     PHASE_MARK(PH_MEM_GRAD);
@@ -502,10 +511,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     // f(x-g) and f(x+g) sit in the group's first two lanes.  A half-wave group shares its wavefront with the other
                     // species, which may have stopped descending: there every lane of the wavefront executes the shuffle.
                     double f1 = 0.0, f3 = 0.0;
-                    if (G < 64 || (live && glead)) {
-                        const int lane0 = G < 64 ? (lane & ~(G - 1)) : 0;
-                        f1 = p_shfl(fl, lane0), f3 = p_shfl(fl, lane0 + 1);
-                    }
+                    if (G < 64 || (live && glead)) f1 = p_shfl(fl, lane0), f3 = p_shfl(fl, lane0 + 1);
                     if (live && glead) {
                         const double f2 = fa;
                         double step_size;
