@@ -15,7 +15,7 @@ for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_col
     for k, v in agg.items():
         out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "min": min(v), "max": max(v)}
 fk, wk = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
-summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 1 "
+summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --timed-only --steps 5 --warmup 1 "
                       "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)", "kernel": "k_solve_lean(SolveArgs)", "counters": out,
            "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
                                     "total_corrected": 2 * fk * 1024 + wk * 1024,
