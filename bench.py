@@ -181,7 +181,7 @@ def main():
                    "batches_in_flight": nfl},
         "success_rate": float(suc.mean()),
         "mean_steps_per_solve": float(steps_q.mean()),
-        "child_evaluations_per_s": generations * POP * args.steps / elapsed if elapsed > 0 else 0.0,  # exact-FK fitness evaluations of children
+        "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
         "max_pos_err_m_of_successes": pos_err,
         "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
