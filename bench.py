@@ -6,9 +6,10 @@ right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), 
 `value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
 GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
-Consecutive steps are issued round-robin on two HIP streams (`--in-flight`, config.batches_in_flight): the tail of one
-launch — a handful of queries that use the whole step budget — overlaps the bulk of the next; `one_batch_at_a_time` holds
-the same measurement with strictly one launch after the other.
+Consecutive steps are issued round-robin on three HIP streams (`--in-flight`, config.batches_in_flight): the tail of one
+launch — a handful of queries that use the whole step budget, 64 sequential steps wherever they start — overlaps the bulk
+of the next ones; `one_batch_at_a_time` holds the same measurement with strictly one launch after the other
+(profiles/r01_inflight_sweep.log: 1 / 2 / 3 in flight).
 
 Extra objects on the JSON line:
   roofline     dominant kernel k_solve against the HBM roofline: ALGORITHMIC bytes per launch (SURVEY.md §8d,
@@ -42,14 +43,14 @@ HBM_PEAK = 8.0e12
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the warm-up and the K timed steps (no one-at-a-time leg, no secondary measurements): what the rocprofv3 kernel "
                          "statistics in profiles/ are taken over, so that their average duration is that of the timed launches")
     ap.add_argument("--cpu-sample", type=int, default=2048)
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "2")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "3")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other)")
     args = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
     d_params = torch.from_numpy(params).to(dev)
     # Consecutive steps go round-robin to `in_flight` HIP streams with their own result buffers: a launch of 4096 queries
     # ends with a long tail (the few queries that use the whole step budget run ~13 ms each) during
-    # which the chip is nearly empty; with two launches in flight the next batch's bulk fills it.  Every step is a complete
+    # which the chip is nearly empty; with more launches in flight the next batches' bulk fills it.  Every step is a complete
     # pass of the hot path over one batch and every batch's results are complete when the timed region ends.
     nfl = max(1, args.in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
