@@ -75,7 +75,8 @@ BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p
 // post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
 enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4 };
-#define RNG_SLOT_RATE 255u
+// random words of child c in one generation: word w = output (w & 1) of Philox(key, ctr0(c, w >> 1), ctr1);
+// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g (two genes per Philox call)
 
 BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
 #pragma unroll
@@ -91,12 +92,13 @@ BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o
 }
 BIOIK_DEV uint32_t rng_ctr0(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
 BIOIK_DEV uint32_t rng_ctr1(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
-// ~N(0,1): Binomial(32,1/2) lattice + triangular jitter
-BIOIK_DEV double rng_gauss(uint32_t x0, uint32_t x1) {
-    int k = p_popc(x0) - 16;
-    uint32_t s = (x1 & 0xffffu) + (x1 >> 16);
-    double t = (double)s * (1.0 / 65536.0) - 1.0;
-    return ((double)k + t) * 0.3499271061118826;
+// ~N(0,1) from ONE 32-bit word: Binomial(16,1/2) lattice (popcount of the low half) + triangular jitter (sum of the two
+// high bytes) -> continuous piecewise-linear density, integer-only up to one exact conversion and one rounding
+BIOIK_DEV double rng_gauss32(uint32_t x) {
+    int k = p_popc(x & 0xffffu) - 8;
+    uint32_t s = ((x >> 16) & 0xffu) + (x >> 24);
+    double t = (double)s * (1.0 / 256.0) - 1.0;
+    return ((double)k + t) * 0.4898979485566356;  // 1 / sqrt(4 + 1/6)
 }
 BIOIK_DEV double rng_uniform(uint32_t x0, uint32_t x1) {
     uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;
@@ -800,83 +802,8 @@ BIOIK_DEV void renormalize_quaternion_genes(ProbPtr pb, double* xo, int xs) {
     }
 }
 
-// four independent Philox2x32-10 streams advanced in lock step: the ten rounds of one stream are a dependent chain of
-// 32x32->64 multiplies, so interleaving four of them gives the in-order wavefront something to issue every cycle
-BIOIK_DEV void philox2x32_10_x4(uint32_t key, const uint32_t (&c0in)[4], uint32_t c1in, uint32_t (&o0)[4], uint32_t (&o1)[4]) {
-    uint32_t c0[4], c1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) c0[j] = c0in[j], c1[j] = c1in;
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        if (r > 0) key += 0x9E3779B9u;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint64_t p = (uint64_t)0xD256D193u * (uint64_t)c0[j];
-            uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
-            c0[j] = hi ^ key ^ c1[j];
-            c1[j] = lo;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) o0[j] = c0[j], o1[j] = c1[j];
-}
-
-template <class PB>
-BIOIK_DEV void reproduce_child(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
-                               double* xo, int xs, double* go, int gs) {
-    BIOIK_FP_STRICT
-    const int n_ops = pb->n_ops, D = pb->D;
-    const double fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
-    const double gradient_factor = (double)(child_index % 3u);
-    uint32_t r0, r1;
-    philox2x32_10(key, rng_ctr0(child_index, RNG_SLOT_RATE), ctr1, r0, r1);
-    const double mutation_rate = (double)(1u << (r0 & 15u)) * (1.0 / (double)(1 << 23));
-    // genes in blocks of four: four random streams and four gene updates per trip, free of branches so that the
-    // scheduler can interleave them (a padding gene past D recomputes gene D-1 and is not stored)
-    for (int g0 = 0; g0 < D; g0 += 4) {
-        uint32_t c0[4], q0[4], q1[4];
-        int kk[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int g = g0 + j < D ? g0 + j : D - 1;
-            kk[j] = pb->op_of_gene[g];
-            c0[j] = rng_ctr0(child_index, (uint32_t)g);
-        }
-        philox2x32_10_x4(key, c0, ctr1, q0, q1);
-        double gene[4], mom[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = kk[j];
-            double r = rng_gauss(q0[j], q1[j]);
-            double f = mutation_rate * pb->ops[k].span;
-            double parent_gene = p0g[k];
-            double gn = parent_gene;
-            gn += r * f;
-            double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
-            double g2 = parent_gradient * gradient_factor;
-            gn += g2;
-            gn = fmin(fmax(gn, pb->ops[k].clip_min), pb->ops[k].clip_max);
-            gene[j] = gn;
-            mom[j] = parent_gradient * (1.0 - 0.3) + (gn - parent_gene) * 0.3;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (g0 + j < D) {
-                xo[(size_t)kk[j] * xs] = gene[j];
-                if (go) go[(size_t)kk[j] * gs] = mom[j];
-            }
-    }
-    if (D < n_ops)
-        for (int k = 0; k < n_ops; k++)
-            if (pb->ops[k].gene < 0) {
-                xo[(size_t)k * xs] = p0g[k];  // inactive op: the seed's value, carried by every elite
-                if (go) go[(size_t)k * gs] = 0.0;
-            }
-    if constexpr (pb_flavour<PB>::general) renormalize_quaternion_genes(pb, xo, xs);
-}
-
-// N children of one lane at once (same parents, same generation): N x 4 interleaved random streams per trip and the
-// parents' genes / momentum and the joint limits loaded once.  Per child the arithmetic of reproduce_child.
+// M independent Philox2x32-10 streams advanced in lock step: the ten rounds of one stream are a dependent chain of
+// 32x32->64 multiplies, so interleaving several of them gives the in-order wavefront something to issue every cycle
 template <int M>
 BIOIK_DEV void philox2x32_10_xm(uint32_t key, const uint32_t (&c0in)[M], uint32_t c1in, uint32_t (&o0)[M], uint32_t (&o1)[M]) {
     uint32_t c0[M], c1[M];
@@ -896,60 +823,74 @@ BIOIK_DEV void philox2x32_10_xm(uint32_t key, const uint32_t (&c0in)[M], uint32_
 #pragma unroll
     for (int j = 0; j < M; j++) o0[j] = c0[j], o1[j] = c1[j];
 }
+
+// Reproduction (ik_evolution_2.cpp:242-326) of N children of one lane at once (same parents, same generation): per trip
+// 4 x N interleaved Philox streams = 8 random words per child (the rate exponent + 7 genes in the first trip, 8 genes in
+// the following ones), the parents' genes / momentum and the joint limits loaded once per gene for all N.  Free of
+// divergent branches (padding words past the last gene recompute gene D-1 and are not stored).  `go` (optional): momentum
+// of child 0 (:299).
 template <int N, class PB>
 BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint32_t (&child_index)[N], const double* p0g, const double* p0d,
-                                  const double* p1d, double* const (&xo)[N], int xs) {
+                                  const double* p1d, double* const (&xo)[N], int xs, double* go = nullptr, int gs = 0) {
     BIOIK_FP_STRICT
     const int n_ops = pb->n_ops, D = pb->D;
     double fmix[N], gradient_factor[N], mutation_rate[N];
-    {
-        uint32_t c0[N], r0[N], r1[N];
 #pragma unroll
-        for (int i = 0; i < N; i++) c0[i] = rng_ctr0(child_index[i], RNG_SLOT_RATE);
-        philox2x32_10_xm<N>(key, c0, ctr1, r0, r1);
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            fmix[i] = (child_index[i] % 2u == 0u) ? 0.2 : 0.0;
-            gradient_factor[i] = (double)(child_index[i] % 3u);
-            mutation_rate[i] = (double)(1u << (r0[i] & 15u)) * (1.0 / (double)(1 << 23));
-        }
+    for (int i = 0; i < N; i++) {
+        fmix[i] = (child_index[i] % 2u == 0u) ? 0.2 : 0.0;
+        gradient_factor[i] = (double)(child_index[i] % 3u);
+        mutation_rate[i] = 0.0;
     }
-    for (int g0 = 0; g0 < D; g0 += 4) {
+    for (int w0 = 0; w0 <= D; w0 += 8) {
         uint32_t c0[4 * N], q0[4 * N], q1[4 * N];
-        int kk[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int g = g0 + j < D ? g0 + j : D - 1;
-            kk[j] = pb->op_of_gene[g];
 #pragma unroll
-            for (int i = 0; i < N; i++) c0[i * 4 + j] = rng_ctr0(child_index[i], (uint32_t)g);
+            for (int i = 0; i < N; i++) c0[i * 4 + j] = rng_ctr0(child_index[i], (uint32_t)((w0 >> 1) + j));
         }
         philox2x32_10_xm<4 * N>(key, c0, ctr1, q0, q1);
-        double gene[N][4];
+        if (w0 == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = kk[j];
-            const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
-            const double parent_gene = p0g[k], d0 = p0d[k], d1 = p1d[k];
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                double r = rng_gauss(q0[i * 4 + j], q1[i * 4 + j]);
-                double f = mutation_rate[i] * span;
-                double gn = parent_gene;
-                gn += r * f;
-                double parent_gradient = d0 * (1.0 - fmix[i]) + d1 * fmix[i];
-                double g2 = parent_gradient * gradient_factor[i];
-                gn += g2;
-                gn = fmin(fmax(gn, cmin), cmax);
-                gene[i][j] = gn;
-            }
+            for (int i = 0; i < N; i++) mutation_rate[i] = (double)(1u << (q0[i * 4] & 15u)) * (1.0 / (double)(1 << 23));
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (g0 + j < D) {
+        for (int h = 0; h < 2; h++) {
+            if (w0 + 4 * h > D) break;  // no gene in this half
+            int kk[4];
+            double gene[N][4], mom[4];
 #pragma unroll
-                for (int i = 0; i < N; i++) xo[i][(size_t)kk[j] * xs] = gene[i][j];
+            for (int j = 0; j < 4; j++) {
+                const int w = 4 * h + j;  // word of this trip; its gene is w0 + w - 1
+                const int g = w0 + w - 1 < 0 ? 0 : (w0 + w - 1 < D ? w0 + w - 1 : D - 1);
+                const int k = pb->op_of_gene[g];
+                kk[j] = k;
+                const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
+                const double parent_gene = p0g[k], d0 = p0d[k], d1 = p1d[k];
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const uint32_t word = (w & 1) ? q1[i * 4 + (w >> 1)] : q0[i * 4 + (w >> 1)];
+                    double r = rng_gauss32(word);
+                    double f = mutation_rate[i] * span;
+                    double gn = parent_gene;
+                    gn += r * f;
+                    double parent_gradient = d0 * (1.0 - fmix[i]) + d1 * fmix[i];
+                    double g2 = parent_gradient * gradient_factor[i];
+                    gn += g2;
+                    gn = fmin(fmax(gn, cmin), cmax);
+                    gene[i][j] = gn;
+                    if (i == 0) mom[j] = parent_gradient * (1.0 - 0.3) + (gn - parent_gene) * 0.3;
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int g = w0 + 4 * h + j - 1;
+                if (g >= 0 && g < D) {
+#pragma unroll
+                    for (int i = 0; i < N; i++) xo[i][(size_t)kk[j] * xs] = gene[i][j];
+                    if (go) go[(size_t)kk[j] * gs] = mom[j];
+                }
+            }
+        }
     }
     if (D < n_ops)
         for (int k = 0; k < n_ops; k++)
@@ -957,9 +898,17 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
                 const double v = p0g[k];  // inactive op: the seed's value, carried by every elite
 #pragma unroll
                 for (int i = 0; i < N; i++) xo[i][(size_t)k * xs] = v;
+                if (go) go[(size_t)k * gs] = 0.0;
             }
     if constexpr (pb_flavour<PB>::general)
         for (int i = 0; i < N; i++) renormalize_quaternion_genes(pb, xo[i], xs);
+}
+template <class PB>
+BIOIK_DEV void reproduce_child(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
+                               double* xo, int xs, double* go, int gs) {
+    const uint32_t ci[1] = {child_index};
+    double* const xc[1] = {xo};
+    reproduce_children<1>(pb, key, ctr1, ci, p0g, p0d, p1d, xc, xs, go, gs);
 }
 
 // ---------------------------------------------------------------------------------------------------------

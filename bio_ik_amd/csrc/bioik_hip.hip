@@ -235,6 +235,9 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 
+#ifndef BIOIK_SOLVE_WAVES_PER_SIMD
+#define BIOIK_SOLVE_WAVES_PER_SIMD 3  // register budget of k_solve: wavefronts per SIMD (its __launch_bounds__)
+#endif
 static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1) {
     const DevProblem& d = p->host.dev;
     return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0, child_cols, groups, slot_sets).total * 8;
@@ -261,6 +264,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             int nth, store, pairs;
         };
         const Cand cands[] = {{128, 1, 1}, {128, 1, 0}, {128, 0, 0}, {64, 0, 0}};
+        const int kCuWaves = 4 * BIOIK_SOLVE_WAVES_PER_SIMD;  // wavefronts a CU holds at this kernel's register budget
         int best = -1, best_waves = -1;
         for (int i = 0; i < 4; i++) {
             const Cand& c = cands[i];
@@ -272,9 +276,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1);
             if (bytes > 160 * 1024) continue;
             int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
-            if (waves > 12) waves = 12;
+            if (waves > kCuWaves) waves = kCuWaves;
             // full CU: first (richest) candidate wins; LDS-limited: a later (leaner) candidate wins ties
-            if (waves > best_waves || (waves == best_waves && waves < 12)) best = i, best_waves = waves;
+            if (waves > best_waves || (waves == best_waves && waves < kCuWaves)) best = i, best_waves = waves;
         }
         if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
         nth = cands[best].nth;

@@ -39,7 +39,7 @@ def lib(kind="strict"):
         L.orc_solver_create.restype = C.c_void_p
         L.orc_solver_create.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_int, C.c_uint32, _pd, _pd]
         L.orc_solver_destroy.argtypes = [C.c_void_p]
-        L.orc_counter_gauss.restype = C.c_double
+        L.orc_counter_gauss32.restype = C.c_double
         L.orc_counter_uniform.restype = C.c_double
         L.orc_query_key.restype = C.c_uint32
         L.orc_query_key.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
@@ -327,8 +327,16 @@ def philox4x32(key2, ctr4, kind="strict"):
     return [int(x) for x in out]
 
 
-def counter_gauss(key, c0, c1, kind="strict"):
-    return lib(kind).orc_counter_gauss(C.c_uint32(key), C.c_uint32(c0), C.c_uint32(c1))
+def counter_gauss32(word, kind="strict"):
+    """the Gaussian the solver derives from one 32-bit random word"""
+    return lib(kind).orc_counter_gauss32(C.c_uint32(word))
+
+
+def counter_child_gauss(key, child, gene, ctr1, kind="strict"):
+    """Gaussian of gene `gene` of child `child`: random word 1 + gene of the child's stream (word w = output w & 1 of
+    Philox(key, child << 8 | w >> 1, ctr1); word 0 is the mutation-rate exponent)"""
+    w = gene + 1
+    return counter_gauss32(philox2x32(key, (child << 8) | (w >> 1), ctr1, kind)[w & 1], kind)
 
 
 def counter_uniform(key, c0, c1, kind="strict"):

@@ -57,17 +57,19 @@ inline void philox4x32_10(const uint32_t* key2, const uint32_t* ctr4, uint32_t* 
 
 // counter layout and integer->double post-processing
 enum { PURPOSE_REPRODUCE = 0, PURPOSE_PRESELECT = 1, PURPOSE_MEMETIC_SIGN = 2, PURPOSE_WIPEOUT = 3, PURPOSE_WIPEOUT_GENE = 4 };
-constexpr uint32_t SLOT_RATE = 255;
+// random words of child c in one generation: word w = output (w & 1) of Philox(key, ctr0(c, w >> 1), ctr1);
+// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g (two genes per Philox call)
 
 inline uint32_t ctr0_of(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
 inline uint32_t ctr1_of(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
 
-// approximately N(0,1): Binomial(32,1/2) lattice + triangular jitter on [-1,1) -> continuous piecewise-linear density
-inline double counter_gauss_from(uint32_t x0, uint32_t x1) {
-    int k = __builtin_popcount(x0) - 16;
-    uint32_t s = (x1 & 0xffffu) + (x1 >> 16);
-    double t = (double)s * (1.0 / 65536.0) - 1.0;
-    return ((double)k + t) * 0.3499271061118826;  // 1/sqrt(8 + 1/6)
+// approximately N(0,1) from ONE 32-bit word: Binomial(16,1/2) lattice (popcount of the low half) + triangular jitter on
+// [-1,1) (sum of the two high bytes) -> continuous piecewise-linear density
+inline double counter_gauss_from32(uint32_t x) {
+    int k = __builtin_popcount(x & 0xffffu) - 8;
+    uint32_t s = ((x >> 16) & 0xffu) + (x >> 24);
+    double t = (double)s * (1.0 / 256.0) - 1.0;
+    return ((double)k + t) * 0.4898979485566356;  // 1/sqrt(4 + 1/6)
 }
 inline double counter_uniform_from(uint32_t x0, uint32_t x1) {
     uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;
@@ -90,16 +92,13 @@ struct CounterRandom {
         species = species_id;
     }
     void reproduce_begin(size_t /*n_total*/, size_t /*gene_count*/) {}
-    unsigned rate_exponent(size_t child_index) {
+    uint32_t child_word(size_t child_index, uint32_t w) {
         uint32_t o[2];
-        philox2x32_10(key, ctr0_of((uint32_t)child_index, SLOT_RATE), ctr1_of(generation, species, PURPOSE_REPRODUCE), o);
-        return o[0] & 15u;
+        philox2x32_10(key, ctr0_of((uint32_t)child_index, w >> 1), ctr1_of(generation, species, PURPOSE_REPRODUCE), o);
+        return o[w & 1u];
     }
-    double gauss(size_t child_index, size_t gene) {
-        uint32_t o[2];
-        philox2x32_10(key, ctr0_of((uint32_t)child_index, (uint32_t)gene), ctr1_of(generation, species, PURPOSE_REPRODUCE), o);
-        return counter_gauss_from(o[0], o[1]);
-    }
+    unsigned rate_exponent(size_t child_index) { return child_word(child_index, 0) & 15u; }
+    double gauss(size_t child_index, size_t gene) { return counter_gauss_from32(child_word(child_index, (uint32_t)gene + 1u)); }
     void child_end(size_t /*gene_count*/) {}
     size_t preselect_count(size_t mu_, size_t lambda) {  // in [mu+1, mu+lambda-1]
         uint32_t o[2];

@@ -19,14 +19,15 @@ def test_counter_gauss_and_uniform_definition():
     # integer-only post-processing, reproduced here with Python integers
     for key, c0, c1 in [(1, 2, 3), (0xdeadbeef, (77 << 8) | 5, (1234 << 4) | 8), (42, 0, 0)]:
         x0, x1 = orc.philox2x32(key, c0, c1)
-        k = bin(x0).count("1") - 16
-        t = ((x1 & 0xffff) + (x1 >> 16)) / 65536.0 - 1.0
-        assert orc.counter_gauss(key, c0, c1) == (k + t) * 0.3499271061118826
+        for x in (x0, x1, 0, 0xffffffff, 0x0000ffff, 0xffff0000):
+            k = bin(x & 0xffff).count("1") - 8
+            t = (((x >> 16) & 0xff) + (x >> 24)) / 256.0 - 1.0
+            assert orc.counter_gauss32(x) == (k + t) * 0.4898979485566356
         assert orc.counter_uniform(key, c0, c1) == (((x0 << 32) | x1) >> 11) * 2.0 ** -53
 
 
 def test_counter_gauss_moments():
-    z = np.array([orc.counter_gauss(7, (c << 8) | g, 5 << 4) for c in range(2000) for g in range(10)])
+    z = np.array([orc.counter_child_gauss(7, c, g, 5 << 4) for c in range(2000) for g in range(10)])
     assert abs(z.mean()) < 0.03
     assert abs(z.var() - 1.0) < 0.03
     assert abs(np.mean(z ** 3)) < 0.1

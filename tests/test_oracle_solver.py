@@ -21,12 +21,12 @@ def test_reproduce_matches_formula(oracles, templates):
     genes, grads = o.reproduce_counter(lam, key, sp, gen, parents)
     c1 = (gen << 4) | (sp << 3) | 0
     for c in range(2, 2 + lam):
-        k = orc.philox2x32(key, (c << 8) | 255, c1)[0] & 15
+        k = orc.philox2x32(key, c << 8, c1)[0] & 15  # random word 0 of the child
         rate = (1 << k) * (1.0 / (1 << 23))
         fmix = 0.2 if c % 2 == 0 else 0.0
         gf = float(c % 3)
         for g in range(D):
-            z = orc.counter_gauss(key, (c << 8) | g, c1)
+            z = orc.counter_child_gauss(key, c, g, c1)  # random word 1 + g
             m = parents[0, 1, g] * (1.0 - fmix) + parents[1, 1, g] * fmix
             x = parents[0, 0, g] + z * (rate * info[g, 2])
             x = x + m * gf
