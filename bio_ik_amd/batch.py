@@ -4,10 +4,15 @@ src/ik_parallel.h:220-269), so the batch is split into contiguous shards with NO
 below only move the queries out and the results back when they originate on one rank:
 
     rank 0:  seeds [n][V], goal_params [n][P]  --scatter-->  shard r = [r*n/W, (r+1)*n/W)
-    rank r:  bioik_problem_set_first_query(shard begin); bioik_solve_batch(shard)      (no communication)
+    rank r:  bioik_problem_set_first_query(shard begin); bioik_solve_batch[_device](shard)      (no communication)
     rank 0:  <--gather--  solutions [n][V], fitness, success, steps
 
-Because the RNG stream of a query is keyed by its GLOBAL index, the sharded result is bit-identical to the unsharded one."""
+Because the RNG stream of a query is keyed by its GLOBAL index, the sharded result is bit-identical to the unsharded one.
+With the exchange buffers on a GPU (nccl) the shard never leaves HBM: the scattered rows are split into the seed / goal
+arrays on the device, `bioik_solve_batch_device` runs on a HIP stream of its own, and the result rows are packed on the
+device for the gather.  A MIXED batch (BASELINE.json configs[4]: PR2 and snake queries) is sorted by model into homogeneous
+blocks (one problem handle each, every workgroup of a launch runs the same joint program); `solve_mixed` shards every block
+over all ranks, so each GPU holds the same mix, and runs a rank's blocks concurrently on separate streams."""
 import numpy as np
 
 
@@ -15,14 +20,15 @@ def shard_bounds(n, world):
     return [(r * n) // world for r in range(world + 1)]
 
 
-def solve_sharded(solver, params, seeds=None, goal_params=None, n=None, device=None, group=None):
-    """Collective call.  `seeds`/`goal_params` are needed on rank 0 only (NumPy, host); every rank passes its own
-    `solver` (a HipSolver on its GPU) and the same `params`.  Returns (solutions, fitness, success, steps) on rank 0,
-    None elsewhere.  `device` = torch device used for the exchange buffers (cuda:<local rank> with nccl, cpu with gloo)."""
+class _Shard:
+    """One block's exchange state on one rank."""
+    pass
+
+
+def _scatter(solver, seeds, goal_params, dev, group):
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    dev = torch.device(device) if device is not None else torch.device("cpu")
     V, P = solver.V, max(solver.P, 1)
     meta = torch.zeros(1, dtype=torch.int64, device=dev)
     if rank == 0:
@@ -31,33 +37,98 @@ def solve_sharded(solver, params, seeds=None, goal_params=None, n=None, device=N
         goal_params = np.ascontiguousarray(goal_params, dtype=np.float64).reshape(n, -1) if solver.P else np.zeros((n, 1))
         meta[0] = n
     dist.broadcast(meta, src=0, group=group)
-    n = int(meta.item())
-    b = shard_bounds(n, world)
-    cap = max(b[r + 1] - b[r] for r in range(world))  # equal-size exchange buffers, padded
-    mine = b[rank + 1] - b[rank]
-    inbuf = torch.zeros((cap, V + P), dtype=torch.float64, device=dev)
+    s = _Shard()
+    s.solver, s.V, s.P = solver, V, P
+    s.n = int(meta.item())
+    s.b = shard_bounds(s.n, world)
+    s.cap = max(s.b[r + 1] - s.b[r] for r in range(world))  # equal-size exchange buffers, padded
+    s.mine = s.b[rank + 1] - s.b[rank]
+    s.first = s.b[rank]
+    s.inbuf = torch.zeros((s.cap, V + P), dtype=torch.float64, device=dev)
     if rank == 0:
         full = torch.from_numpy(np.concatenate([seeds, goal_params], axis=1))
         chunks = []
         for r in range(world):
-            c = torch.zeros((cap, V + P), dtype=torch.float64)
-            c[:b[r + 1] - b[r]] = full[b[r]:b[r + 1]]
+            c = torch.zeros((s.cap, V + P), dtype=torch.float64)
+            c[:s.b[r + 1] - s.b[r]] = full[s.b[r]:s.b[r + 1]]
             chunks.append(c.to(dev))
-        dist.scatter(inbuf, scatter_list=chunks, src=0, group=group)
+        dist.scatter(s.inbuf, scatter_list=chunks, src=0, group=group)
     else:
-        dist.scatter(inbuf, src=0, group=group)
-    local = inbuf[:mine].cpu().numpy()
-    solver.set_first_query(b[rank])
-    sol, fit, suc, steps = solver.solve_batch(params, local[:, :V], local[:, V:V + solver.P]) if mine else (
-        np.zeros((0, V)), np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32))
-    solver.set_first_query(0)
-    out = torch.zeros((cap, V + 3), dtype=torch.float64, device=dev)
-    if mine:
-        out[:mine] = torch.from_numpy(np.concatenate([sol, fit[:, None], suc[:, None].astype(np.float64), steps[:, None].astype(np.float64)], axis=1)).to(dev)
+        dist.scatter(s.inbuf, src=0, group=group)
+    return s
+
+
+def _launch(s, params, dev, stream=None):
+    """Solve this rank's shard.  On a GPU: enqueue on `stream` and return (the rows are packed in _finish); on the CPU
+    (gloo tests, host-simulator back end) the host-pointer entry point is synchronous."""
+    import torch
+    V, P = s.V, s.P
+    s.out = torch.zeros((s.cap, V + 3), dtype=torch.float64, device=dev)
+    s.stream = stream
+    if not s.mine:
+        return
+    s.solver.set_first_query(s.first)  # read when the launch is enqueued
+    if dev.type == "cuda":
+        with torch.cuda.stream(stream):
+            s.d_seeds = s.inbuf[:s.mine, :V].contiguous()
+            s.d_par = s.inbuf[:s.mine, V:V + P].contiguous()
+            s.d_sol = torch.empty((s.mine, V), dtype=torch.float64, device=dev)
+            s.d_fit = torch.empty(s.mine, dtype=torch.float64, device=dev)
+            s.d_suc = torch.empty(s.mine, dtype=torch.int32, device=dev)
+            s.d_steps = torch.empty(s.mine, dtype=torch.int32, device=dev)
+            s.solver.solve_batch_device(params, s.mine, s.d_seeds.data_ptr(), s.d_par.data_ptr(), s.d_sol.data_ptr(), s.d_fit.data_ptr(),
+                                        s.d_suc.data_ptr(), s.d_steps.data_ptr(), stream.cuda_stream)
+            s.out[:s.mine, :V] = s.d_sol
+            s.out[:s.mine, V] = s.d_fit
+            s.out[:s.mine, V + 1] = s.d_suc.to(torch.float64)
+            s.out[:s.mine, V + 2] = s.d_steps.to(torch.float64)
+    else:
+        local = s.inbuf[:s.mine].numpy()
+        sol, fit, suc, steps = s.solver.solve_batch(params, local[:, :V], local[:, V:V + s.solver.P])
+        s.out[:s.mine] = torch.from_numpy(np.concatenate([sol, fit[:, None], suc[:, None].astype(np.float64), steps[:, None].astype(np.float64)], axis=1))
+    s.solver.set_first_query(0)
+
+
+def _gather(s, dev, group):
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if dev.type == "cuda" and s.stream is not None:
+        torch.cuda.current_stream(dev).wait_stream(s.stream)
+    V = s.V
     if rank == 0:
-        gathered = [torch.zeros_like(out) for _ in range(world)]
-        dist.gather(out, gather_list=gathered, dst=0, group=group)
-        res = np.concatenate([gathered[r][:b[r + 1] - b[r]].cpu().numpy() for r in range(world)], axis=0)
+        gathered = [torch.zeros_like(s.out) for _ in range(world)]
+        dist.gather(s.out, gather_list=gathered, dst=0, group=group)
+        res = np.concatenate([gathered[r][:s.b[r + 1] - s.b[r]].cpu().numpy() for r in range(world)], axis=0)
         return res[:, :V], res[:, V], res[:, V + 1].astype(np.int32), res[:, V + 2].astype(np.int32)
-    dist.gather(out, dst=0, group=group)
+    dist.gather(s.out, dst=0, group=group)
     return None
+
+
+def _device(device):
+    import torch
+    return torch.device(device) if device is not None else torch.device("cpu")
+
+
+def solve_sharded(solver, params, seeds=None, goal_params=None, n=None, device=None, group=None):
+    """Collective call.  `seeds`/`goal_params` are needed on rank 0 only (NumPy, host); every rank passes its own
+    `solver` (a HipSolver on its GPU) and the same `params`.  Returns (solutions, fitness, success, steps) on rank 0,
+    None elsewhere.  `device` = torch device used for the exchange buffers (cuda:<local rank> with nccl, cpu with gloo)."""
+    res = solve_mixed([(solver, params, seeds, goal_params)], device=device, group=group)
+    return None if res is None else res[0]
+
+
+def solve_mixed(blocks, device=None, group=None):
+    """Collective call over a batch sorted by model: `blocks` = [(solver, params, seeds, goal_params), ...], one homogeneous
+    block per problem template (the same list of solvers and params on every rank; seeds / goal_params on rank 0 only).
+    Every block is sharded over all ranks; a rank's blocks run concurrently (one HIP stream each).  Returns on rank 0 a list
+    with one (solutions, fitness, success, steps) per block, None elsewhere."""
+    import torch
+    dev = _device(device)
+    shards = [_scatter(solver, seeds, gp, dev, group) for solver, _, seeds, gp in blocks]
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)  # the scattered rows are complete before the solver streams read them
+    for s, (_, params, _, _) in zip(shards, blocks):
+        _launch(s, params, dev, torch.cuda.Stream(dev) if dev.type == "cuda" else None)
+    out = [_gather(s, dev, group) for s in shards]
+    return None if out[0] is None else out

@@ -4,6 +4,8 @@ Three levels: function level (same genes -> same frames / fitne
 trajectory level (same RNG streams -> the same solution, bit for bit: both sides use bioik_sincos and the explicitly fused IEEE
 arithmetic), result level at BASELINE.json's full sizes (every reported success reproduces its goal pose under the
 ORACLE's exact FK within 1e-4 m / 1e-3 rad, joints inside their limits, success rate equal to the oracle's on a sample)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,8 @@ from bio_ik_amd import ProblemTemplate, abi
 from bio_ik_amd.workload import make_queries
 from conftest import gnarly_goals
 from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -266,3 +270,19 @@ def test_error_conventions(pr2):
     with pytest.raises(BioIKError) as e:  # variable outside the group: reference ERROR("joint variable not found"), problem.cpp:125
         HipSolver(ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), JointVariableGoal("l_elbow_flex_joint", 0.0)]))
     assert e.value.code == abi.ERR_NOT_FOUND
+
+
+@pytest.mark.gpu
+def test_sharded_and_mixed_batch_device_path(tmp_path):
+    """bio_ik_amd/batch.py with the exchange buffers in HBM (backend nccl = RCCL, one rank on this one-GPU box): the shard is
+    solved by bioik_solve_batch_device on its own stream and gathered; equal, bit for bit, to the host-pointer solve."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "result.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BIOIK_WORKER_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "tests", "_gloo_worker.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = np.load(out)
+    assert res[0] == 1 and res[1] == 1

@@ -1,6 +1,6 @@
 """Throughput of the BASELINE.json configurations that are parity cases, not bench lines: C2 (global and tracking seeds), C3
 (PR2 'all': two PoseGoals + secondary MinimalDisplacementGoal, pop=128), C4 (31-DOF snake: PoseGoal + secondary
-AvoidJointLimitsGoal, pop=512); 4096 queries per launch, two launches in flight as in bench.py.  Prints one line per case."""
+AvoidJointLimitsGoal, pop=512); 4096 queries per launch, three launches in flight as in bench.py.  Prints one line per case."""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ def sec(g):
     return g
 
 
-def run(name, template, pop, kind, max_steps, n=4096, steps=8, nfl=2):
+def run(name, template, pop, kind, max_steps, n=4096, steps=9, nfl=3):
     dev = torch.device("cuda", 0)
     h = HipSolver(template, device=0)
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=0xB101C, kind=kind)
@@ -47,7 +47,7 @@ def run(name, template, pop, kind, max_steps, n=4096, steps=8, nfl=2):
     torch.cuda.synchronize(dev)
     d1 = time.perf_counter() - t0
     suc, st = bufs[0][2].cpu().numpy(), bufs[0][3].cpu().numpy()
-    print("%-22s D=%2d T=%d pop=%3d %-8s: %8.0f solves/s  %6.2f ms/batch (two in flight)  %6.2f ms alone  success %.4f  mean steps %.2f" %
+    print("%-22s D=%2d T=%d pop=%3d %-8s: %8.0f solves/s  %6.2f ms/batch (three in flight)  %6.2f ms alone  success %.4f  mean steps %.2f" %
           (name, h.D, h.T, pop, kind, suc.sum() / dt, dt * 1e3, d1 * 1e3, suc.mean(), st.mean()), flush=True)
 
 
