@@ -351,7 +351,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         }
         ops[k].mimic_src = value_op_of_var[sv];
     }
-    if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 32 moving joints on the goal chains");
+    if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 moving joints on the goal chains");
     if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 8 tip links");
     for (size_t k = 0; k < ops.size(); k++) {
         DevOp& op = ops[k];
@@ -389,9 +389,9 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         for (int c = 0; c < 4; c++) dt.e[3 + c] = tt[t].e.q[c];
         dt.out_index = tt[t].pub;
         dev.tip_of_out[tt[t].pub] = t;
-        uint32_t mask = 0;
+        uint64_t mask = 0;
         for (int l = tip_links[tt[t].pub]; l >= 0; l = m->links[l].parent)
-            if (op_of_link[l] >= 0) mask |= 1u << op_of_link[l];
+            if (op_of_link[l] >= 0) mask |= 1ull << op_of_link[l];
         dt.dep_mask = mask;
         if (dt.src < 0) {
             dev.n_root_tips++;
@@ -440,6 +440,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.n_secondary = ns;
     dev.n_ops = (int)ops.size();
     dev.n_chain_ops = n_chain;
+    // the memetic phase gives gene i to lane i of a 64-lane wavefront and the unperturbed elite to lane D
+    if (D > 63) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 63 active variables");
     dev.D = D;
     dev.T = T;
     dev.V = nv;
@@ -457,8 +459,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         if (dev.op_of_gene[i] <= dev.op_of_gene[i - 1]) dev.genes_follow_ops = 0;
     for (size_t k = 0; k < ops.size(); k++) {
         dev.ops[k] = ops[k];
-        if (ops[k].gene >= 0) dev.active_mask |= 1u << k;
-        if ((int)k < n_chain && ops[k].mimic_src >= 0) dev.mimic_followers[ops[k].mimic_src] |= 1u << k;
+        if (ops[k].gene >= 0) dev.active_mask |= 1ull << k;
+        if ((int)k < n_chain && ops[k].mimic_src >= 0) dev.mimic_followers[ops[k].mimic_src] |= 1ull << k;
     }
 }
 

@@ -640,7 +640,7 @@ BIOIK_DEV F7 linear_tip(PB pb, int t, const XV& x, const LinModel& lm) {
     const int n_ops = pb->n_ops;
     const bool by_op = pb_flavour<PB>::general ? pb->genes_follow_ops != 0 : true;
     const int cnt = by_op ? n_ops : pb->D;
-    const uint32_t active = pb->active_mask;
+    const uint64_t active = pb->active_mask;
     const double* tb = lm.tipbase + t * 7;
     double px = tb[0], py = tb[1], pz = tb[2], rx = tb[3], ry = tb[4], rz = tb[5], rw = tb[6];
     for (int g0 = 0; g0 < cnt; g0 += 4) {
@@ -649,7 +649,7 @@ BIOIK_DEV F7 linear_tip(PB pb, int t, const XV& x, const LinModel& lm) {
         for (int j = 0; j < 4; j++) {
             const int idx = g0 + j < cnt ? g0 + j : cnt - 1;
             const int kk = by_op ? idx : pb->op_of_gene[idx];
-            const bool on = g0 + j < cnt && ((active >> kk) & 1u);
+            const bool on = g0 + j < cnt && ((active >> kk) & 1ull);
             const double xv = x(kk), bv = lm.base[kk];
             dv[j] = on ? xv - bv : 0.0;
             const double* dp = lm.delta + ((size_t)t * n_ops + kk) * 7;
@@ -735,12 +735,12 @@ template <class PB>
 BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, const double* tips, double* out7, const double* base = nullptr,
                                   const double* prefix = nullptr) {
     BIOIK_FP_STRICT
-    const uint32_t dep_mask = pb->tips[t].dep_mask;
+    const uint64_t dep_mask = pb->tips[t].dep_mask;
     const int n_chain = pb->n_chain_ops;
     const bool gene = pb->ops[k].gene >= 0;
     const int jop = pb_flavour<PB>::general ? pb->ops[k].joint_op : -1;
     if (jop >= 0) {  // a variable of a floating / planar joint
-        if (!gene || ((dep_mask >> jop) & 1u) == 0 || base == nullptr) {
+        if (!gene || ((dep_mask >> jop) & 1ull) == 0 || base == nullptr) {
             for (int c = 0; c < 7; c++) out7[c] = 0.0;
             return;
         }
@@ -756,9 +756,9 @@ BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, con
         out7[3] = dq.x - tf.q.x, out7[4] = dq.y - tf.q.y, out7[5] = dq.z - tf.q.z, out7[6] = dq.w - tf.q.w;
         return;
     }
-    const bool own = gene && k < n_chain && ((dep_mask >> k) & 1u) != 0;
-    const uint32_t followers = gene ? pb->mimic_followers[k] & dep_mask : 0u;  // mimic joints of this gene on the tip's chain
-    if (!own && followers == 0u) {
+    const bool own = gene && k < n_chain && ((dep_mask >> k) & 1ull) != 0;
+    const uint64_t followers = gene ? pb->mimic_followers[k] & dep_mask : 0ull;  // mimic joints of this gene on the tip's chain
+    if (!own && followers == 0ull) {
         for (int c = 0; c < 7; c++) out7[c] = 0.0;
         return;
     }
@@ -766,8 +766,8 @@ BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, con
     V3 vel = v3(0.0, 0.0, 0.0), om = v3(0.0, 0.0, 0.0);
     if (own) jacobian_column(pb, k, f7_load(frames + k * 7), tf, vel, om);
     // the joints that mimic this one move with it: their columns, scaled (joint_dependencies, forward_kinematics.h:623-636)
-    for (uint32_t rest = followers; rest != 0u; rest &= rest - 1u) {
-        const int m = __builtin_ctz(rest);
+    for (uint64_t rest = followers; rest != 0ull; rest &= rest - 1ull) {
+        const int m = __builtin_ctzll(rest);
         V3 v2, o2;
         jacobian_column(pb, m, f7_load(frames + m * 7), tf, v2, o2);
         const double scale = pb->ops[m].mimic_factor;

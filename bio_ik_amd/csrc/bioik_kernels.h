@@ -194,7 +194,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int tid = p_tid(), nth = p_nthreads(), lane = tid & 63;
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
-    const uint32_t active_mask = pb->active_mask;  // bit k: op k is a gene
+    const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
     const bool has_sec = pb->n_secondary > 0;
     const bool exact = sp.fk_mode == FK_EXACT;
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
@@ -397,16 +397,17 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 if (first.id != 1 && (second.id < 0 || cand_better(S.pf1, 1, second.f, second.pos))) second = Cand{S.pf1, 1, 1};
                 if (second.id < 0 || cand_better(c2f, c2p, second.f, second.pos)) second = Cand{c2f, c2p, c2p};
                 // the winners become the elites (written to the species' other buffer)
-                // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its op k (at most 32 ops)
+                // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its ops k, k + 32
                 double* nb = popS + (S.cur ^ 1) * BF;
                 for (int pass = 0; pass < (G >= 64 ? 1 : 2); pass++) {  // a half-wave group has 32 lanes: one winner per pass
                     if (gtid >= 64) break;
-                    const int i = G >= 64 ? gtid >> 5 : pass, k = gtid & 31;
+                    const int i = G >= 64 ? gtid >> 5 : pass, k0 = gtid & 31;
                     const int id = i == 0 ? first.id : second.id;
                     double* dst = nb + i * 2 * M;
                     if (id < 2) {
                         const double* src = cb + id * 2 * M;
-                        if (k < M) dst[k] = src[k], dst[M + k] = src[M + k];
+                        if (k0 < M) dst[k0] = src[k0], dst[M + k0] = src[M + k0];
+                        if (M > 32 && k0 + 32 < M) dst[k0 + 32] = src[k0 + 32], dst[M + k0 + 32] = src[M + k0 + 32];  // (at most 64 ops)
                     } else if (stored) {
                         // the winner's genes are still in its owner's column; its momentum follows from the genes
                         // (ik_evolution_2.cpp:299: gradient = mix(parent_gradient, gene - parent_gene, 0.3))
@@ -415,16 +416,18 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         const int c = has_sec ? s_order[r] : r;
                         const double fmix = (((uint32_t)c + 2u) % 2u == 0u) ? 0.2 : 0.0;
                         const double* src = (lds + L.xcol) + (size_t)(r / G) * M * nth + (grp * G + r % G);
-                        if (k < n_ops) {
+                        auto take = [&](int k) {
                             double gene = src[(size_t)k * nth];
                             double mom = 0.0;
-                            if ((active_mask >> k) & 1u) {
+                            if ((active_mask >> k) & 1ull) {
                                 double parent_gradient = p0d[k] * (1.0 - fmix) + p1d[k] * fmix;
                                 mom = parent_gradient * (1.0 - 0.3) + (gene - p0g[k]) * 0.3;
                             }
                             dst[k] = gene, dst[M + k] = mom;
-                        }
-                    } else if (k == 0) {  // not stored: re-derive the child from the counter RNG
+                        };
+                        if (k0 < n_ops) take(k0);
+                        if (n_ops > 32 && k0 + 32 < n_ops) take(k0 + 32);  // (at most 64 ops)
+                    } else if (k0 == 0) {  // not stored: re-derive the child from the counter RNG
                         int c = has_sec ? s_order[id - 2] : id - 2;
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, dst, 1, dst + M, 1);
                     }
@@ -526,7 +529,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         for (int k = 0; k < n_ops; k++) {
                             const double cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
                             const double e = el[k], gv = s_gop[k] * fnorm;
-                            xcol[(size_t)k * nth] = ((active_mask >> k) & 1u) ? fmin(fmax(e + gv * step_size, cmin), cmax) : e;
+                            xcol[(size_t)k * nth] = ((active_mask >> k) & 1ull) ? fmin(fmax(e + gv * step_size, cmin), cmax) : e;
                         }
                         PHASE_MARK(PH_MEM_CANDIDATE);
                         const double f4p = eval_linear_primary(pb, xl, qc, lm);

@@ -7,7 +7,7 @@
 #pragma once
 #include <stdint.h>
 
-#define BIOIK_MAX_OPS 32    // moving joints on the union of the root->tip chains (+ off-chain goal variables)
+#define BIOIK_MAX_OPS 64    // moving joints on the union of the root->tip chains (+ off-chain goal variables)
 #define BIOIK_MAX_TIPS 8
 #define BIOIK_MAX_GOALS 24  // per class (primary / secondary)
 
@@ -46,7 +46,7 @@ struct DevTip {
     int32_t has_e;                     // 0: E is the identity
     int32_t out_index;                 // index in Problem::tip_link_indices (order of the public API)
     int32_t goal_first, goal_count;    // primary link goals reading this tip: DevProblem::primary[goal_first..)
-    uint32_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
+    uint64_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
 };
 
 struct DevGoal {
@@ -78,10 +78,10 @@ struct DevProblem {
     int32_t n_link_primary;  // primary[0..n_link_primary) are link goals grouped by tip; the rest read genes only
     int32_t n_primary;
     int32_t n_secondary;
-    uint32_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
+    uint64_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
     double multi_c[7];     // constant frame in front of the floating / planar joint
     int32_t quat_op[4];    // op index of the first of the four orientation value ops
-    uint32_t mimic_followers[BIOIK_MAX_OPS];  // bit m: chain op m is a mimic joint following op k
+    uint64_t mimic_followers[BIOIK_MAX_OPS];  // bit m: chain op m is a mimic joint following op k
     int32_t op_of_gene[BIOIK_MAX_OPS];
     int32_t tip_of_out[BIOIK_MAX_TIPS];  // device tip index of public tip i
     DevOp ops[BIOIK_MAX_OPS];

@@ -68,6 +68,22 @@ def test_mimic_joints():
     pc.trajectory(h2, o2, t2, n=16, pop=128, steps_list=(1, 6))
     pc.trajectory(h2, o2, t2, n=8, pop=70, steps_list=(3,), fk_mode=abi.FK_LINEAR)
 
+def test_more_than_32_joints():
+    """48 moving joints on one chain: function level and whole solves bit for bit, every lane mapping the launcher picks
+    for 16 / 70 / 128 children per species; 64 active variables are refused"""
+    from bio_ik_amd import AvoidJointLimitsGoal, PoseGoal, snake
+    from bio_ik_amd.solver import BioIKError, HipSolver
+    m = snake(48)
+    t = ProblemTemplate(m, "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()])
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == 48
+    pc.function_level(h, o, m, np.random.default_rng(11), n=300, exact_bits=True)
+    pc.trajectory(h, o, t, n=8, pop=16, steps_list=(1, 3))
+    pc.trajectory(h, o, t, n=4, pop=128, steps_list=(2,))
+    pc.trajectory(h, o, t, n=4, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+    with pytest.raises(BioIKError):
+        HipSolver(ProblemTemplate(snake(64), "snake", [PoseGoal("tip")]))
+
 
 @pytest.mark.parametrize("base", ["floating", "planar"])
 def test_floating_and_planar_joints(base):

@@ -121,6 +121,21 @@ def test_mimic_joints(hostsim_lib):
     pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
+def test_more_than_32_joints(hostsim_lib):
+    """48 moving joints on one chain (op masks, winner copy and the memetic lanes beyond 32 ops): function level and whole
+    solves bit for bit; 64 active variables are refused (the memetic phase needs lane D of a 64-lane wavefront)."""
+    from bio_ik_amd import AvoidJointLimitsGoal, PoseGoal, snake
+    from bio_ik_amd.solver import BioIKError
+    m = snake(48)
+    t = ProblemTemplate(m, "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()])
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    assert h.D == o.D == 48
+    pc.function_level(h, o, m, np.random.default_rng(11), n=24, exact_bits=True)
+    pc.trajectory(h, o, t, n=2, pop=20, steps_list=(1, 2))
+    pc.trajectory(h, o, t, n=1, pop=70, steps_list=(1,), fk_mode=abi.FK_LINEAR)
+    with pytest.raises(BioIKError):
+        HipSolver(ProblemTemplate(snake(64), "snake", [PoseGoal("tip")]), lib=hostsim_lib)
+
 
 @pytest.mark.parametrize("base", ["floating", "planar"])
 def test_floating_and_planar_joints(hostsim_lib, base):
