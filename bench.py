@@ -20,6 +20,7 @@ Extra objects on the JSON line:
   cpu_baseline the reference's own CPU code (oracle/_ref: the reference sources compiled unmodified, Release flags) when the
                prebuilt library is present, else the oracle port; timed on this host, rank 0, N=1 only, one thread, on a
                bounded sample of the same queries.  The port at the GPU run's own parameters is reported beside it.
+  tracking_seeds  the same template and parameters on seeds near the target (SURVEY.md section 8(d)'s second workload).
   reference_parameters  the GPU on the same queries at the reference's own parameters (its population, its linearised
                phenotypes): the like-for-like figure next to cpu_baseline.value.
 """
@@ -252,6 +253,29 @@ def main():
         out["reference_parameters"] = {"value": float(rsuc.sum()) / dtr, "unit": "solves/s", "ms_per_step": dtr * 1e3, "success_rate": float(rsuc.mean()),
                                        "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "population": 16, "fk": "linear", "max_steps": 512,
                                        "batches_in_flight": nfl}
+
+    if rank == 0 and world == 1 and not args.timed_only:
+        # The "tracking" workload of SURVEY.md section 8(d) (seed = target + N(0, 0.1 rad), as the reference's ik_test does): same
+        # template, same parameters, same issue pattern; reported next to the global-seed figure, never `value`.
+        tseeds, tparams, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank, kind="tracking")
+        dts, dtp = torch.from_numpy(tseeds).to(dev), torch.from_numpy(tparams).to(dev)
+
+        def tstep(i):
+            o = bufs[i % nfl]
+            h.solve_batch_device(p, BATCH, dts.data_ptr(), dtp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+        for i in range(nfl):
+            tstep(i)
+        torch.cuda.synchronize(dev)
+        kt = 30
+        t1 = time.perf_counter()
+        for i in range(kt):
+            tstep(i)
+        torch.cuda.synchronize(dev)
+        dtt = (time.perf_counter() - t1) / kt
+        tsuc = bufs[0][2].cpu().numpy()
+        out["tracking_seeds"] = {"value": float(tsuc.sum()) / dtt, "unit": "solves/s", "ms_per_step": dtt * 1e3, "success_rate": float(tsuc.mean()),
+                                 "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "batches_in_flight": nfl,
+                                 "sample": "4096 queries, seed = target configuration + N(0, 0.1 rad) clipped to the joint limits"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle import orc, ref

@@ -230,17 +230,21 @@ def test_device_pointer_entry_and_streamed_fitness(gpus, oracles, templates):
     st.synchronize()
     assert np.array_equal(sol.cpu().numpy(), ref[0]) and np.array_equal(steps.cpu().numpy(), ref[3])
     # streamed generation: genes [unit][D][pop] in HBM -> fitness [unit][pop], against the oracle
-    pop, units = 128, 8
-    rng = np.random.default_rng(0)
-    genes = rng.uniform(-1, 1, size=(units, h.D, pop))
-    dg = torch.from_numpy(genes).to(dev)
-    df = torch.empty((units, pop), dtype=torch.float64, device=dev)
-    h.stream_fitness_device(units, pop, ds.data_ptr(), dp.data_ptr(), dg.data_ptr(), df.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
-    torch.cuda.synchronize(dev)
-    got = df.cpu().numpy()
-    for u in range(units):
-        want, _ = o.fitness(abi.FK_EXACT, seeds[u], params[u], genes[u].T)
-        assert np.array_equal(got[u], want)
+    # (odd tails, several blocks per unit, a tree with parked branch frames)
+    for cfg, pop, units in (("c2", 128, 8), ("c2", 77, 5), ("c2", 600, 3), ("c3", 130, 4)):
+        h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, units, seed=6)
+        ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
+        rng = np.random.default_rng(pop)
+        genes = rng.uniform(-1, 1, size=(units, h.D, pop))
+        dg = torch.from_numpy(genes).to(dev)
+        df = torch.empty((units, pop), dtype=torch.float64, device=dev)
+        h.stream_fitness_device(units, pop, ds.data_ptr(), dp.data_ptr(), dg.data_ptr(), df.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        got = df.cpu().numpy()
+        for u in range(units):
+            want, _ = o.fitness(abi.FK_EXACT, seeds[u], params[u], genes[u].T)
+            assert np.array_equal(got[u], want), (cfg, pop, u)
 
 
 def test_two_launches_in_flight(gpus, templates):

@@ -121,6 +121,21 @@ def test_mimic_joints(hostsim_lib):
     pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
+def test_streamed_fitness(sims, oracles, templates):
+    """bioik_stream_fitness_device (genes [unit][D][pop] -> fitness [unit][pop]): odd
+    tails, several blocks per unit, a tree with parked branch frames; in the host simulator device pointers are host pointers"""
+    from bio_ik_amd.workload import make_queries
+    for cfg, pop, units in (("c2", 128, 2), ("c2", 77, 2), ("c2", 600, 1), ("c3", 130, 2)):
+        h, o, t = sims[cfg], oracles[cfg], templates[cfg]
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, units, seed=6)
+        genes = np.ascontiguousarray(np.random.default_rng(pop).uniform(-1, 1, size=(units, h.D, pop)))
+        got = np.zeros((units, pop))
+        h.stream_fitness_device(units, pop, seeds.ctypes.data, params.ctypes.data, genes.ctypes.data, got.ctypes.data, 0)
+        for u in range(units):
+            want, _ = o.fitness(abi.FK_EXACT, seeds[u], params[u], genes[u].T)
+            assert np.array_equal(got[u], want), (cfg, pop, u)
+
+
 def test_more_than_32_joints(hostsim_lib):
     """48 moving joints on one chain (op masks, winner copy and the memetic lanes beyond 32 ops): function level and whole
     solves bit for bit; 64 active variables are refused (the memetic phase needs lane D of a 64-lane wavefront)."""
