@@ -238,9 +238,9 @@ struct DevBuf {
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3  // register budget of k_solve: wavefronts per SIMD (its __launch_bounds__)
 #endif
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0, child_cols, groups, slot_sets).total * 8;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets).total * 8;
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
@@ -256,6 +256,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
     // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
     int nth = solve_threads(sp, units);
+    const bool exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
     const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
     const bool manual = std::getenv("BIOIK_SOLVE_THREADS") || std::getenv("BIOIK_SOLVE_STORE_CHILDREN") || std::getenv("BIOIK_SOLVE_CHILD_PAIRS") ||
                         std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL");
@@ -273,7 +274,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
             const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : 1;
             if (c.pairs && cols < 2) continue;
-            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1);
+            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact);
             if (bytes > 160 * 1024) continue;
             int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
             if (waves > kCuWaves) waves = kCuWaves;
@@ -287,7 +288,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
         sp.child_pairs = cands[best].pairs;
     } else {
-        while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
+        while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2, 1, exact) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
         // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
         // (small populations, <= 32 children per species: +65..80 % measured, tools/halfwave_sweep.sh; at 64 and more children
         // per species the sequential single wavefront or the two-wavefront mapping is as good or better)
@@ -299,18 +300,26 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             sp.child_cols = 1;
         } else if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
             if (std::atoi(e) == 0) sp.child_cols = 1;
-        } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m) > 48 * 1024) {
+        } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 1, exact) > 48 * 1024) {
             sp.child_cols = 1;
         }
         // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
         // trees, a second set of parked frames
-        sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2) <= 64 * 1024) ? 1 : 0;
+        sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2, exact) <= 64 * 1024) ? 1 : 0;
         if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
             if (std::atoi(e) == 0) sp.child_pairs = 0;
     }
     const int groups = sp.species_parallel ? 2 : 1;
-    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1);
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+    if (std::getenv("BIOIK_SOLVE_REPORT")) {  // diagnostics: the lane mapping and the residency it gives
+        const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.child_cols, groups,
+                                        sp.child_pairs ? 2 : 1);
+        std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d | LDS %zu B "
+                     "(genotype columns %d, parked frames %d, per-group %d x %d) -> %d workgroups = %d wavefronts per CU\n",
+                     dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, lds, (L.slots - L.xcol) * 8,
+                     (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(160 * 1024 / lds), (int)(160 * 1024 / lds) * (nth / 64));
+    }
 #if !defined(BIOIK_HOSTSIM)
     if (lds > 64 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

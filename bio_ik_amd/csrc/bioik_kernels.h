@@ -47,10 +47,19 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.delta = g, g += T * m * 7;
     L.base = g, g += m;
     L.grad = g, g += m;
+    // has_secondary == 2: the pre-selection scratch of the generation loop shares the space of the memetic phase's vectors and
+    // linear model (exact-FK generations never read the linear model, and both are rebuilt before every use)
+    const int n_sec = has_secondary ? lambda : 0, n_order = has_secondary ? (lambda + 1) / 2 : 0;
+    if (has_secondary == 2) {
+        L.sec = 0, L.order = n_sec;
+        if (n_sec + n_order > g) g = n_sec + n_order;
+    }
     L.red = g, g += 4 * (nthreads / 64) + 4;
     L.bc = g, g += 4;  // values broadcast from the group's leading wavefront
-    L.sec = g, g += has_secondary ? lambda : 0;
-    L.order = g, g += has_secondary ? (lambda + 1) / 2 : 0;
+    if (has_secondary != 2) {
+        L.sec = g, g += n_sec;
+        L.order = g, g += n_order;
+    }
     L.g_first = o;
     L.g_stride = g;
     o += g * (groups > 0 ? groups : 1);
@@ -203,7 +212,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int groups = sp.species_parallel ? 2 : 1;
     const int G = nth / groups;        // lanes per species group (a multiple of 64)
     const int grp = tid / G, gtid = tid - grp * G;
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec, n_cols, groups, sp.child_pairs ? 2 : 1);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, n_cols, groups, sp.child_pairs ? 2 : 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
