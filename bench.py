@@ -69,15 +69,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: bio_ik_amd has no CPU compute path")
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; BIOIK_BENCH_BACKEND=gloo lets several ranks share the GPUs of a smaller box (RCCL refuses two ranks on one
+    # device): a dry run of the N>1 control flow, not a measurement
+    backend = os.environ.get("BIOIK_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    if world > 1:
+        torch.cuda.set_device(gpu)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend=backend)
+    dev = torch.device("cuda", gpu)
     torch.cuda.set_device(dev)
 
     template = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
-    h = HipSolver(template, device=local_rank)
+    h = HipSolver(template, device=gpu)
     D, V, T = h.D, h.V, h.T
     # synthetic queries of the reference's own self-test recipe (README.md:410-418); every rank draws its own shard
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank)
@@ -201,7 +209,7 @@ def main():
     # (individual index fastest), one launch = exact-FK fitness of every individual.  Reported next to the solver line;
     # it is not what `value` measures.
     if rank == 0 and world == 1 and os.environ.get("BIOIK_BENCH_STREAM", "1") != "0" and not args.timed_only:
-        units = 16384
+        units = int(os.environ.get("BIOIK_BENCH_STREAM_UNITS", "16384"))
         stream = torch.cuda.current_stream(dev)
         g = torch.rand((units, D, POP), dtype=torch.float64, device=dev) * 2.0 - 1.0
         f = torch.empty((units, POP), dtype=torch.float64, device=dev)
