@@ -3,7 +3,7 @@
 # no query may succeed (dtwist 1e-300) so every workgroup runs exactly 32 steps.  usage: tools/lone_probe.sh build/libphase.so
 lib=$1
 for cfg in "1 128" "1 256" "1536 128"; do set -- $cfg
-  BIOIK_BENCH_STREAM=0 BIOIK_BENCH_DTWIST=1e-300 BIOIK_BENCH_MAX_STEPS=32 BIOIK_BENCH_BATCH=$1 BIOIK_PHASE_DUMP=/tmp/phase.bin BIOIK_HIP_LIBRARY=$lib BIOIK_SOLVE_THREADS=$2 python bench.py --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2>&1
+  BIOIK_BENCH_STREAM=0 BIOIK_BENCH_DTWIST=1e-300 BIOIK_BENCH_MAX_STEPS=32 BIOIK_BENCH_BATCH=$1 BIOIK_PHASE_DUMP=/tmp/phase.bin BIOIK_HIP_LIBRARY=$lib BIOIK_SOLVE_THREADS=$2 python bench.py --timed-only --in-flight 1 --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2>&1
   python - <<PY
 import numpy as np
 a=np.fromfile("/tmp/phase.bin",dtype=np.uint64).reshape(-1,28).astype(np.float64)

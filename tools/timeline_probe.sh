@@ -3,7 +3,7 @@
 # 100 MHz wall clock, the CU it ran on, and the phase breakdown.  usage: tools/timeline_probe.sh build/libphase.so
 lib=$1
 for cfg in "4096 128" "4096 256" "16384 128"; do set -- $cfg
-  BIOIK_BENCH_BATCH=$1 BIOIK_PHASE_DUMP=/tmp/phase.bin BIOIK_HIP_LIBRARY=$lib BIOIK_SOLVE_THREADS=$2 python bench.py --no-cpu-baseline --steps 1 --warmup 0 > /tmp/tl.json 2>/dev/null
+  BIOIK_BENCH_BATCH=$1 BIOIK_PHASE_DUMP=/tmp/phase.bin BIOIK_HIP_LIBRARY=$lib BIOIK_SOLVE_THREADS=$2 python bench.py --timed-only --in-flight 1 --no-cpu-baseline --steps 1 --warmup 0 > /tmp/tl.json 2>/dev/null
   python - <<PY
 import numpy as np, json
 a=np.fromfile("/tmp/phase.bin",dtype=np.uint64).reshape(-1,28)
