@@ -267,6 +267,31 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             qrot(C.q, L.axis, op.cb);
             op.cb[3] = 0.0;
         }
+        // A branch whose parent frame is not the running frame: if the chain root -> parent is short (a torso in front of two
+        // arms), walk it again in front of the branch instead of parking the parent frame in LDS (7 doubles per lane and
+        // slot set).  The repeated ops read the value of the op they repeat (mimic factor 1) and are on no tip's chain mask,
+        // so genes, Jacobian columns and the linear model are untouched and the frames are the same bits.
+        if (!multi && base_src >= 0 && base_src != (int)ops.size() - 1) {
+            std::vector<int> chain;
+            bool plain = true;
+            for (int o = base_src; o >= 0; o = ops[o].src) {
+                chain.push_back(o);
+                plain = plain && (ops[o].type == BIOIK_OP_REVOLUTE || ops[o].type == BIOIK_OP_PRISMATIC);
+            }
+            if (plain && chain.size() <= 2 && ops.size() + chain.size() < (size_t)BIOIK_MAX_OPS) {
+                int prev = -1;
+                for (size_t c = chain.size(); c-- > 0;) {
+                    DevOp rep = ops[chain[c]];
+                    rep.gene = -1;
+                    rep.src = prev;
+                    rep.load_slot = rep.save_slot = -1;
+                    if (rep.mimic_src == -1) rep.mimic_src = chain[c], rep.mimic_factor = 1.0, rep.mimic_offset = 0.0;
+                    prev = (int)ops.size();
+                    ops.push_back(rep);
+                }
+                op.src = prev;
+            }
+        }
         int k = (int)ops.size();
         ops.push_back(op);
         src_of[l] = k;

@@ -46,6 +46,9 @@ def main():
         ok = ok and all(np.array_equal(a, b) for a, b in zip(mixed[0], h.solve_batch(p, seeds[:3], params[:3])))
         ok = ok and all(np.array_equal(a, b) for a, b in zip(mixed[1], h2.solve_batch(p2, seeds2, params2)))
         np.save(sys.argv[1], np.array([1 if ok else 0, dist.get_world_size()]))
+        if backend == "nccl":  # the result is on disk; do not wait for the communicator's teardown
+            sys.stdout.flush()
+            os._exit(0)
     else:
         assert res is None and mixed is None
     dist.destroy_process_group()
