@@ -439,19 +439,12 @@ BIOIK_DEV void fk_walk(PB pb, const XV& x, double* slots, double* frames_out, Ti
                 f = f7_identity();
             }
             {
-                // the joint's local frame: a revolute joint turns about its axis behind the constant frame (position = the
-                // constant's), every other op slides along cb (zero for the ops that only fetch a parked frame); the op type is
-                // wavefront-uniform, so this is a scalar branch, not a select per component
-                Q4 lq;
-                V3 lp;
-                if (type == BIOIK_OP_REVOLUTE) {
-                    const double s = sn[j], c = cs[j];
-                    lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
-                    lp = v3(cp0, cp1, cp2);
-                } else {
-                    lq = Q4{ca0, ca1, ca2, ca3};
-                    lp = v3(BK_FMA(xv[j], cb0, cp0), BK_FMA(xv[j], cb1, cp1), BK_FMA(xv[j], cb2, cp2));
-                }
+                // (selects, not a branch: this single-genotype walk is unrolled over BIOIK_FK_BLOCK joints, and a branch per joint
+                // with its own copy of the transform measured 5-9 % slower on the LDS-heavy problems that use it; fk_walk_n branches)
+                const bool rev = type == BIOIK_OP_REVOLUTE;
+                const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
+                const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
+                const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
                 f.p = f.p + qrot(f.q, lp);
                 f.q = qmul(f.q, lq);
             }
@@ -567,29 +560,27 @@ BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_st
 #pragma unroll
             for (int j = 0; j < N; j++) f[j] = f7_identity();
         }
-        // the joint's local frame (see fk_walk): scalar branch on the op type; the half-angle trigonometry only where it is used
-        Q4 lq[N];
-        V3 lp[N];
+        // the joint's local frame: a revolute joint turns about its axis behind the constant frame (position = the constant's), every
+        // other op slides along cb (zero for the ops that only fetch a parked frame).  The op type is wavefront-uniform: a scalar
+        // branch, not a select per component; the half-angle trigonometry only where it is used,
+        // and the frame applied inside each branch so that the constants stay scalar operands
         if (type == BIOIK_OP_REVOLUTE) {
             double sn[N], cs[N];
 #pragma unroll
             for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                lq[j] = Q4{BK_FMA(cs[j], ca0, sn[j] * cb0), BK_FMA(cs[j], ca1, sn[j] * cb1), BK_FMA(cs[j], ca2, sn[j] * cb2), BK_FMA(cs[j], ca3, sn[j] * cb3)};
-                lp[j] = v3(cp0, cp1, cp2);
+                const Q4 lq = Q4{BK_FMA(cs[j], ca0, sn[j] * cb0), BK_FMA(cs[j], ca1, sn[j] * cb1), BK_FMA(cs[j], ca2, sn[j] * cb2), BK_FMA(cs[j], ca3, sn[j] * cb3)};
+                f[j].p = f[j].p + qrot(f[j].q, v3(cp0, cp1, cp2));
+                f[j].q = qmul(f[j].q, lq);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < N; j++) {
-                lq[j] = Q4{ca0, ca1, ca2, ca3};
-                lp[j] = v3(BK_FMA(xv[j], cb0, cp0), BK_FMA(xv[j], cb1, cp1), BK_FMA(xv[j], cb2, cp2));
+                const V3 lp = v3(BK_FMA(xv[j], cb0, cp0), BK_FMA(xv[j], cb1, cp1), BK_FMA(xv[j], cb2, cp2));
+                f[j].p = f[j].p + qrot(f[j].q, lp);
+                f[j].q = qmul(f[j].q, Q4{ca0, ca1, ca2, ca3});
             }
-        }
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            f[j].p = f[j].p + qrot(f[j].q, lp[j]);
-            f[j].q = qmul(f[j].q, lq[j]);
         }
         if (ss >= 0) {
 #pragma unroll
