@@ -179,7 +179,9 @@ int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** o
 void bioik_model_destroy(bioik_model* m);
 
 /* replaces Problem::initialize + IKBase::initialize(problem) -> RobotFK::initialize(tips)
- * (problem.cpp:72-228, ik_base.h:154-161, forward_kinematics.h:253-330, 566-599) */
+ * (problem.cpp:72-228, ik_base.h:154-161, forward_kinematics.h:253-330, 566-599).
+ * Size limits of one problem (BIOIK_ERR_UNSUPPORTED beyond them): 64 moving joints on the union of the goal chains (a short
+ * chain in front of a branch counts once per branch), 63 active variables, 8 tip links, 24 primary + 24 secondary goals. */
 int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bioik_problem** out);
 void bioik_problem_destroy(bioik_problem* p);
 
