@@ -219,6 +219,10 @@ static int solve_threads(const DevSolveParams& sp, uint64_t units) {
         // step for a lone query, 95 k vs 84 k solves/s at batch 1024)
         int per_species = sp.lambda > 32 ? 64 : 32;
         t = 2 * per_species;
+        // a launch that cannot fill the chip anyway (a single query of the plugin, a few hundred queries): one lane per child,
+        // two wavefronts per species — a lone step takes 131 instead of 141 us, 1024 queries run 6 % faster; beyond ~768
+        // queries the 128-lane mapping wins (profiles/r01_batch_sweep.log, r01_lone_workgroup_phases.log)
+        if (sp.lambda >= 128 && units <= 768) t = 256;
     }
     if (t < 64) t = 64;
     t = (t + 63) / 64 * 64;
@@ -257,6 +261,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
     int nth = solve_threads(sp, units);
     const bool exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
+    if (!std::getenv("BIOIK_SOLVE_THREADS") && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
     const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
     const bool manual = std::getenv("BIOIK_SOLVE_THREADS") || std::getenv("BIOIK_SOLVE_STORE_CHILDREN") || std::getenv("BIOIK_SOLVE_CHILD_PAIRS") ||
                         std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL");
