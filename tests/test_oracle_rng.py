@@ -38,3 +38,29 @@ def test_counter_gauss_moments():
     zz = z.reshape(2000, 10)
     assert abs(np.corrcoef(zz[:, 0], zz[:, 1])[0, 1]) < 0.08
     assert abs(np.corrcoef(zz[:-1, 0], zz[1:, 0])[0, 1]) < 0.08
+
+
+def test_counter_gauss_distribution_shape():
+    """the one-word Gaussian (Binomial(16, 1/2) lattice + triangular jitter): unit variance by construction, support
+    +-9 * 0.4899 = 4.41 sigma, distribution function within 0.5 % of the normal one everywhere (exact enumeration of the
+    lattice, no sampling), kurtosis 2.885"""
+    from math import comb, erf, sqrt
+    scale = 0.4898979485566356
+    assert abs(scale - 1.0 / sqrt(4.0 + 1.0 / 6.0)) < 1e-15
+    assert orc.counter_gauss32(0x00000000) == (-8 - 1.0) * scale and orc.counter_gauss32(0xffffffff) == (8 + 510 / 256.0 - 1.0) * scale
+    # exact moments: k ~ Binomial(16) - 8, t = (a + b) / 256 - 1 with a, b uniform on 0..255
+    pk = np.array([comb(16, i) for i in range(17)], dtype=np.float64) / 2.0 ** 16
+    k = np.arange(17) - 8.0
+    ab = np.add.outer(np.arange(256), np.arange(256)).ravel() / 256.0 - 1.0
+    m2 = (pk * k ** 2).sum() + (ab ** 2).mean() + 2 * 0  # independent, E[k] = 0
+    m4 = (pk * k ** 4).sum() + 6 * (pk * k ** 2).sum() * (ab ** 2).mean() + (ab ** 4).mean() + 4 * 0
+    mean_t = ab.mean()
+    assert abs(mean_t + 1.0 / 256.0) < 1e-12  # the jitter is centred up to its own grid (-1/256)
+    var = (m2 - mean_t ** 2) * scale ** 2
+    assert abs(var - 1.0) < 2e-3
+    assert abs(m4 * scale ** 4 / var ** 2 - 2.885) < 0.01
+    # distribution function on a grid, exact: P(z <= x) = sum_k pk * P(t <= x / scale - k)
+    ts = np.sort(ab)
+    for x in np.linspace(-3.5, 3.5, 57):
+        cdf = sum(pk[i] * np.searchsorted(ts, x / scale - k[i], side="right") / ts.size for i in range(17))
+        assert abs(cdf - 0.5 * (1.0 + erf(x / sqrt(2.0)))) < 5e-3, x
