@@ -852,7 +852,7 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
         gradient_factor[i] = (double)(child_index[i] % 3u);
         mutation_rate[i] = 0.0;
     }
-    for (int w0 = 0; w0 <= D; w0 += 8) {
+    for (int w0 = 0; D > 0 && w0 <= D; w0 += 8) {  // (a problem whose variables are all fixed has no gene to draw)
         uint32_t c0[4 * N], q0[4 * N], q1[4 * N];
 #pragma unroll
         for (int j = 0; j < 4; j++) {

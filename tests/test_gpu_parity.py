@@ -68,6 +68,23 @@ def test_mimic_joints():
     pc.trajectory(h2, o2, t2, n=16, pop=128, steps_list=(1, 6))
     pc.trajectory(h2, o2, t2, n=8, pop=70, steps_list=(3,), fk_mode=abi.FK_LINEAR)
 
+def test_no_active_variable(pr2):
+    """every joint of the group fixed: D = 0, the solve runs its budget and returns the seed, as the oracle does"""
+    from bio_ik_amd import PoseGoal
+    from bio_ik_amd.solver import HipSolver
+    t0 = ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")])
+    names = [pr2.variable_names[v] for v in HipSolver(t0).active_variables]
+    t = ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")], fixed_joints=names)
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == 0
+    seeds, params = np.tile(pr2.default_positions(), (64, 1)), np.tile(t.pack_params(), (64, 1))
+    for pop, fk in ((16, abi.FK_EXACT), (128, abi.FK_EXACT), (16, abi.FK_LINEAR)):
+        p = abi.default_solve_params(population=pop, max_steps=2, random_seed=1, fk_mode=fk)
+        got, want = h.solve_batch(p, seeds, params), o.solve_batch(p, orc.RNG_COUNTER, seeds, params)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert np.array_equal(got[0], seeds) and not got[2].any()
+
+
 def test_more_than_32_joints():
     """48 moving joints on one chain: function level and whole solves bit for bit, every lane mapping the launcher picks
     for 16 / 70 / 128 children per species; 64 active variables are refused"""

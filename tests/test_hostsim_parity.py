@@ -121,6 +121,23 @@ def test_mimic_joints(hostsim_lib):
     pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
+def test_no_active_variable(hostsim_lib, pr2):
+    """every joint of the group fixed (BioIKKinematicsQueryOptions::fixed_joints, problem.cpp:104-114): D = 0, the solve runs its
+    budget and returns the seed, as the oracle does"""
+    from bio_ik_amd import PoseGoal
+    t0 = ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")])
+    names = [pr2.variable_names[v] for v in HipSolver(t0, lib=hostsim_lib).active_variables]
+    t = ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")], fixed_joints=names)
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    assert h.D == o.D == 0
+    seeds, params = np.tile(pr2.default_positions(), (2, 1)), np.tile(t.pack_params(), (2, 1))
+    for pop, fk in ((16, abi.FK_EXACT), (128, abi.FK_EXACT), (16, abi.FK_LINEAR)):
+        p = abi.default_solve_params(population=pop, max_steps=2, random_seed=1, fk_mode=fk)
+        got, want = h.solve_batch(p, seeds, params), o.solve_batch(p, orc.RNG_COUNTER, seeds, params)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert np.array_equal(got[0], seeds) and not got[2].any()
+
+
 def test_streamed_fitness(sims, oracles, templates):
     """bioik_stream_fitness_device (genes [unit][D][pop] -> fitness [unit][pop]): odd
     tails, several blocks per unit, a tree with parked branch frames; in the host simulator device pointers are host pointers"""
