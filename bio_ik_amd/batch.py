@@ -25,10 +25,19 @@ class _Shard:
     pass
 
 
+def _rank_world(group):
+    """(rank, world) of the process group; a process without torch.distributed (one GPU, no launcher) is rank 0 of 1 and the
+    collectives below degenerate to local copies"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1, False
+    return dist.get_rank(group), dist.get_world_size(group), True
+
+
 def _scatter(solver, seeds, goal_params, dev, group):
     import torch
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world, live = _rank_world(group)
     V, P = solver.V, max(solver.P, 1)
     meta = torch.zeros(1, dtype=torch.int64, device=dev)
     if rank == 0:
@@ -36,7 +45,8 @@ def _scatter(solver, seeds, goal_params, dev, group):
         n = seeds.shape[0]
         goal_params = np.ascontiguousarray(goal_params, dtype=np.float64).reshape(n, -1) if solver.P else np.zeros((n, 1))
         meta[0] = n
-    dist.broadcast(meta, src=0, group=group)
+    if live:
+        dist.broadcast(meta, src=0, group=group)
     s = _Shard()
     s.solver, s.V, s.P = solver, V, P
     s.n = int(meta.item())
@@ -44,6 +54,9 @@ def _scatter(solver, seeds, goal_params, dev, group):
     s.cap = max(s.b[r + 1] - s.b[r] for r in range(world))  # equal-size exchange buffers, padded
     s.mine = s.b[rank + 1] - s.b[rank]
     s.first = s.b[rank]
+    if not live:  # single process: the rows go straight to the device, no exchange buffer
+        s.inbuf = torch.from_numpy(np.concatenate([seeds, goal_params], axis=1)).to(dev)
+        return s
     s.inbuf = torch.zeros((s.cap, V + P), dtype=torch.float64, device=dev)
     if rank == 0:
         full = torch.from_numpy(np.concatenate([seeds, goal_params], axis=1))
@@ -63,8 +76,15 @@ def _launch(s, params, dev, stream=None):
     (gloo tests, host-simulator back end) the host-pointer entry point is synchronous."""
     import torch
     V, P = s.V, s.P
-    s.out = torch.zeros((s.cap, V + 3), dtype=torch.float64, device=dev)
     s.stream = stream
+    if dev.type == "cuda":
+        # everything of this shard — the zero-filled result rows included — is allocated and written on the shard's own stream, which
+        # first waits for what the current stream did to the exchange buffer (the scatter): no write is unordered against another
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            s.out = torch.zeros((s.cap, V + 3), dtype=torch.float64, device=dev)
+    else:
+        s.out = torch.zeros((s.cap, V + 3), dtype=torch.float64, device=dev)
     if not s.mine:
         return
     s.solver.set_first_query(s.first)  # read when the launch is enqueued
@@ -92,10 +112,18 @@ def _launch(s, params, dev, stream=None):
 def _gather(s, dev, group):
     import torch
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world, live = _rank_world(group)
     if dev.type == "cuda" and s.stream is not None:
-        torch.cuda.current_stream(dev).wait_stream(s.stream)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(s.stream)
+        for tns in (s.out, getattr(s, "d_seeds", None), getattr(s, "d_par", None), getattr(s, "d_sol", None), getattr(s, "d_fit", None),
+                    getattr(s, "d_suc", None), getattr(s, "d_steps", None)):
+            if tns is not None:
+                tns.record_stream(cur)  # allocated under the shard's stream, consumed (or freed) under the current one
     V = s.V
+    if not live:
+        res = s.out[:s.n].cpu().numpy()
+        return res[:, :V], res[:, V], res[:, V + 1].astype(np.int32), res[:, V + 2].astype(np.int32)
     if rank == 0:
         gathered = [torch.zeros_like(s.out) for _ in range(world)]
         dist.gather(s.out, gather_list=gathered, dst=0, group=group)

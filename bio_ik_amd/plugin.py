@@ -162,7 +162,10 @@ class BioIKKinematicsPlugin:
                 off = template.param_offsets[i]
                 for k in range(n):
                     r = self._base_default if context_states is None else link_transform(m, self._base_link, state[k])
-                    params[k, off:off + 7] = frame_concat(r, poses[k, i])
+                    f = frame_concat(r, poses[k, i])
+                    q = f[3:7]
+                    f[3:7] = q * (1.0 / np.sqrt(float(q @ q)))  # PoseGoal::setOrientation (goal_types.h:146, tf2 normalized()), :543-544
+                    params[k, off:off + 7] = f
         sp = self._solve_params()
         sol = np.zeros_like(state)
         fit = np.zeros(n)

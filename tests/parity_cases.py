@@ -3,12 +3,27 @@ host-simulator suite (tests/test_hostsim_parity.py, same kernel bodies built for
 
 `h` is a bio_ik_amd.solver.HipSolver, `o` an oracle.orc.Oracle of the same problem template.  The oracle must be in
 trig mode 1 (bioik_sincos shared with the device) wherever bit-exactness is asserted."""
+import contextlib
+
 import numpy as np
 
 from bio_ik_amd import abi
 from bio_ik_amd.workload import make_queries
 from conftest import random_configuration
 from oracle import orc
+
+
+@contextlib.contextmanager
+def oracle_arithmetic(mode):
+    """Run a block with the oracle in arithmetic mode 0 (the reference's own expressions + libm: the mode in which the oracle is
+    pinned bit for bit against the reference's code, tests/test_oracle_vs_reference.py) or 1 (bioik_sincos + the fused forms the
+    device evaluates); restores the previous mode."""
+    prev = int(orc.lib().orc_get_trig_mode())
+    orc.set_trig_mode(mode)
+    try:
+        yield
+    finally:
+        orc.set_trig_mode(prev)
 
 
 def assert_same_structure(h, o):

@@ -172,11 +172,13 @@ def test_full_batch_c2_result_level(gpus, oracles, templates):
     """BASELINE.json configs[1]: 4096 PoseGoals, pop=128.  FK -> IK -> FK round trip (reference README.md:404-447)."""
     h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
     n = 4096
-    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=0xB101C)
+    with pc.oracle_arithmetic(0):  # goal poses from the reference-pinned arithmetic, not from the device's own FK
+        seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=0xB101C)
     p = abi.default_solve_params(population=128, max_steps=64, random_seed=1)
     sol, fit, suc, steps = h.solve_batch(p, seeds, params)
     assert suc.mean() >= 0.99
-    perr, rerr = pc.pose_errors(o, sol, params)
+    with pc.oracle_arithmetic(0):  # ... and the returned poses verified under it
+        perr, rerr = pc.pose_errors(o, sol, params)
     assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
     info = o.robot_info()
     bounded = info[:, 1] != np.finfo(float).max
@@ -196,18 +198,44 @@ def test_full_batch_c3_c4_result_level(gpus, oracles, templates):
     """configs[2] (two tips + MinimalDisplacement) and configs[3] (31-DOF snake + AvoidJointLimits, pop=512)"""
     for cfg, pop, n, max_steps, min_rate in (("c3", 128, 4096, 64, 0.3), ("c4", 512, 4096, 64, 0.99)):
         h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
-        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=0xB101C)
+        with pc.oracle_arithmetic(0):
+            seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=0xB101C)
         p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=1)
         sol, fit, suc, steps = h.solve_batch(p, seeds, params)
         assert suc.mean() >= min_rate
         off = 0
         for tip in range(h.T):
-            perr, rerr = pc.pose_errors(o, sol, params, tip=tip, off=off)
+            with pc.oracle_arithmetic(0):
+                perr, rerr = pc.pose_errors(o, sol, params, tip=tip, off=off)
             assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
             off += 8
         k = 8
         so = o.solve_batch(p, orc.RNG_COUNTER, seeds[:k], params[:k], n_threads=8)
         assert np.array_equal(so[0], sol[:k]) and np.array_equal(so[2], suc[:k])
+
+
+def test_full_size_mixed_batch_on_one_gpu(gpus, oracles, templates):
+    """BASELINE.json configs[4] on the one GPU of this box: a mixed batch of 8192 queries — 4096 PR2 right-arm (pop=128) and 4096
+    31-DOF snake (pop=512) — sorted by model into two homogeneous blocks that bio_ik_amd.batch.solve_mixed runs concurrently on two
+    HIP streams with all arrays resident in HBM.  Every block must come back bit-identical to its own solve."""
+    import torch
+    from bio_ik_amd.batch import solve_mixed
+    blocks, want = [], []
+    for cfg, pop, max_steps in (("c2", 128, 64), ("c4", 512, 32)):
+        h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+        with pc.oracle_arithmetic(0):
+            seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 4096, seed=0xB101C + pop)
+        p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=3)
+        blocks.append((h, p, seeds, params))
+        want.append(h.solve_batch(p, seeds, params))
+    got = solve_mixed(blocks, device="cuda:0")
+    torch.cuda.synchronize()
+    for (h, p, seeds, params), g, w in zip(blocks, got, want):
+        assert all(np.array_equal(a, b) for a, b in zip(g, w))
+        assert g[2].mean() > 0.98
+        with pc.oracle_arithmetic(0):
+            perr, rerr = pc.pose_errors(oracles["c2" if h is gpus["c2"] else "c4"], g[0], params)
+        assert perr[g[2] == 1].max() < POS_TOL and rerr[g[2] == 1].max() < ROT_TOL
 
 
 def test_sharded_batch_equals_whole_batch(gpus, templates):

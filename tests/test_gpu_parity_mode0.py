@@ -1,0 +1,76 @@
+"""The HIP path against the oracle in ARITHMETIC MODE 0 — the reference's own unfused expressions with libm sin / cos, i.e. the
+mode in which the oracle is pinned bit for bit against the reference's code (tests/test_oracle_vs_reference.py).
+
+tests/test_gpu_parity.py compares the device with the oracle's "device arithmetic" mode 1, bit for bit; that mode shares two
+headers with the product (csrc/bioik_fused.h, csrc/bioik_sincos.h), so an error inside those headers would pass there.  Here
+nothing is shared: device FK / fitness / approximator tables / success flags against the reference-pinned arithmetic within
+1e-12 (frames, tables) and 1e-10 relative (fitness), and result-level checks whose goals come from the mode-0 oracle FK and whose
+returned poses are verified under the mode-0 oracle FK."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from bio_ik_amd import ProblemTemplate, abi
+from bio_ik_amd.workload import make_queries
+from conftest import gnarly_goals, mimic_robot
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ROT_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def reference_arithmetic():
+    with pc.oracle_arithmetic(0):
+        yield
+
+
+@pytest.fixture(scope="module")
+def gpus(templates):
+    from bio_ik_amd.solver import HipSolver, device_count
+    assert device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return {k: HipSolver(t, device=0) for k, t in templates.items()}
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_function_level_against_reference_arithmetic(gpus, oracles, templates, cfg):
+    assert orc.lib().orc_get_trig_mode() == 0
+    pc.function_level(gpus[cfg], oracles[cfg], templates[cfg].model, np.random.default_rng(31), n=2000, frame_tol=1e-12, fit_rtol=1e-10)
+
+
+def test_function_level_gnarly_and_mimic_against_reference_arithmetic(gnarly):
+    from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
+    from bio_ik_amd.solver import HipSolver
+    t = ProblemTemplate(gnarly, "body", gnarly_goals())
+    pc.function_level(HipSolver(t), orc.Oracle(t), gnarly, np.random.default_rng(32), n=1500, frame_tol=1e-12, fit_rtol=1e-10)
+    m = mimic_robot()
+    sec = MinimalDisplacementGoal(weight=0.5)
+    sec.secondary_ = True
+    t = ProblemTemplate(m, "arm", [PoseGoal("tool"), PositionGoal("finger_r_tip", weight=0.3), sec])
+    pc.function_level(HipSolver(t), orc.Oracle(t), m, np.random.default_rng(33), n=500, frame_tol=1e-12, fit_rtol=1e-10)
+
+
+@pytest.mark.parametrize("cfg,pop,max_steps,min_rate", [("c2", 128, 64, 0.99), ("c3", 128, 64, 0.3), ("c4", 512, 32, 0.98)])
+def test_full_batch_result_level_goals_and_poses_from_reference_arithmetic(gpus, oracles, templates, cfg, pop, max_steps, min_rate):
+    """BASELINE.json configs[1..3] at full size.  Nothing of the device takes part in building or checking the round trip: the goal
+    poses are the mode-0 oracle FK of the target configurations, and every reported success must reproduce them under the mode-0
+    oracle FK within the north-star tolerance."""
+    h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+    n = 4096
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=0xB101C)
+    p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=1)
+    sol, fit, suc, steps = h.solve_batch(p, seeds, params)
+    assert suc.mean() >= min_rate
+    off = 0
+    for tip in range(h.T):
+        perr, rerr = pc.pose_errors(o, sol, params, tip=tip, off=off)
+        assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+        off += 8
+    # the reported fitness (ik_parallel.h:229-246: primary, plus secondary for a success when secondary goals exist) is the mode-0
+    # oracle's fitness of the returned configuration, to rounding
+    has_sec = any(g.isSecondary() for g in t.goals)
+    for i in np.nonzero(suc)[0][:64]:
+        prim, sec = o.fitness(abi.FK_EXACT, seeds[i], params[i], sol[i][o.active_variables][None, :])
+        want = prim[0] + (sec[0] if has_sec else 0.0)
+        assert abs(want - fit[i]) <= 1e-6 * abs(want) + 1e-22, (cfg, i, want, fit[i])

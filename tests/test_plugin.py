@@ -59,6 +59,23 @@ def test_search_position_ik_round_trip(plugin, pr2):
     assert plugin.searchPositionIK([pose], list(seed), 0.005, [], MoveItErrorCodes(), solution_callback=reject) is False
 
 
+def test_pose_quaternion_is_normalised_like_set_orientation(plugin, pr2):
+    """geometry_msgs orientations are rarely exactly unit: PoseGoal::setOrientation normalises (goal_types.h:146, called at
+    kinematics_plugin.cpp:543-544), so a scaled quaternion must give the same solve as the unit one"""
+    rng = np.random.default_rng(12)
+    target = pr2.default_positions()
+    gv = plugin._group_vars
+    target[gv] = random_configuration(pr2, rng)[gv]
+    pose = goal_in_base_frame(pr2, target)
+    seed = list(np.clip(target[gv] + 0.2 * rng.normal(size=len(gv)), np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv]))
+    scaled = pose.copy()
+    scaled[3:] *= 2.0
+    a, b = [], []
+    assert plugin.searchPositionIK([pose], seed, 0.005, a, MoveItErrorCodes()) is True
+    assert plugin.searchPositionIK([scaled], seed, 0.005, b, MoveItErrorCodes()) is True
+    assert np.allclose(a, b, atol=1e-9)
+
+
 def test_unreachable_goal_error_codes(plugin, pr2):
     far = np.array([5.0, 5.0, 5.0, 0, 0, 0, 1.0])
     seed = list(pr2.default_positions()[plugin._group_vars])
