@@ -75,8 +75,22 @@ BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p
 // post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
 enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4 };
-// random words of child c in one generation: word w = output (w & 1) of Philox(key, ctr0(c, w >> 1), ctr1);
-// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g (two genes per Philox call)
+// Random words of child c in one generation -- the bulk of all draws, 1 + D words per child -- come from a two-multiply
+// avalanche hash of the counter instead of Philox (a Philox2x32-10 call is twenty 32-bit multiplies, and an integer multiply
+// costs 2.4 issue slots of an FP64 FMA on gfx950: profiles/r01_gfx950_latency_microbench.log):
+//     word w = mix32( ((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77) ),   mix32 = MurmurHash3's 32-bit finaliser
+// The stream value mix32(key ^ ...) is wavefront-uniform (scalar unit), (c << 8) * 0x9E3779B1 is per child, w * 0x9E3779B1 per
+// word and uniform: a word costs one add and the finaliser.  Word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g.
+// Philox2x32-10 keeps the control draws (query key, pre-selection count, memetic sign, wipe-out).
+BIOIK_DEV uint32_t rng_mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+BIOIK_DEV uint32_t rng_child_stream(uint32_t key, uint32_t ctr1) { return rng_mix32(key ^ (ctr1 * 0x85EBCA77u)); }
 
 BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
 #pragma unroll
@@ -142,12 +156,9 @@ struct XV {
 // goal costs (goal_types.h); joint-set goals walk the active ops.
 // ---------------------------------------------------------------------------------------------------------
 // The link goals beyond position / orientation / pose: one out-of-line copy (sqrt, divisions, acos) instead of one per
-// evaluation site.  p: the goal's numbers (at most 11, goal_types.h), by value.
-struct GoalPar {
-    double v[11];
-};
-BIOIK_CALL double goal_eval_link_rare(int type, GoalPar gp, F7 fb) {
-    const double* P = gp.v;
+// evaluation site.  P: the goal's numbers (at most 11, goal_types.h) where they lie in LDS -- the pointer crosses the call with its
+// address space spelled out, and the 16 argument registers stay inside the 32 the calling convention passes without stack traffic.
+BIOIK_CALL double goal_eval_link_rare(int type, const lds_f64* P, F7 fb) {
     switch (type) {
         case G_LOOK_AT: {  // :204-211
             V3 axis = qrot(fb.q, v3(P[0], P[1], P[2]));
@@ -249,15 +260,6 @@ BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int v
 BIOIK_CALL double goal_eval_joint_set(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
     return goal_eval_joint_set_inl(pb, type, var_op, var_seed, p0, xp, xs, seed);
 }
-BIOIK_DEV int goal_param_count(int type) {  // include/bioik_hip.h bioik_goal_param_count
-    switch (type) {
-        case G_LOOK_AT: case G_LINE: case G_PLANE: case G_SIDE: case G_DIRECTION: return 6;
-        case G_MAX_DISTANCE: case G_MIN_DISTANCE: return 4;
-        case G_CONE: return 11;
-    }
-    return 0;
-}
-
 // JS_INLINE: the goals over the joint values are inlined (the one hot site: secondary fitness of every child in the pre-selection)
 template <bool JS_INLINE = false>
 BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
@@ -286,13 +288,8 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             if (JS_INLINE)
                 return goal_eval_joint_set_inl(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
             return goal_eval_joint_set(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
-        default: {  // the remaining link goals
-            GoalPar gp;
-            const int np = goal_param_count(type);
-#pragma unroll
-            for (int i = 0; i < 11; i++) gp.v[i] = i < np ? P[i] : 0.0;
-            return goal_eval_link_rare(type, gp, fb);
-        }
+        default:  // the remaining link goals
+            return goal_eval_link_rare(type, (const lds_f64*)P, fb);
     }
     return 0.0;
 }
@@ -836,8 +833,8 @@ BIOIK_DEV void philox2x32_10_xm(uint32_t key, const uint32_t (&c0in)[M], uint32_
 }
 
 // Reproduction (ik_evolution_2.cpp:242-326) of N children of one lane at once (same parents, same generation): per trip
-// 4 x N interleaved Philox streams = 8 random words per child (the rate exponent + 7 genes in the first trip, 8 genes in
-// the following ones), the parents' genes / momentum and the joint limits loaded once per gene for all N.  Free of
+// 8 random words per child (the rate exponent + 7 genes in the first trip, 8 genes in the following ones), each one hash of
+// the child's counter, the parents' genes / momentum and the joint limits loaded once per gene for all N.  Free of
 // divergent branches (padding words past the last gene recompute gene D-1 and are not stored).  `go` (optional): momentum
 // of child 0 (:299).
 template <int N, class PB>
@@ -852,17 +849,14 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
         gradient_factor[i] = (double)(child_index[i] % 3u);
         mutation_rate[i] = 0.0;
     }
+    const uint32_t stream = rng_child_stream(key, ctr1);
+    uint32_t base[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) base[i] = (child_index[i] << 8) * 0x9E3779B1u + stream;
     for (int w0 = 0; D > 0 && w0 <= D; w0 += 8) {  // (a problem whose variables are all fixed has no gene to draw)
-        uint32_t c0[4 * N], q0[4 * N], q1[4 * N];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-            for (int i = 0; i < N; i++) c0[i * 4 + j] = rng_ctr0(child_index[i], (uint32_t)((w0 >> 1) + j));
-        }
-        philox2x32_10_xm<4 * N>(key, c0, ctr1, q0, q1);
         if (w0 == 0) {
 #pragma unroll
-            for (int i = 0; i < N; i++) mutation_rate[i] = (double)(1u << (q0[i * 4] & 15u)) * (1.0 / (double)(1 << 23));
+            for (int i = 0; i < N; i++) mutation_rate[i] = (double)(1u << (rng_mix32(base[i]) & 15u)) * (1.0 / (double)(1 << 23));
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -879,7 +873,7 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
                 const double parent_gene = p0g[k], d0 = p0d[k], d1 = p1d[k];
 #pragma unroll
                 for (int i = 0; i < N; i++) {
-                    const uint32_t word = (w & 1) ? q1[i * 4 + (w >> 1)] : q0[i * 4 + (w >> 1)];
+                    const uint32_t word = rng_mix32(base[i] + (uint32_t)(w0 + w) * 0x9E3779B1u);
                     double r = rng_gauss32(word);
                     double f = mutation_rate[i] * span;
                     double gn = parent_gene;
@@ -994,8 +988,13 @@ BIOIK_DEV double angle_shortest_path(Q4 a, Q4 b) {  // tf2::Quaternion::angleSho
 
 // position / orientation / pose goals (problem.cpp:270-323): one out-of-line copy of the KDL-equivalent twist arithmetic
 // (sqrt, atan2, acos, divisions) for all the success-test sites; values in, value out
-BIOIK_CALL int check_frame_goal(int type, F7 fa, F7 fb, double dpos, double drot, double dtwist) {
+// (the goal's numbers travel as a pointer into the query's LDS parameters: 22 argument registers, no stack traffic)
+BIOIK_CALL int check_frame_goal(int type, const lds_f64* P, F7 fb, double dpos, double drot, double dtwist) {
     bool ok = true;
+    F7 fa = f7_identity();
+    if (type == G_POSITION) fa.p = v3(P[0], P[1], P[2]);
+    else if (type == G_ORIENTATION) fa.q = Q4{P[0], P[1], P[2], P[3]};
+    else fa = F7{{P[0], P[1], P[2]}, {P[3], P[4], P[5], P[6]}};
     if (type == G_POSITION) {
         if (dpos != BIOIK_DBL_MAX) ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
         if (dtwist != BIOIK_DBL_MAX) {
@@ -1028,17 +1027,8 @@ BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const Qu
     const int type = pb->primary[g].type;
     const double* P = qc.par + pb->primary[g].param_off;
     bool ok = true;
-    if (type == G_POSITION) {
-        F7 fa = f7_identity();
-        fa.p = v3(P[0], P[1], P[2]);
-        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
-    } else if (type == G_ORIENTATION) {
-        F7 fa = f7_identity();
-        fa.q = Q4{P[0], P[1], P[2], P[3]};
-        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
-    } else if (type == G_POSE) {
-        F7 fa = F7{{P[0], P[1], P[2]}, {P[3], P[4], P[5], P[6]}};
-        ok = check_frame_goal(type, fa, fb, dpos, drot, dtwist) != 0;
+    if (type == G_POSITION || type == G_ORIENTATION || type == G_POSE) {
+        ok = check_frame_goal(type, (const lds_f64*)P, fb, dpos, drot, dtwist) != 0;
     } else {
         double dmax = fmin(BIOIK_DBL_MAX, fmin(dpos, dtwist));
         double d = goal_eval(pb, type, pb->primary[g].var_op, pb->primary[g].var_seed, P, fb, x, qc) * pb->primary[g].weight_sq;

@@ -23,8 +23,9 @@
 #endif
 
 struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species group (stride g_stride)
-    int seed, par, pop, sol, prefix, state, xcol, slots, g_first, g_stride, total;
+    int seed, par, pop, sol, prefix, state, clip, xcol, slots, g_first, g_stride, total;
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
+    int xm, xp, dv, fc;  // memetic phase (per group): support points x -+ g, gene displacements [4][m], tip-frame components [4][T*8]
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
                                int groups = 1, int slot_sets = 1) {
@@ -37,6 +38,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.sol = o, o += m;
     L.prefix = o, o += 8;               // frame behind the leading non-gene joints (DevProblem::n_prefix), per query
     L.state = o, o += 2 * 8 + 4;        // species bookkeeping exchanged between the two species groups + workgroup broadcast slots
+    L.clip = o, o += 2 * m;             // RobotInfo clip_min | clip_max per op (robot_info.h:109-113), staged once per query
     L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
     int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
@@ -47,6 +49,11 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.delta = g, g += T * m * 7;
     L.base = g, g += m;
     L.grad = g, g += m;
+    L.xm = g, g += m;
+    L.xp = g, g += m;
+    L.dv = g, g += 4 * m;
+    g += g & 1;  // (two-double alignment of the component blocks)
+    L.fc = g, g += 4 * 8 * (T > 0 ? T : 1);
     // has_secondary == 2: the pre-selection scratch of the generation loop shares the space of the memetic phase's vectors and
     // linear model (exact-FK generations never read the linear model, and both are rebuilt before every use)
     const int n_sec = has_secondary ? lambda : 0, n_order = has_secondary ? (lambda + 1) / 2 : 0;
@@ -228,6 +235,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     double* s_delta = gbase + L.delta;
     double* s_base = gbase + L.base;
     double* s_grad = gbase + L.grad;
+    double* s_xm = gbase + L.xm;
+    double* s_xp = gbase + L.xp;
+    double* s_dv = gbase + L.dv;
+    double* s_fc = gbase + L.fc;
+    double* s_clip = lds + L.clip;
     double* s_red = gbase + L.red;
     double* s_sec = gbase + L.sec;
     int32_t* s_order = (int32_t*)(gbase + L.order);
@@ -298,6 +310,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 d[k] = v, d[M + k] = 0.0;
             }
         s_sol[k] = v;
+        s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
     }
     p_barrier();
     if (pb->n_prefix > 0) {  // the joints in front of the first gene see the seed in every individual: walk them once per query
@@ -449,115 +462,177 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 PHASE_MARK(PH_SEL_BAR);
             }
 
-            // memetic phase on the elite (:436-570).  The workgroup barriers inside are executed a fixed number of times
-            // per iteration whether or not this species is still descending, so that two species groups stay in step.
+            // memetic phase on the elite (:436-570): finite-difference gradient of the linearised fitness, L1 normalisation, three-point
+            // line search, clipped candidate, acceptance on primary fitness; up to 8 iterations.
+            // One wavefront (the group's leading one; a half-wave group: its half) does the whole phase, and its lanes take three roles:
+            //   op lane k        owns op k of the vectors involved (the elite, the support points x -+ g, the candidate) and their
+            //                    displacements from the linearisation point, dv[k] = x[k] - base[k]
+            //   component lane   (t, c) runs the first-order model for ONE component c of ONE tip frame t: the chain
+            //                    F[t][c] = tipbase[t][c] + sum over the genes, in gene order, of delta[t][gene][c] * dv[gene]
+            //                    -- the same fused multiply-adds in the same order as linear_tip, 1/7 of them per lane
+            //   every lane       then reads the finished frames and evaluates the goals: lane i < D on the frame advanced by
+            //                    delta[.][gene i] * dp (its gradient entry), lane D on the frame itself; the support points on even / odd
+            //                    lanes; the candidate on all lanes alike (scalars of the line search are carried redundantly)
+            // Hand-overs are LDS writes and reads of one wavefront in program order (p_wave_sync): no s_barrier inside the phase, so a
+            // species stops as soon as a candidate is rejected, whatever the other species' wavefront is doing.
             if (sp.memetic) {
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
                 if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);  // fresh linearisation at the elite
                 PHASE_MARK(PH_MEM_APPROX);
-                double dp = 0.0000001;
-                {
-                    uint32_t o0, o1;
-                    philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)S.id, RNG_MEMETIC_SIGN), o0, o1);
-                    if (rng_uniform(o0, o1) < 0.5) dp = -dp;
-                }
-                const int my_op = gtid < D ? pb->op_of_gene[gtid] : -1;  // lane i of the group differentiates gene i
-                // gradient in op order (zero for the ops that are not genes), next to the gene-ordered copy the L1 norm sums
-                double* s_gop = s_gv;
-                for (int k = gtid; k < n_ops; k += G) s_gop[k] = 0.0;
-                group_sync(G);
-                const double* cand = (lds + L.xcol) + grp * G;  // the line-search candidate: column of the group's lane 0
-                bool live = true;  // still descending; the leading wavefront of the group does the arithmetic
-                const int lane0 = G < 64 ? (lane & ~(G - 1)) : 0;  // first lane of the group inside its wavefront
-                for (int it = 0; it < 8; it++) {
-                    double f2p = 0.0, fa = 0.0;
-                    if (live) PHASE_COUNT(PH_N_MEM_ITER);
-                    // One evaluation per lane: lane i < D scores the elite with gene i advanced by dp (computeApproximateMutation1 on the
-                    // tip frames), every other lane the elite itself (its column is the unperturbed elite, its delta zero); the base
-                    // values are then taken from lane D of the group.
-                    double vprim = 0.0, vall = 0.0;
-                    if (live && glead) {
-                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
+                if (gtid < 64) {
+                    const int Gw = G < 64 ? G : 64;  // lanes at work
+                    double dp = 0.0000001;
+                    {
+                        uint32_t o0, o1;
+                        philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)S.id, RNG_MEMETIC_SIGN), o0, o1);
+                        if (rng_uniform(o0, o1) < 0.5) dp = -dp;
+                    }
+                    const bool xgoals = pb->n_primary > pb->n_link_primary || pb->n_secondary > 0;  // goals that read the joint values
+                    const bool by_op = pb_flavour<PB>::general ? pb->genes_follow_ops != 0 : true;
+                    const int cnt = by_op ? n_ops : D;
+                    const int my_op = gtid < D ? pb->op_of_gene[gtid] : -1;  // lane i differentiates gene i, lane D holds the elite itself
+                    double* s_gop = s_gv;  // gradient in op order (zero for the ops that are not genes), next to the gene-ordered s_grad
+                    const int FB = 8 * T;
+                    double* s_x4 = s_xn;
+                    double* s_ex = s_bc;  // values exchanged between lanes: [0] primary, [1] all goals at the elite, [2] / [3] f(x - g) / f(x + g)
+                    // component lanes: one or two chains (same delta entries, two displacement vectors), four entries per trip
+                    auto chains = [&](const double* d0, double* f0, const double* d1, double* f1) {
+                        for (int idx = gtid; idx < FB; idx += Gw) {
+                            const int t = idx >> 3, c = idx & 7;
+                            if (c == 7) continue;
+                            double a0 = s_tips[t * 7 + c], a1 = a0;
+                            const double* dl = s_delta + (size_t)t * n_ops * 7 + c;
+                            for (int g0 = 0; g0 < cnt; g0 += 4) {
+                                double d[4], v0[4], v1[4];
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const int i2 = g0 + j < cnt ? g0 + j : cnt - 1;
+                                    const int kk = by_op ? i2 : pb->op_of_gene[i2];
+                                    const bool pad = g0 + j >= cnt;
+                                    d[j] = dl[(size_t)kk * 7];
+                                    v0[j] = pad ? 0.0 : d0[kk];
+                                    v1[j] = (pad || !d1) ? 0.0 : d1[kk];
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    a0 = BK_FMA(d[j], v0[j], a0);
+                                    if (d1) a1 = BK_FMA(d[j], v1[j], a1);
+                                }
+                            }
+                            f0[idx] = a0;
+                            if (d1) f1[idx] = a1;
+                        }
+                    };
+                    auto frame_of = [&](const double* fc, int t) { return f7_load(fc + t * 8); };
+                    // goal fitness of the lane's frames `fc` (+ its gene's delta * step): (primary, all goals); x: what joint-value goals read
+                    auto goals_on = [&](const double* fc, int dop, double dstep, const XV& x, double& prim, double& all) {
                         double acc = 0.0;
                         for (int t = 0; t < T; t++) {
-                            const F7 f = linear_tip(pb, t, xe, lm);
-                            double d[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                            if (my_op >= 0) {
-                                const double* dl = s_delta + ((size_t)t * n_ops + my_op) * 7;
-                                for (int c = 0; c < 7; c++) d[c] = dl[c];
+                            F7 f = frame_of(fc, t);
+                            if (dstep != 0.0) {
+                                double d[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                                if (dop >= 0) {
+                                    const double* dl = s_delta + ((size_t)t * n_ops + dop) * 7;
+                                    for (int c = 0; c < 7; c++) d[c] = dl[c];
+                                }
+                                f = F7{{BK_FMA(d[0], dstep, f.p.x), BK_FMA(d[1], dstep, f.p.y), BK_FMA(d[2], dstep, f.p.z)},
+                                       {BK_FMA(d[3], dstep, f.q.x), BK_FMA(d[4], dstep, f.q.y), BK_FMA(d[5], dstep, f.q.z), BK_FMA(d[6], dstep, f.q.w)}};
                             }
-                            const F7 f3 = F7{{BK_FMA(d[0], dp, f.p.x), BK_FMA(d[1], dp, f.p.y), BK_FMA(d[2], dp, f.p.z)},
-                                             {BK_FMA(d[3], dp, f.q.x), BK_FMA(d[4], dp, f.q.y), BK_FMA(d[5], dp, f.q.z), BK_FMA(d[6], dp, f.q.w)}};
-                            acc += tip_goals(pb, t, f3, xl, qc);
+                            acc += tip_goals(pb, t, f, x, qc);
                         }
-                        acc += nonlink_primary(pb, xl, qc);
-                        vprim = acc;
-                        vall = acc + secondary_fitness(pb, xl, qc);
-                    }
-                    if (G < 64 || (live && glead)) {  // (a half-wave group shares its wavefront: every lane executes the shuffle)
-                        f2p = p_shfl(vprim, lane0 + D);
-                        fa = p_shfl(vall, lane0 + D);
-                    }
-                    if (live && glead && my_op >= 0) {
-                        s_grad[gtid] = vall - fa;
-                        s_gop[my_op] = vall - fa;
-                    }
-                    group_sync(G);
-                    PHASE_MARK(PH_MEM_GRAD);
-                    // From here every lane of the leading wavefront carries the whole line search redundantly in its own
-                    // genotype column (no hand-over through LDS, no rendezvous): L1 norm (:477-482), the two support points
-                    // x-g (even lanes) / x+g (odd lanes) (:485-495), the step (:498-568), the clipped candidate and its fitness.
-                    double fnorm = 0.0, fl = 0.0;
-                    if (live && glead) {
-                        double sum = dp * dp;
-                        for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
-                        fnorm = 1.0 / sum * dp;
-                        PHASE_MARK(PH_MEM_NORM);
-                        const double sgn = (lane & 1) ? 1.0 : -1.0;
-                        for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = el[k] + sgn * (s_gop[k] * fnorm);
-                        PHASE_MARK(PH_MEM_SUPPORT_COLS);
-                        fl = eval_linear_primary(pb, xl, qc, lm) + secondary_fitness(pb, xl, qc);
-                        PHASE_MARK(PH_MEM_SUPPORT_EVAL);
-                    }
-                    // f(x-g) and f(x+g) sit in the group's first two lanes.  A half-wave group shares its wavefront with the other
-                    // species, which may have stopped descending: there every lane of the wavefront executes the shuffle.
-                    double f1 = 0.0, f3 = 0.0;
-                    if (G < 64 || (live && glead)) f1 = p_shfl(fl, lane0), f3 = p_shfl(fl, lane0 + 1);
-                    if (live && glead) {
-                        const double f2 = fa;
-                        double step_size;
-                        if (sp.memetic == 'q') {  // :498-539
-                            double v1 = f2 - f1, v2 = f3 - f2;
-                            double v = (v1 + v2) * 0.5, aa = v1 - v2;
-                            step_size = v / aa;
-                        } else {  // 'l' :545-568
-                            double cost_diff = (f3 - f1) * 0.5;
-                            step_size = -(f2 / cost_diff);
+                        acc += nonlink_primary(pb, x, qc);
+                        prim = acc;
+                        all = acc + secondary_fitness(pb, x, qc);
+                    };
+                    for (int k = gtid; k < n_ops; k += Gw) s_gop[k] = 0.0;
+                    const bool odd = gtid & 1;
+                    bool descending = true;
+                    for (int it = 0; it < 8 && descending; it++) {
+                        PHASE_COUNT(PH_N_MEM_ITER);
+                        // three rounds of the same shape -- op lanes prepare displacement vectors, component lanes run the chains, every
+                        // lane evaluates the goals on its frames -- written as one loop so that each piece of code exists once:
+                        //   round 0  gradient (:450-475): D + 1 evaluations, one per lane
+                        //   round 1  L1 normalisation (:477-482) and the two support points x - g (even lanes), x + g (odd lanes) (:485-495)
+                        //   round 2  step along the gradient (:498-568), clipped candidate, acceptance on primary fitness
+                        double f2p = 0.0, fa = 0.0, fnorm = 0.0;
+                        for (int round = 0; round < 3; round++) {
+                            double* dv0 = s_dv + (round == 0 ? 0 : round == 1 ? 1 : 3) * M;
+                            double* fc0 = s_fc + (round == 0 ? 0 : round == 1 ? 1 : 3) * FB;
+                            if (round == 0) {
+                                for (int k = gtid; k < n_ops; k += Gw) dv0[k] = ((active_mask >> k) & 1ull) ? el[k] - s_base[k] : 0.0;
+                            } else if (round == 1) {
+                                double sum = dp * dp;
+                                for (int i = 0; i < D; i++) sum += fabs(s_grad[i]);
+                                fnorm = 1.0 / sum * dp;
+                                PHASE_MARK(PH_MEM_NORM);
+                                for (int k = gtid; k < n_ops; k += Gw) {
+                                    const double e = el[k], g = s_gop[k] * fnorm, b = s_base[k];
+                                    const bool on = (active_mask >> k) & 1ull;
+                                    const double xm = e - g, xp = e + g;
+                                    s_xm[k] = xm, s_xp[k] = xp;
+                                    dv0[k] = on ? xm - b : 0.0;
+                                    dv0[M + k] = on ? xp - b : 0.0;
+                                }
+                            } else {
+                                const double f1 = s_ex[2], f3 = s_ex[3], f2 = fa;
+                                double step_size;
+                                if (sp.memetic == 'q') {  // :498-539
+                                    double v1 = f2 - f1, v2 = f3 - f2;
+                                    double v = (v1 + v2) * 0.5, aa = v1 - v2;
+                                    step_size = v / aa;
+                                } else {  // 'l' :545-568
+                                    double cost_diff = (f3 - f1) * 0.5;
+                                    step_size = -(f2 / cost_diff);
+                                }
+                                for (int k = gtid; k < n_ops; k += Gw) {
+                                    const double e = el[k], gv = s_gop[k] * fnorm;
+                                    const bool on = (active_mask >> k) & 1ull;
+                                    const double x4 = on ? fmin(fmax(e + gv * step_size, s_clip[k]), s_clip[M + k]) : e;
+                                    s_x4[k] = x4;
+                                    dv0[k] = on ? x4 - s_base[k] : 0.0;
+                                }
+                            }
+                            p_wave_sync();
+                            PHASE_MARK(PH_MEM_SUPPORT_COLS);
+                            chains(dv0, fc0, round == 1 ? dv0 + M : nullptr, fc0 + FB);
+                            XV xq = XV{round == 2 ? s_x4 : (odd ? s_xp : s_xm), 1};
+                            if (round == 0) {
+                                xq = xe;
+                                if (xgoals) {  // the lane's own vector (the elite with its gene advanced by dp), as a column
+                                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
+                                    xq = xl;
+                                }
+                            }
+                            p_wave_sync();
+                            double vprim, vall;
+                            goals_on(fc0 + ((round == 1 && odd) ? FB : 0), round == 0 ? my_op : -1, round == 0 ? dp : 0.0, xq, vprim, vall);
+                            PHASE_MARK(PH_MEM_SUPPORT_EVAL);
+                            if (round == 0) {
+                                if (gtid == D) s_ex[0] = vprim, s_ex[1] = vall;
+                                p_wave_sync();
+                                f2p = s_ex[0], fa = s_ex[1];
+                                if (my_op >= 0) {
+                                    s_grad[gtid] = vall - fa;
+                                    s_gop[my_op] = vall - fa;
+                                }
+                                p_wave_sync();
+                                PHASE_MARK(PH_MEM_GRAD);
+                            } else if (round == 1) {
+                                if (gtid < 2) s_ex[2 + gtid] = vall;
+                                p_wave_sync();
+                            } else {
+                                const bool accept = vprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
+                                // (a half-wave group shares its wavefront with the other species: it stays in step with it and merely
+                                // repeats the rejected iteration, which changes nothing)
+                                if (G >= 64 && !accept) descending = false;
+                                if (accept)
+                                    for (int k = gtid; k < n_ops; k += Gw) el[k] = s_x4[k];
+                                p_wave_sync();
+                                PHASE_MARK(PH_MEM_ACCEPT);
+                            }
                         }
-                        for (int k = 0; k < n_ops; k++) {
-                            const double cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
-                            const double e = el[k], gv = s_gop[k] * fnorm;
-                            xcol[(size_t)k * nth] = ((active_mask >> k) & 1ull) ? fmin(fmax(e + gv * step_size, cmin), cmax) : e;
-                        }
-                        PHASE_MARK(PH_MEM_CANDIDATE);
-                        const double f4p = eval_linear_primary(pb, xl, qc, lm);
-                        if (!(f4p < f2p)) live = false;  // accept iff the primary fitness improves, else stop (:527-538)
                     }
-                    PHASE_MARK(PH_MEM_LINE);
-                    if (G > 64) {  // the other wavefronts of the group learn the verdict
-                        if (gtid == 0) s_bc[1] = live ? 1.0 : 0.0;
-                        p_barrier();
-                        live = s_bc[1] != 0.0;
-                        p_barrier();
-                    } else {
-                        p_wave_sync();  // every lane has read the elite before it is replaced (program order on the device)
-                    }
-                    if (live)
-                        for (int k = gtid; k < n_ops; k += G) el[k] = cand[(size_t)k * nth];
-                    group_sync(G);
-                    PHASE_MARK(PH_MEM_ACCEPT);
-                    if ((groups == 1 || G == 64) && !live) break;  // only groups sharing workgroup barriers must keep each other's count
                 }
                 group_sync(G);
                 PHASE_MARK(PH_MEM_TAIL);

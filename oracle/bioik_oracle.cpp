@@ -340,6 +340,7 @@ void orc_pose_twist(const double* goal7, const double* tip7, double* out6) { kdl
 // ---- counter RNG ----
 void orc_philox2x32(uint32_t key, uint32_t c0, uint32_t c1, uint32_t* out2) { philox2x32_10(key, c0, c1, out2); }
 void orc_philox4x32(const uint32_t* key2, const uint32_t* ctr4, uint32_t* out4) { philox4x32_10(key2, ctr4, out4); }
+uint32_t orc_child_word(uint32_t key, uint32_t ctr1, uint32_t child, uint32_t w) { return child_word_of(child_stream(key, ctr1), child, w); }
 double orc_counter_gauss32(uint32_t word) { return counter_gauss_from32(word); }
 double orc_counter_uniform(uint32_t key, uint32_t c0, uint32_t c1) {
     uint32_t o[2];

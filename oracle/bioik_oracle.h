@@ -99,6 +99,7 @@ void orc_pose_twist(const double* goal7, const double* tip7, double* out6);
 /* ---- counter RNG ---- */
 void orc_philox2x32(uint32_t key, uint32_t c0, uint32_t c1, uint32_t* out2);
 void orc_philox4x32(const uint32_t* key2, const uint32_t* ctr4, uint32_t* out4);
+uint32_t orc_child_word(uint32_t key, uint32_t ctr1, uint32_t child, uint32_t w); /* random word w of a child of the stream (key, ctr1) */
 double orc_counter_gauss32(uint32_t word);  // the Gaussian of one random word (orc_rng.h)
 double orc_counter_uniform(uint32_t key, uint32_t c0, uint32_t c1);
 uint32_t orc_query_key(uint64_t seed, uint64_t query, uint32_t island);

@@ -332,11 +332,16 @@ def counter_gauss32(word, kind="strict"):
     return lib(kind).orc_counter_gauss32(C.c_uint32(word))
 
 
+def child_word(key, ctr1, child, w, kind="strict"):
+    """random word w of child `child` in the stream (key, ctr1): word 0 is the mutation-rate exponent, word 1 + g the Gaussian of gene g"""
+    L = lib(kind)
+    L.orc_child_word.restype = C.c_uint32
+    return int(L.orc_child_word(C.c_uint32(key), C.c_uint32(ctr1), C.c_uint32(child), C.c_uint32(w)))
+
+
 def counter_child_gauss(key, child, gene, ctr1, kind="strict"):
-    """Gaussian of gene `gene` of child `child`: random word 1 + gene of the child's stream (word w = output w & 1 of
-    Philox(key, child << 8 | w >> 1, ctr1); word 0 is the mutation-rate exponent)"""
-    w = gene + 1
-    return counter_gauss32(philox2x32(key, (child << 8) | (w >> 1), ctr1, kind)[w & 1], kind)
+    """Gaussian of gene `gene` of child `child`: from random word 1 + gene of the child's stream"""
+    return counter_gauss32(child_word(key, ctr1, child, gene + 1, kind), kind)
 
 
 def counter_uniform(key, c0, c1, kind="strict"):

@@ -3,8 +3,10 @@
 // (a) ReferenceRandom restates reference src/ik_base.h:49-126 (std::minstd_rand, 8 Mi-entry uniform and
 //     Gaussian tables, XORShift64 index generator of src/utils.h:369-385).
 // (b) CounterRandom is the counter-based generator the device uses: Philox2x32-10
-//     (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 v1.14 constants),
-//     integer-only post-processing so CPU and GPU produce bit-identical doubles.
+//     (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 v1.14 constants) for the control
+//     draws (query key, pre-selection count, memetic sign, wipe-out), a two-multiply avalanche hash of the counter for the
+//     bulk draws of reproduction (one 32-bit word per gene), integer-only post-processing so CPU and GPU produce
+//     bit-identical doubles.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -57,8 +59,22 @@ inline void philox4x32_10(const uint32_t* key2, const uint32_t* ctr4, uint32_t* 
 
 // counter layout and integer->double post-processing
 enum { PURPOSE_REPRODUCE = 0, PURPOSE_PRESELECT = 1, PURPOSE_MEMETIC_SIGN = 2, PURPOSE_WIPEOUT = 3, PURPOSE_WIPEOUT_GENE = 4 };
-// random words of child c in one generation: word w = output (w & 1) of Philox(key, ctr0(c, w >> 1), ctr1);
-// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g (two genes per Philox call)
+// random words of child c in one generation (the bulk of all draws: 1 + D words per child):
+//     word w = mix32( ((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77) )
+// mix32 = the 32-bit finaliser of MurmurHash3 (Appleby, public domain: xor-shift 16, * 0x85EBCA6B, xor-shift 13, * 0xC2B2AE35,
+// xor-shift 16 -- every input bit flips every output bit with probability ~1/2).  The odd multiplier makes the inner value
+// a bijection of (c, w) for a given stream (key, ctr1), so no two words of a generation share their input.
+// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g
+inline uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+inline uint32_t child_stream(uint32_t key, uint32_t ctr1) { return mix32(key ^ (ctr1 * 0x85EBCA77u)); }
+inline uint32_t child_word_of(uint32_t stream, uint32_t child, uint32_t w) { return mix32(((child << 8) + w) * 0x9E3779B1u + stream); }
 
 inline uint32_t ctr0_of(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
 inline uint32_t ctr1_of(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
@@ -93,9 +109,7 @@ struct CounterRandom {
     }
     void reproduce_begin(size_t /*n_total*/, size_t /*gene_count*/) {}
     uint32_t child_word(size_t child_index, uint32_t w) {
-        uint32_t o[2];
-        philox2x32_10(key, ctr0_of((uint32_t)child_index, w >> 1), ctr1_of(generation, species, PURPOSE_REPRODUCE), o);
-        return o[w & 1u];
+        return child_word_of(child_stream(key, ctr1_of(generation, species, PURPOSE_REPRODUCE)), (uint32_t)child_index, w);
     }
     unsigned rate_exponent(size_t child_index) { return child_word(child_index, 0) & 15u; }
     double gauss(size_t child_index, size_t gene) { return counter_gauss_from32(child_word(child_index, (uint32_t)gene + 1u)); }

@@ -100,7 +100,7 @@ def test_pose_twist_matches_rotation_vector():
 
 def test_shared_sincos_accuracy():
     """bioik_sincos (bio_ik_amd/csrc/bioik_sincos.h, evaluated by the kernels and by the oracle's device-arithmetic mode) against
-    long-double sin / cos: <= 1.1 ulp over joint-value ranges and far beyond, including arguments next to multiples of pi/2"""
+    long-double sin / cos: <= 1.6 ulp over joint-value ranges and far beyond, including arguments next to multiples of pi/2"""
     from oracle import orc
     rng = np.random.default_rng(0)
     for scale in (1.0, 4.0, 100.0, 1e5):
@@ -109,5 +109,5 @@ def test_shared_sincos_accuracy():
         xl = x.astype(np.longdouble)
         for got, ref in ((s, np.sin(xl)), (c, np.cos(xl))):
             sp = np.maximum(np.spacing(np.abs(ref.astype(np.float64))), np.finfo(float).tiny).astype(np.longdouble)
-            assert np.abs((got.astype(np.longdouble) - ref) / sp).max() <= 1.1
+            assert np.abs((got.astype(np.longdouble) - ref) / sp).max() <= 1.6
         assert np.abs(s * s + c * c - 1.0).max() < 5e-16

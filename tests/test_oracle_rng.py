@@ -15,6 +15,41 @@ def test_philox_known_answers():
     assert orc.philox2x32(0x13198a2e, 0x243f6a88, 0x85a308d3) == (0xdd7ce038, 0xf62a4c12)
 
 
+def _mix32(h):
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xffffffff
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xffffffff
+    h ^= h >> 16
+    return h
+
+
+def test_child_word_definition_and_avalanche():
+    """the bulk generator of reproduction, restated with Python integers: word w of child c in the stream (key, ctr1) =
+    mix32(((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77)), mix32 = MurmurHash3's 32-bit finaliser
+    (known answers of the finaliser: 0 -> 0, and the published test values below)"""
+    assert _mix32(0) == 0 and _mix32(1) == 0x514E28B7 and _mix32(0xffffffff) == 0x81F16F39
+    for key, ctr1, c, w in [(0, 0, 0, 0), (1, 2, 3, 4), (0xdeadbeef, (1234 << 4) | 8, 129, 8), (0xffffffff, 0xffffffff, (1 << 24) - 1, 255)]:
+        stream = _mix32(key ^ ((ctr1 * 0x85EBCA77) & 0xffffffff))
+        want = _mix32(((((c << 8) + w) * 0x9E3779B1) + stream) & 0xffffffff)
+        assert orc.child_word(key, ctr1, c, w) == want
+    # avalanche over the inputs the solver varies: flipping the child, the word, the generation or the key flips ~16 of 32 bits
+    rng = np.random.default_rng(0)
+    flips = []
+    for _ in range(300):
+        key, ctr1, c, w = int(rng.integers(1 << 32)), int(rng.integers(1 << 20)), int(rng.integers(2, 600)), int(rng.integers(0, 64))
+        a = orc.child_word(key, ctr1, c, w)
+        for b in (orc.child_word(key, ctr1, c + 1, w), orc.child_word(key, ctr1, c, w + 1), orc.child_word(key, ctr1 + 16, c, w), orc.child_word(key ^ 1, ctr1, c, w)):
+            flips.append(bin(a ^ b).count("1"))
+    flips = np.array(flips)
+    assert abs(flips.mean() - 16.0) < 0.5 and flips.min() >= 4
+    # every bit of the word is balanced over the children and words of one generation
+    words = np.array([orc.child_word(77, 5 << 4, c, w) for c in range(2, 514) for w in range(8)], dtype=np.uint64)
+    for bit in range(32):
+        assert abs(((words >> np.uint64(bit)) & np.uint64(1)).mean() - 0.5) < 0.04
+    assert len(np.unique(words)) == words.size
+
+
 def test_counter_gauss_and_uniform_definition():
     # integer-only post-processing, reproduced here with Python integers
     for key, c0, c1 in [(1, 2, 3), (0xdeadbeef, (77 << 8) | 5, (1234 << 4) | 8), (42, 0, 0)]:
