@@ -59,7 +59,7 @@ class ProblemDesc(C.Structure):
 class SolveParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_int32), ("fk_mode", C.c_int32), ("population", C.c_int32),
                 ("islands", C.c_int32), ("max_steps", C.c_int32), ("random_seed", C.c_uint64), ("dpos", C.c_double),
-                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("reserved", C.c_int32)]
+                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("reserved", C.c_int32), ("timeout", C.c_double)]
 
 
 def default_solve_params(**kw):
@@ -76,6 +76,7 @@ def default_solve_params(**kw):
     p.drot = -1.0
     p.dtwist = 1e-5
     p.no_wipeout = 0
+    p.timeout = 0.0
     for k, v in kw.items():
         if k == "mode" and isinstance(v, str):
             v = MODE_BY_NAME[v]

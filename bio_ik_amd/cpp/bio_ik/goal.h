@@ -10,10 +10,15 @@
 #pragma once
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../../include/bioik_hip.h"
+#if defined(BIOIK_WITH_KINEMATICS_BASE)  // built inside the MoveIt plugin (src/kinematics_plugin_hip.cpp): MoveIt's own option struct
+#include <moveit/kinematics_base/kinematics_base.h>
+#endif
 
 namespace bio_ik {
 
@@ -53,12 +58,27 @@ public:
     virtual void gpuParams(std::vector<double>&) const {}
 };
 
-// kinematics::KinematicsQueryOptions stand-in (moveit/kinematics_base/kinematics_base.h)
+#if defined(BIOIK_WITH_KINEMATICS_BASE)
+typedef kinematics::KinematicsQueryOptions KinematicsQueryOptions;
+#else
+// kinematics::KinematicsQueryOptions stand-in (moveit/kinematics_base/kinematics_base.h) for builds without MoveIt
 struct KinematicsQueryOptions {
     bool lock_redundant_joints = false;
     bool return_approximate_solution = false;
     virtual ~KinematicsQueryOptions() {}
 };
+#endif
+
+// MoveIt hands the options to the plugin as a `const kinematics::KinematicsQueryOptions&`, a struct without virtual members, so a
+// BioIK options object is recognised by its address in a process-wide registry (reference src/kinematics_plugin.cpp:75-101)
+inline std::mutex& bioIKKinematicsQueryOptionsMutex() {
+    static std::mutex m;
+    return m;
+}
+inline std::unordered_set<const void*>& bioIKKinematicsQueryOptionsList() {
+    static std::unordered_set<const void*> l;
+    return l;
+}
 
 // reference goal.h:121-129
 struct BioIKKinematicsQueryOptions : KinematicsQueryOptions {
@@ -66,6 +86,18 @@ struct BioIKKinematicsQueryOptions : KinematicsQueryOptions {
     std::vector<std::string> fixed_joints;
     bool replace = false;
     mutable double solution_fitness = 0;
+    BioIKKinematicsQueryOptions() {
+        std::lock_guard<std::mutex> lock(bioIKKinematicsQueryOptionsMutex());
+        bioIKKinematicsQueryOptionsList().insert(this);
+    }
+    ~BioIKKinematicsQueryOptions() {
+        std::lock_guard<std::mutex> lock(bioIKKinematicsQueryOptionsMutex());
+        bioIKKinematicsQueryOptionsList().erase(this);
+    }
 };
+inline const BioIKKinematicsQueryOptions* toBioIKKinematicsQueryOptions(const void* ptr) {  // kinematics_plugin.cpp:93-99
+    std::lock_guard<std::mutex> lock(bioIKKinematicsQueryOptionsMutex());
+    return bioIKKinematicsQueryOptionsList().count(ptr) ? (const BioIKKinematicsQueryOptions*)ptr : nullptr;
+}
 
 }  // namespace bio_ik

@@ -142,9 +142,9 @@ public:
     bool searchPositionIKBatch(const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses, const std::vector<std::vector<double>>& ik_seed_states,
                                std::vector<std::vector<double>>& solutions, std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
                                const bio_ik::KinematicsQueryOptions& options = bio_ik::KinematicsQueryOptions(),
-                               const std::vector<double>* context_state = nullptr) const {
+                               const std::vector<double>* context_state = nullptr, double timeout = 0.0) const {
         const size_t n = ik_seed_states.size(), V = robot_model->variable_names.size();
-        auto* bio = dynamic_cast<const bio_ik::BioIKKinematicsQueryOptions*>(&options);  // the reference keeps a registry (:75-101)
+        auto* bio = bio_ik::toBioIKKinematicsQueryOptions(&options);  // recognised by address, as the reference does (:75-101)
         std::vector<const bio_ik::Goal*> all_goals;
         if (!bio || !bio->replace)
             for (auto& g : default_goals) all_goals.push_back(g.get());  // :550-552
@@ -189,6 +189,7 @@ public:
         sp.random_seed = (uint64_t)ikparams.random_seed;
         sp.dpos = ikparams.dpos, sp.drot = ikparams.drot, sp.dtwist = ikparams.dtwist;
         sp.no_wipeout = ikparams.no_wipeout;
+        sp.timeout = timeout > 0.0 ? timeout : 0.0;  // ik_parallel.h:160: wall-clock budget of the call, honoured on the device
         solutions.assign(n, std::vector<double>());
         error_codes.assign(n, moveit_msgs::MoveItErrorCodes());
         if (bioik_solve_batch(problem, &sp, n, state.data(), params.data(), sol.data(), fit.data(), suc.data(), steps.data()) != BIOIK_OK) {
@@ -230,13 +231,13 @@ public:
     }
 
     // kinematics_plugin.cpp:437-655 (the multi-pose overload every other overload forwards to)
-    bool searchPositionIK(const std::vector<geometry_msgs::Pose>& ik_poses, const std::vector<double>& ik_seed_state, double /*timeout*/,
+    bool searchPositionIK(const std::vector<geometry_msgs::Pose>& ik_poses, const std::vector<double>& ik_seed_state, double timeout,
                           const std::vector<double>& /*consistency_limits*/, std::vector<double>& solution, const IKCallbackFn& solution_callback,
                           moveit_msgs::MoveItErrorCodes& error_code, const bio_ik::KinematicsQueryOptions& options = bio_ik::KinematicsQueryOptions(),
                           const std::vector<double>* context_state = nullptr) const {
         std::vector<std::vector<double>> sols;
         std::vector<moveit_msgs::MoveItErrorCodes> codes;
-        bool ok = searchPositionIKBatch({ik_poses}, {ik_seed_state}, sols, codes, options, context_state);
+        bool ok = searchPositionIKBatch({ik_poses}, {ik_seed_state}, sols, codes, options, context_state, timeout);
         solution = sols.empty() ? ik_seed_state : sols[0];
         if (!ok) {
             error_code.val = moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;

@@ -1,0 +1,23 @@
+// bio_ik/kinematics_plugin_hip.h — what libbio_ik (MI355X build) exports next to the pluginlib class `bio_ik/BioIKKinematicsPlugin`:
+// the additive batched form of searchPositionIK (the reference's interface, src/kinematics_plugin.cpp:437-446, solves one query per call).
+#pragma once
+#include <vector>
+
+#include <geometry_msgs/Pose.h>
+#include <moveit/kinematics_base/kinematics_base.h>
+#include <moveit/robot_state/robot_state.h>
+#include <moveit_msgs/MoveItErrorCodes.h>
+
+namespace bio_ik_kinematics_plugin {
+
+// n independent queries sharing one goal structure in ONE device launch.  `solver` must be the plugin instance MoveIt loaded
+// (kinematics::KinematicsBase of class bio_ik/BioIKKinematicsPlugin); ik_poses[k] holds the tip poses of query k in the base frame
+// (ignored with BioIKKinematicsQueryOptions::replace), ik_seed_states[k] its group variables; `timeout` [s] bounds the whole call.
+// Returns true iff every query has an acceptable solution; the per-query verdicts are in error_codes.
+bool searchPositionIKBatch(const kinematics::KinematicsBase& solver, const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses,
+                           const std::vector<std::vector<double>>& ik_seed_states, double timeout, std::vector<std::vector<double>>& solutions,
+                           std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
+                           const kinematics::KinematicsQueryOptions& options = kinematics::KinematicsQueryOptions(),
+                           const moveit::core::RobotState* context_state = nullptr);
+
+}  // namespace bio_ik_kinematics_plugin

@@ -1,0 +1,43 @@
+// stand-in for moveit/robot_state/robot_state.h: variable positions and global link transforms (see ../../README.md)
+#pragma once
+#include <moveit/robot_model/robot_model.h>
+namespace moveit {
+namespace core {
+class RobotState {
+    RobotModelConstPtr model_;
+    std::vector<double> position_;
+
+public:
+    explicit RobotState(const RobotModelConstPtr& model) : model_(model), position_(model->getVariableCount(), 0.0) {}
+    const RobotModelConstPtr& getRobotModel() const { return model_; }
+    void setToDefaultValues() { model_->getVariableDefaultPositions(position_); }
+    const double* getVariablePositions() const { return position_.data(); }
+    double* getVariablePositions() { return position_.data(); }
+    void setVariablePositions(const std::vector<double>& p) { position_ = p; }
+    void setVariablePosition(const std::string& name, double v) { position_[(size_t)model_->getVariableIndex(name)] = v; }
+    Eigen::Isometry3d getGlobalLinkTransform(const std::string& link_name) const {
+        std::vector<const LinkModel*> chain;
+        for (const LinkModel* l = model_->getLinkModel(link_name); l; l = l->getParentLinkModel()) chain.insert(chain.begin(), l);
+        if (chain.empty()) throw std::runtime_error("RobotState: unknown link " + link_name);
+        Eigen::Isometry3d T;
+        for (const LinkModel* l : chain) {
+            T = T * l->getJointOriginTransform();
+            const JointModel* j = l->getParentJointModel();
+            double v = 0.0;
+            if (j->getVariableCount()) v = position_[(size_t)j->getFirstVariableIndex()];
+            if (j->getMimic()) v = position_[(size_t)j->getMimic()->getFirstVariableIndex()] * j->getMimicFactor() + j->getMimicOffset();
+            Eigen::Isometry3d J;
+            if (j->getType() == JointModel::REVOLUTE) {
+                const double s = std::sin(v / 2);
+                J.linear() = Eigen::Quaterniond(std::cos(v / 2), j->axis_.x() * s, j->axis_.y() * s, j->axis_.z() * s).toRotationMatrix();
+            } else if (j->getType() == JointModel::PRISMATIC) {
+                J.translation() = Eigen::Vector3d(j->axis_.x() * v, j->axis_.y() * v, j->axis_.z() * v);
+            }
+            T = T * J;
+        }
+        return T;
+    }
+};
+}  // namespace core
+}  // namespace moveit
+namespace robot_state = moveit::core;

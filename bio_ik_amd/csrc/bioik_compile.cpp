@@ -505,6 +505,10 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
     o.islands = p.islands > 0 ? p.islands : 1;
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
+    if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
+        const double ticks = p.timeout * 1e8;
+        o.timeout_ticks = ticks >= 9e18 ? (uint64_t)9e18 : (ticks < 1.0 ? 1ull : (uint64_t)ticks);
+    }
     o.no_wipeout = p.no_wipeout;
     o.generations = o.memetic ? 8 : 16;  // ik_evolution_2.cpp:349-351
     return o;

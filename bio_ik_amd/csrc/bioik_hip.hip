@@ -36,6 +36,11 @@ namespace sim {
 thread_local Block* blk = nullptr;
 thread_local int tid = 0;
 }  // namespace sim
+#include <chrono>
+unsigned long long sim_wall_clock() {
+    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, bytes); }
 typedef void* stream_t;
 static int be_device_count() { return 1; }
 static void be_set_device(int) {}
@@ -113,6 +118,7 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
 }
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
+static void be_zero_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
 
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3
@@ -183,6 +189,10 @@ struct bioik_problem {
     void* io_host = nullptr;
     size_t io_bytes = 0;
     uint64_t first_query = 0;
+    // launch clocks of solves with a wall-clock timeout: a ring of words, one per launch in flight, zeroed in stream order
+    unsigned long long* d_clocks = nullptr;
+    unsigned clock_next = 0;
+    static constexpr unsigned kClocks = 64;
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
     ProbPtr pb() const { return (ProbPtr)d_pb; }
@@ -341,6 +351,11 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.seeds = d_seeds;
     a.params = d_params;
     a.phase_cycles = nullptr;
+    a.launch_clock = nullptr;
+    if (sp.timeout_ticks != 0) {
+        a.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
+        be_zero_async(a.launch_clock, sizeof(unsigned long long), stream);
+    }
 #if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
     const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
@@ -412,6 +427,7 @@ void bioik_default_solve_params(bioik_solve_params* p) {
     p->drot = -1.0;
     p->dtwist = 1e-5;
     p->no_wipeout = 0;
+    p->timeout = 0.0;
 }
 
 int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out) {
@@ -433,6 +449,7 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     std::unique_ptr<bioik_problem> p(new bioik_problem(model, *desc));
     be_set_device(model->device);
     p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
+    p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kClocks * sizeof(unsigned long long));
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
     be_sync(0);
     *out = p.release();
@@ -441,6 +458,7 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
 void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
+    be_free(p->d_clocks);
     be_free(p->io_dev);
     be_free_pinned(p->io_host);
     delete p;

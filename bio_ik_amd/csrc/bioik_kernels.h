@@ -189,6 +189,7 @@ struct SolveArgs {
     int32_t* success;       // [n*islands]
     int32_t* steps;         // [n*islands]
     unsigned long long* phase_cycles;  // [n*islands][8] or null: per-phase shader cycles (builds with -DBIOIK_PHASE_TIMING)
+    unsigned long long* launch_clock;  // one zeroed word per launch (timeout_ticks != 0): the first workgroup's start on the device clock
 };
 
 struct SpeciesState {
@@ -325,6 +326,19 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
     PHASE_MARK(PH_INIT);
 
+    // ik_parallel.h:160: the caller's timeout bounds the call, not the query.  The launch's clock starts when its first workgroup
+    // does (one compare-and-swap per workgroup on a word the host zeroed); lane 0 reads the clock once per step and the verdict
+    // crosses LDS, so that every wavefront of the workgroup leaves the loop in the same step.
+    unsigned long long deadline = 0ull;
+    if (sp.timeout_ticks != 0ull) {
+        if (tid == 0) {
+            const unsigned long long t0 = p_stamp_once(a.launch_clock, p_wall_clock());
+            s_wbc[2] = (double)(t0 >> 32), s_wbc[3] = (double)(t0 & 0xffffffffull);  // (two exact halves: the slots are doubles)
+        }
+        p_barrier();
+        deadline = (((unsigned long long)s_wbc[2] << 32) | (unsigned long long)s_wbc[3]) + sp.timeout_ticks;
+        p_barrier();
+    }
     int steps = 0;
     bool success = false;
     double final_fit = BIOIK_DBL_MAX;
@@ -709,6 +723,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         success = sol_ok != 0;
         PHASE_MARK(PH_CHECK);
         if (success) break;
+        if (sp.timeout_ticks != 0ull) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
+            if (tid == 0) s_wbc[2] = p_wall_clock() >= deadline ? 1.0 : 0.0;
+            p_barrier();
+            const bool expired = s_wbc[2] != 0.0;
+            p_barrier();
+            if (expired) break;
+        }
     }
     PHASE_DUMP(a.phase_cycles, unit);
 

@@ -66,6 +66,12 @@ BIOIK_DEV T p_row_mirror(T v) {
 }
 BIOIK_DEV int p_uniform(int v) { return v; }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
+unsigned long long sim_wall_clock();  // 100 MHz ticks of a steady host clock (defined with the simulator's back end)
+BIOIK_DEV unsigned long long p_wall_clock() { return sim_wall_clock(); }
+BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned long long value) {  // first caller's value wins; returns the winner
+    unsigned long long expected = 0ull;
+    return __atomic_compare_exchange_n(word, &expected, value, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? value : expected;
+}
 #define P_INF (__builtin_inf())
 
 #else
@@ -118,6 +124,11 @@ BIOIK_DEV double p_quad_xor(double v) {
 }
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
+BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock
+BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned long long value) {  // first caller's value wins; returns the winner
+    const unsigned long long old = atomicCAS(word, 0ull, value);
+    return old ? old : value;
+}
 #define P_INF (__builtin_inf())
 #endif
 

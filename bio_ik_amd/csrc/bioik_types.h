@@ -99,6 +99,7 @@ struct DevSolveParams {
     double dpos, drot, dtwist;  // DBL_MAX = disabled
     uint64_t random_seed;
     uint64_t first_query;       // global index of query 0 of this launch (multi-GPU shards keep their RNG streams)
+    uint64_t timeout_ticks;     // wall-clock budget of the launch in ticks of the 100 MHz device clock, 0 = none (ik_parallel.h:160)
     int32_t memetic;            // 0, 'q', 'l'
     int32_t fk_mode;            // BIOIK_FK_*
     int32_t lambda;             // children per species per generation

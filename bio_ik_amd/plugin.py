@@ -112,9 +112,10 @@ class BioIKKinematicsPlugin:
         return True  # kinematics_plugin.cpp:657-662
 
     # ---- problem / solver cache ----------------------------------------------------------------------------------
-    def _solve_params(self):
+    def _solve_params(self, timeout=0.0):
         p = self.params
-        return abi.default_solve_params(mode=p["mode"], fk_mode=abi.FK_EXACT if p["gpu_fk"] == "exact" else abi.FK_LINEAR,
+        return abi.default_solve_params(timeout=float(timeout) if timeout and timeout > 0.0 else 0.0,
+                                        mode=p["mode"], fk_mode=abi.FK_EXACT if p["gpu_fk"] == "exact" else abi.FK_LINEAR,
                                         population=int(p["gpu_population"]), islands=int(p["gpu_islands"]), max_steps=int(p["gpu_max_steps"]),
                                         random_seed=int(p["random_seed"]), dpos=float(p["dpos"]), drot=float(p["drot"]), dtwist=float(p["dtwist"]),
                                         no_wipeout=1 if p["no_wipeout"] else 0)
@@ -136,8 +137,9 @@ class BioIKKinematicsPlugin:
         return self._solvers[key]
 
     # ---- the batched entry point (new) and the reference's single-query one ---------------------------------------------
-    def searchPositionIKBatch(self, ik_poses, ik_seed_states, options=None, context_states=None, devices=None, first_query=0):
-        """n independent queries sharing one goal structure.
+    def searchPositionIKBatch(self, ik_poses, ik_seed_states, options=None, context_states=None, devices=None, first_query=0, timeout=0.0):
+        """n independent queries sharing one goal structure.  `timeout` [s] bounds the whole call on the device clock
+        (ik_parallel.h:160; every query still runs one step), <= 0: only the step budget gpu_max_steps applies.
         ik_poses [n][tips][7] (ignored when options.replace), ik_seed_states [n][group variables]
         -> (solutions [n][group variables], success [n] bool, fitness [n], error codes [n])."""
         options = options or KinematicsQueryOptions()
@@ -166,7 +168,7 @@ class BioIKKinematicsPlugin:
                     q = f[3:7]
                     f[3:7] = q * (1.0 / np.sqrt(float(q @ q)))  # PoseGoal::setOrientation (goal_types.h:146, tf2 normalized()), :543-544
                     params[k, off:off + 7] = f
-        sp = self._solve_params()
+        sp = self._solve_params(timeout)
         sol = np.zeros_like(state)
         fit = np.zeros(n)
         suc = np.zeros(n, dtype=np.int32)
@@ -198,9 +200,11 @@ class BioIKKinematicsPlugin:
 
     def searchPositionIK(self, ik_poses, ik_seed_state, timeout, solution, error_code, options=None, consistency_limits=None,
                          solution_callback=None, context_state=None):
-        """kinematics_plugin.cpp:437-655.  `timeout` is accepted for signature compatibility; the budget is `gpu_max_steps`."""
+        """kinematics_plugin.cpp:437-655.  `timeout` [s] is the reference's wall-clock budget (:504, :574; honoured on the device,
+        at least one step); `gpu_max_steps` bounds the call as well."""
         poses = np.asarray(ik_poses, dtype=np.float64).reshape(1, -1, 7) if len(ik_poses) else np.zeros((1, 0, 7))
-        sols, ok, fit, codes = self.searchPositionIKBatch(poses, [ik_seed_state], options, None if context_state is None else [context_state])
+        sols, ok, fit, codes = self.searchPositionIKBatch(poses, [ik_seed_state], options, None if context_state is None else [context_state],
+                                                          timeout=timeout)
         solution[:] = list(sols[0])
         if not ok[0]:
             error_code.val = MoveItErrorCodes.NO_IK_SOLUTION

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BIOIK_ABI_VERSION 1
+#define BIOIK_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -155,15 +155,21 @@ typedef struct bioik_solve_params {
                                 ik_evolution_2.cpp:138); new key "gpu_population"                        */
     int32_t islands;         /* independent islands per query (reference concurrency()==4 identical
                                 clones, ik_evolution_2.cpp:649 + utils.h:423); new key "gpu_islands"     */
-    int32_t max_steps;       /* budget in IKEvolution2::step() calls per island; replaces the wall-clock
-                                timeout of ik_parallel.h:160 by a deterministic budget                   */
+    int32_t max_steps;       /* budget in IKEvolution2::step() calls per island (deterministic; checked after
+                                every step like the success test of ik_parallel.h:173-181)               */
     uint64_t random_seed;    /* yaml "random_seed" (kinematics_plugin.cpp:256)                           */
     double dpos, drot, dtwist; /* yaml keys (kinematics_plugin.cpp:259-261); <0 or >=FLT_MAX disables   */
     int32_t no_wipeout;      /* debugging aid: disable species wipe-outs                                 */
     int32_t reserved;
+    double timeout;          /* the caller's `timeout` of searchPositionIK [s] (kinematics_plugin.cpp:504, 574;
+                                ik_parallel.h:160 `ros::WallTime::now() < timeout`): wall-clock budget of ONE
+                                bioik_solve_batch* call, measured on the device from the moment the launch's first
+                                workgroup starts.  Every query runs at least one step (ik_parallel.h:160
+                                `iteration != 0`), then stops at the first of: success, max_steps, timeout.
+                                <= 0: no wall-clock limit (results are then independent of timing).          */
 } bioik_solve_params;
 
-/* defaults: bio2_memetic, exact FK, population 128, 1 island, 64 steps, seed 0, dpos=drot=off, dtwist=1e-5 */
+/* defaults: bio2_memetic, exact FK, population 128, 1 island, 64 steps, no timeout, seed 0, dpos=drot=off, dtwist=1e-5 */
 void bioik_default_solve_params(bioik_solve_params* p);
 
 typedef struct bioik_model bioik_model;

@@ -1,0 +1,208 @@
+// The MoveIt plugin translation unit (bio_ik_amd/cpp/src/kinematics_plugin_hip.cpp, built as libbio_ik.so) driven the way MoveIt
+// drives it: the class is created by its pluginlib name from the factory registry, held as kinematics::KinematicsBase*, configured
+// through private-namespace parameters (the kinematics.yaml keys), initialised from a moveit::core::RobotModel, and asked for IK
+// through every searchPositionIK overload of the interface (reference src/kinematics_plugin.cpp:130-155, 337-446, 657).
+// MoveIt / ROS are stand-ins here (bio_ik_amd/cpp/standin); the solver behind the C-ABI is libbioik_hip.so on a GPU box and the host
+// simulator of the kernels in the CPU suite.
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <random>
+#include <sstream>
+
+#include <moveit/kinematics_base/kinematics_base.h>
+#include <pluginlib/class_list_macros.h>
+#include <ros/ros.h>
+
+#define BIOIK_WITH_KINEMATICS_BASE 1
+#include <bio_ik/bio_ik.h>
+#include <bio_ik/kinematics_plugin_hip.h>
+
+#ifndef TEST_TIMEOUT
+#define TEST_TIMEOUT 0.25
+#endif
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+static moveit::core::RobotModelPtr pr2Arm() {
+    moveit::core::RobotModelPtr m(new moveit::core::RobotModel());
+    m->addLink("base_footprint", "", "root_joint", "fixed", 0, 0, 0, 0, 0, 0, 0, 0, 1);
+    m->addLink("base_link", "base_footprint", "base_footprint_joint", "fixed", 0, 0, 0.051, 0, 0, 0, 0, 0, 1);
+    m->addLink("torso_lift_link", "base_link", "torso_lift_joint", "prismatic", -0.05, 0, 0.739675, 0, 0, 0, 0, 0, 1, 0.0, 0.33, 0.013);
+    m->addLink("r_shoulder_pan_link", "torso_lift_link", "r_shoulder_pan_joint", "revolute", 0, -0.188, 0, 0, 0, 0, 0, 0, 1, -2.2854, 0.7146, 2.088);
+    m->addLink("r_shoulder_lift_link", "r_shoulder_pan_link", "r_shoulder_lift_joint", "revolute", 0.1, 0, 0, 0, 0, 0, 0, 1, 0, -0.5236, 1.3963, 2.082);
+    m->addLink("r_upper_arm_roll_link", "r_shoulder_lift_link", "r_upper_arm_roll_joint", "revolute", 0, 0, 0, 0, 0, 0, 1, 0, 0, -3.9, 0.8, 3.27);
+    m->addLink("r_upper_arm_link", "r_upper_arm_roll_link", "r_upper_arm_joint", "fixed", 0, 0, 0, 0, 0, 0, 0, 0, 1);
+    m->addLink("r_elbow_flex_link", "r_upper_arm_link", "r_elbow_flex_joint", "revolute", 0.4, 0, 0, 0, 0, 0, 0, 1, 0, -2.3213, 0.0, 3.3);
+    m->addLink("r_forearm_roll_link", "r_elbow_flex_link", "r_forearm_roll_joint", "continuous", 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 3.6);
+    m->addLink("r_forearm_link", "r_forearm_roll_link", "r_forearm_joint", "fixed", 0, 0, 0, 0, 0, 0, 0, 0, 1);
+    m->addLink("r_wrist_flex_link", "r_forearm_link", "r_wrist_flex_joint", "revolute", 0.321, 0, 0, 0, 0, 0, 0, 1, 0, -2.18, 0.0, 3.078);
+    m->addLink("r_wrist_roll_link", "r_wrist_flex_link", "r_wrist_roll_joint", "continuous", 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 3.6);
+    m->addChainGroup("right_arm", "torso_lift_link", "r_wrist_roll_link");
+    return m;
+}
+
+static geometry_msgs::Pose poseInBase(const moveit::core::RobotState& st, const std::string& base, const std::string& tip) {
+    const Eigen::Isometry3d B = st.getGlobalLinkTransform(base), T = st.getGlobalLinkTransform(tip);
+    Eigen::Isometry3d Bi;  // inverse of a rigid transform
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Bi.linear()(i, j) = B.linear()(j, i);
+    const Eigen::Vector3d bt = Bi.linear() * B.translation();
+    Bi.translation() = Eigen::Vector3d(-bt.x(), -bt.y(), -bt.z());
+    const Eigen::Isometry3d R = Bi * T;
+    const Eigen::Quaterniond q(R.rotation());
+    geometry_msgs::Pose p;
+    p.position.x = R.translation().x(), p.position.y = R.translation().y(), p.position.z = R.translation().z();
+    p.orientation.x = q.x(), p.orientation.y = q.y(), p.orientation.z = q.z(), p.orientation.w = q.w();
+    return p;
+}
+
+int main(int argc, char** argv) {
+    // the plugin description a ROS package exports names this library and class (reference bio_ik_kinematics_description.xml:1-4)
+    if (argc > 1) {
+        std::ifstream f(argv[1]);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::string xml = ss.str();
+        CHECK(xml.find("library path=\"libbio_ik\"") != std::string::npos);
+        CHECK(xml.find("name=\"bio_ik/BioIKKinematicsPlugin\"") != std::string::npos);
+        CHECK(xml.find("type=\"bio_ik_kinematics_plugin::BioIKKinematicsPlugin\"") != std::string::npos);
+        CHECK(xml.find("base_class_type=\"kinematics::KinematicsBase\"") != std::string::npos);
+    }
+    // kinematics.yaml keys arrive as private parameters (:243-328); additive gpu_* keys size the device solve
+    ros::set_param("mode", "bio2_memetic");
+    ros::set_param("random_seed", 3);
+    ros::set_param("gpu_population", 16);
+    ros::set_param("gpu_fk", "linear");
+    ros::set_param("gpu_max_steps", 80);
+    // pluginlib: create the class registered by PLUGINLIB_EXPORT_CLASS, keep it as its base class
+    std::unique_ptr<kinematics::KinematicsBase> solver(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
+    CHECK(solver != nullptr);
+    CHECK(pluginlib_standin_create("no_such::Class") == nullptr);
+    moveit::core::RobotModelPtr rm = pr2Arm();
+    CHECK(solver->initialize(*rm, "right_arm", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0));
+    CHECK(solver->getGroupName() == "right_arm" && solver->getBaseFrame() == "torso_lift_link");
+    CHECK(solver->getJointNames().size() == 7 && solver->getJointNames()[0] == "r_shoulder_pan_joint");
+    CHECK(solver->getLinkNames() == std::vector<std::string>{"r_wrist_roll_link"} && solver->supportsGroup(rm->getJointModelGroup("right_arm")));
+    {
+        std::vector<geometry_msgs::Pose> poses;
+        std::vector<double> sol;
+        moveit_msgs::MoveItErrorCodes code;
+        CHECK(!solver->getPositionFK({}, {}, poses));                                  // :140-145
+        CHECK(!solver->getPositionIK(geometry_msgs::Pose(), {}, sol, code));           // :147-155
+    }
+    // FK -> IK -> FK round trips (reference README.md:404-447)
+    std::mt19937 rng(5);
+    auto uniform = [&](double lo, double hi) { return std::uniform_real_distribution<double>(lo, hi)(rng); };
+    moveit::core::RobotState target(rm), check(rm);
+    std::vector<geometry_msgs::Pose> poses;
+    std::vector<std::vector<double>> seeds;
+    for (int k = 0; k < 3; k++) {
+        target.setToDefaultValues();
+        std::vector<double> seed;
+        for (auto& jn : solver->getJointNames()) {
+            const auto& b = rm->getVariableBounds(jn);
+            const double v = uniform(b.min_position_, b.max_position_);
+            target.setVariablePosition(jn, v);
+            seed.push_back(std::min(std::max(v + uniform(-0.2, 0.2), b.min_position_), b.max_position_));
+        }
+        poses.push_back(poseInBase(target, "torso_lift_link", "r_wrist_roll_link"));
+        seeds.push_back(seed);
+    }
+    auto tipError = [&](const std::vector<double>& solution, const geometry_msgs::Pose& want) {
+        check.setToDefaultValues();
+        for (size_t i = 0; i < solution.size(); i++) check.setVariablePosition(solver->getJointNames()[i], solution[i]);
+        const geometry_msgs::Pose got = poseInBase(check, "torso_lift_link", "r_wrist_roll_link");
+        const double dx = got.position.x - want.position.x, dy = got.position.y - want.position.y, dz = got.position.z - want.position.z;
+        const double dot = std::fabs(got.orientation.x * want.orientation.x + got.orientation.y * want.orientation.y + got.orientation.z * want.orientation.z +
+                                     got.orientation.w * want.orientation.w);
+        return std::max(std::sqrt(dx * dx + dy * dy + dz * dz) / 1e-4, 2 * std::acos(std::min(1.0, dot)) / 1e-3);  // in units of the tolerance
+    };
+    std::vector<double> solution;
+    moveit_msgs::MoveItErrorCodes code;
+    const std::vector<double> no_limits;
+    // the four single-pose overloads and the multi-pose one (:376-446)
+    CHECK(solver->searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, solution, code) && code.val == code.SUCCESS && solution.size() == 7);
+    CHECK(tipError(solution, poses[0]) < 1.0);
+    for (size_t i = 0; i < 7; i++) {
+        const auto& b = rm->getVariableBounds(solver->getJointNames()[i]);
+        CHECK(solution[i] >= b.min_position_ - 1e-12 && solution[i] <= b.max_position_ + 1e-12);
+    }
+    CHECK(solver->searchPositionIK(poses[1], seeds[1], TEST_TIMEOUT, no_limits, solution, code) && tipError(solution, poses[1]) < 1.0);
+    int called = 0;
+    kinematics::KinematicsBase::IKCallbackFn accept = [&](const geometry_msgs::Pose&, const std::vector<double>& s, moveit_msgs::MoveItErrorCodes& e) {
+        called += (int)s.size();
+        e.val = e.SUCCESS;
+    };
+    kinematics::KinematicsBase::IKCallbackFn reject = [](const geometry_msgs::Pose&, const std::vector<double>&, moveit_msgs::MoveItErrorCodes& e) { e.val = e.NO_IK_SOLUTION; };
+    CHECK(solver->searchPositionIK(poses[2], seeds[2], TEST_TIMEOUT, solution, accept, code) && called == 7 && tipError(solution, poses[2]) < 1.0);
+    CHECK(!solver->searchPositionIK(poses[2], seeds[2], TEST_TIMEOUT, no_limits, solution, reject, code));  // the callback's verdict (:644-649)
+    CHECK(solver->searchPositionIK(std::vector<geometry_msgs::Pose>{poses[0]}, seeds[0], TEST_TIMEOUT, no_limits, solution, kinematics::KinematicsBase::IKCallbackFn(), code));
+    // context state: the pose is interpreted against the base frame of THAT state (:492-497); here the torso is raised
+    {
+        moveit::core::RobotState context(rm);
+        context.setToDefaultValues();
+        context.setVariablePosition("torso_lift_joint", 0.2);
+        CHECK(solver->searchPositionIK(std::vector<geometry_msgs::Pose>{poses[0]}, seeds[0], TEST_TIMEOUT, no_limits, solution, kinematics::KinematicsBase::IKCallbackFn(),
+                                       code, kinematics::KinematicsQueryOptions(), &context));
+        CHECK(tipError(solution, poses[0]) < 1.0);  // the arm hangs off the torso link: same joint values solve it
+    }
+    // unreachable: NO_IK_SOLUTION, or the best effort when an approximate solution is acceptable (:638-641); the timeout ends the call
+    geometry_msgs::Pose far;
+    far.position.x = far.position.y = far.position.z = 5.0;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        CHECK(!solver->searchPositionIK(far, seeds[0], TEST_TIMEOUT * 0.2, solution, code) && code.val == code.NO_IK_SOLUTION);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("unreachable goal, timeout %.3f s: returned after %.3f s\n", TEST_TIMEOUT * 0.2, dt);
+        kinematics::KinematicsQueryOptions approx;
+        approx.return_approximate_solution = true;
+        CHECK(solver->searchPositionIK(far, seeds[0], TEST_TIMEOUT * 0.2, solution, code, approx) && code.val == code.SUCCESS && solution.size() == 7);
+    }
+    // the goal (cost) plugin interface: caller-supplied goals, replacing the default pose goal (:540-556); fixed joints (:104-114)
+    {
+        bio_ik::BioIKKinematicsQueryOptions opts;
+        opts.replace = true;
+        opts.return_approximate_solution = true;
+        opts.goals.emplace_back(new bio_ik::PositionGoal("r_wrist_roll_link", bio_ik::Vector3(0.45, -0.3, 0.9)));
+        opts.fixed_joints.push_back("r_wrist_roll_joint");
+        CHECK(solver->searchPositionIK(std::vector<geometry_msgs::Pose>(), seeds[0], TEST_TIMEOUT, no_limits, solution, kinematics::KinematicsBase::IKCallbackFn(), code, opts));
+        CHECK(opts.solution_fitness >= 0.0 && opts.solution_fitness < 1e-6 && solution.size() == 7);
+        CHECK(solution[6] == seeds[0][6]);  // the fixed joint keeps the seed's value
+        check.setToDefaultValues();
+        for (size_t i = 0; i < solution.size(); i++) check.setVariablePosition(solver->getJointNames()[i], solution[i]);
+        const Eigen::Isometry3d T = check.getGlobalLinkTransform("r_wrist_roll_link");
+        CHECK(std::fabs(T.translation().x() - 0.45) < 1e-3 && std::fabs(T.translation().y() + 0.3) < 1e-3 && std::fabs(T.translation().z() - 0.9) < 1e-3);
+    }
+    // the additive batched entry point: one device launch for all queries
+    {
+        std::vector<std::vector<geometry_msgs::Pose>> bp;
+        for (auto& p : poses) bp.push_back({p});
+        std::vector<std::vector<double>> sols;
+        std::vector<moveit_msgs::MoveItErrorCodes> codes;
+        CHECK(bio_ik_kinematics_plugin::searchPositionIKBatch(*solver, bp, seeds, TEST_TIMEOUT, sols, codes));
+        CHECK(sols.size() == 3);
+        for (size_t k = 0; k < 3; k++) CHECK(codes[k].val == moveit_msgs::MoveItErrorCodes::SUCCESS && tipError(sols[k], poses[k]) < 1.0);
+    }
+    // configuration errors throw, as the reference's ERROR macro does
+    {
+        ros::set_param("mode", "gd_r_42");
+        std::unique_ptr<kinematics::KinematicsBase> bad(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
+        bool threw = false;
+        try {
+            bad->initialize(*rm, "right_arm", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+        ros::set_param("mode", "bio2_memetic");
+    }
+    std::printf("ok\n");
+    return 0;
+}

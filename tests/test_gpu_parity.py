@@ -316,6 +316,28 @@ def test_two_launches_in_flight(gpus, templates):
             assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3])
 
 
+def test_wall_clock_timeout(gpus, templates):
+    """the caller's timeout (reference ik_parallel.h:160, kinematics_plugin.cpp:504): wall-clock budget of the call on the device
+    clock; at least one step per query; a generous timeout changes no bit of the result"""
+    import time
+    h, t = gpus["c2"], templates["c2"]
+    n = 2048
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=123)
+    far = params.copy()
+    far[:, :3] += 10.0  # unreachable: no query can succeed, only a budget ends the call
+    h.solve_batch(abi.default_solve_params(population=128, max_steps=2, random_seed=1), seeds, far)  # (first launch of the process)
+    t0 = time.perf_counter()
+    sol, fit, suc, steps = h.solve_batch(abi.default_solve_params(population=128, max_steps=1000000, random_seed=1, timeout=0.02), seeds, far)
+    dt = time.perf_counter() - t0
+    assert not suc.any() and steps.min() >= 1
+    assert 0.015 < dt < 0.2, dt  # ~20 ms on the device + whatever the last single steps and the copies take; a million steps would take minutes
+    assert steps.max() > 20      # the workgroups that started first used their time
+    p0 = abi.default_solve_params(population=128, max_steps=24, random_seed=4)
+    p1 = abi.default_solve_params(population=128, max_steps=24, random_seed=4, timeout=3600.0)
+    a, b = h.solve_batch(p0, seeds, params), h.solve_batch(p1, seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_error_conventions(pr2):
     """status codes instead of exceptions/aborts (include/bioik_hip.h)"""
     from bio_ik_amd import PoseGoal, RobotModel

@@ -190,3 +190,18 @@ def test_floating_and_planar_joints(hostsim_lib, base):
     finally:
         for k in monkey:
             os.environ.pop(k, None)
+
+
+def test_wall_clock_timeout(sims, oracles, templates):
+    """the caller's timeout (ik_parallel.h:160): every query runs at least one step, then stops when the launch's clock passes the
+    budget; a generous timeout changes nothing"""
+    h, o, t = sims["c2"], oracles["c2"], templates["c2"]
+    from bio_ik_amd.workload import make_queries
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 3, seed=9)
+    free = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=2), seeds, params)
+    slack = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=2, timeout=3600.0), seeds, params)
+    assert all(np.array_equal(a, b) for a, b in zip(free, slack))
+    tight = h.solve_batch(abi.default_solve_params(population=16, max_steps=1000, random_seed=2, timeout=1e-9), seeds, params)
+    assert np.all(tight[3] == 1)  # one step each (`iteration != 0`), the state after that step is what comes back
+    one = h.solve_batch(abi.default_solve_params(population=16, max_steps=1, random_seed=2), seeds, params)
+    assert all(np.array_equal(a, b) for a, b in zip(tight, one))

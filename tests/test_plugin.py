@@ -44,7 +44,7 @@ def test_search_position_ik_round_trip(plugin, pr2):
     pose = goal_in_base_frame(pr2, target)
     seed = np.clip(target[gv] + 0.2 * rng.normal(size=len(gv)), np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv])
     solution, code = [], MoveItErrorCodes()
-    assert plugin.searchPositionIK([pose], list(seed), 0.005, solution, code) is True
+    assert plugin.searchPositionIK([pose], list(seed), 60.0, solution, code) is True
     assert code.val == MoveItErrorCodes.SUCCESS and len(solution) == 7
     state = pr2.default_positions()
     state[gv] = solution
@@ -56,7 +56,7 @@ def test_search_position_ik_round_trip(plugin, pr2):
     # callback semantics (:644-649): the callback's verdict is the return value
     def reject(p, s, e):
         e.val = MoveItErrorCodes.NO_IK_SOLUTION
-    assert plugin.searchPositionIK([pose], list(seed), 0.005, [], MoveItErrorCodes(), solution_callback=reject) is False
+    assert plugin.searchPositionIK([pose], list(seed), 60.0, [], MoveItErrorCodes(), solution_callback=reject) is False
 
 
 def test_pose_quaternion_is_normalised_like_set_orientation(plugin, pr2):
@@ -71,8 +71,8 @@ def test_pose_quaternion_is_normalised_like_set_orientation(plugin, pr2):
     scaled = pose.copy()
     scaled[3:] *= 2.0
     a, b = [], []
-    assert plugin.searchPositionIK([pose], seed, 0.005, a, MoveItErrorCodes()) is True
-    assert plugin.searchPositionIK([scaled], seed, 0.005, b, MoveItErrorCodes()) is True
+    assert plugin.searchPositionIK([pose], seed, 60.0, a, MoveItErrorCodes()) is True
+    assert plugin.searchPositionIK([scaled], seed, 60.0, b, MoveItErrorCodes()) is True
     assert np.allclose(a, b, atol=1e-9)
 
 
@@ -82,15 +82,15 @@ def test_unreachable_goal_error_codes(plugin, pr2):
     plugin.params["gpu_max_steps"] = 2
     try:
         sol, code = [], MoveItErrorCodes()
-        assert plugin.searchPositionIK([far], seed, 0.005, sol, code) is False and code.val == MoveItErrorCodes.NO_IK_SOLUTION  # :638-641
+        assert plugin.searchPositionIK([far], seed, 60.0, sol, code) is False and code.val == MoveItErrorCodes.NO_IK_SOLUTION  # :638-641
         sol, code = [], MoveItErrorCodes()
-        assert plugin.searchPositionIK([far], seed, 0.005, sol, code, options=KinematicsQueryOptions(return_approximate_solution=True)) is True
+        assert plugin.searchPositionIK([far], seed, 60.0, sol, code, options=KinematicsQueryOptions(return_approximate_solution=True)) is True
         assert len(sol) == 7
         opts = BioIKKinematicsQueryOptions()  # replace: only the caller's goals (:540-556)
         opts.replace = True
         opts.return_approximate_solution = True
         opts.goals.append(PositionGoal("r_wrist_roll_link", (0.5, -0.2, 0.9)))
-        assert plugin.searchPositionIK([], seed, 0.005, sol, MoveItErrorCodes(), options=opts) is True
+        assert plugin.searchPositionIK([], seed, 60.0, sol, MoveItErrorCodes(), options=opts) is True
         assert opts.solution_fitness >= 0.0
     finally:
         plugin.params["gpu_max_steps"] = 40
