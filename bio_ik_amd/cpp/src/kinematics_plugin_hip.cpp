@@ -156,13 +156,18 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
     std::string gpu_fk = "exact";
 
     std::unique_ptr<FlatModel> flat;
-    bioik_model* model = nullptr;
-    mutable std::map<std::string, bioik_problem*> problems;  // one compiled problem per goal structure
+    std::vector<int> devices;            // kinematics.yaml `gpu_devices: "0,1,2,3"` (default: the single `gpu_device`): a batch is sharded over them
+    std::vector<bioik_model*> models;    // one per device
+    mutable std::map<std::string, std::vector<bioik_problem*>> problems;  // per goal structure: one compiled problem per device
 
     BioIKKinematicsPlugin() {}
-    ~BioIKKinematicsPlugin() override {
-        for (auto& kv : problems) bioik_problem_destroy(kv.second);
-        bioik_model_destroy(model);
+    ~BioIKKinematicsPlugin() override { release(); }
+    void release() {
+        for (auto& kv : problems)
+            for (auto* p : kv.second) bioik_problem_destroy(p);
+        problems.clear();
+        for (auto* m : models) bioik_model_destroy(m);
+        models.clear();
     }
 
     const std::vector<std::string>& getJointNames() const override { return joint_names; }  // :130-133
@@ -204,13 +209,26 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         lookupParam("gpu_max_steps", gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query
         lookupParam("gpu_fk", gpu_fk, std::string("exact"));  // "exact" | "linear" (the reference's linearised phenotypes)
         lookupParam("gpu_device", gpu_device, 0);
+        std::string gpu_devices;
+        lookupParam("gpu_devices", gpu_devices, std::string());
+        devices.clear();
+        {
+            std::stringstream ss(gpu_devices);
+            for (std::string item; std::getline(ss, item, ',');)
+                if (!item.empty()) devices.push_back(std::stoi(item));
+        }
+        if (devices.empty()) devices.push_back(gpu_device);
         solverMode(mode);
 
         temp_state.reset(new moveit::core::RobotState(robot_model));
         flat.reset(new FlatModel(*robot_model));
         bioik_model_desc md = flat->desc();
-        if (model) bioik_model_destroy(model), model = nullptr;
-        if (bioik_model_create(&md, gpu_device, &model) != BIOIK_OK) throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
+        release();
+        for (int dev : devices) {
+            bioik_model* m = nullptr;
+            if (bioik_model_create(&md, dev, &m) != BIOIK_OK) throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
+            models.push_back(m);
+        }
 
         default_goals.clear();  // :279-329
         for (size_t i = 0; i < tip_frames_.size(); i++) {
@@ -281,7 +299,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
     }
 
     // one compiled problem (Problem::initialize + RobotFK::initialize on the device side) per goal STRUCTURE; the numbers travel per query
-    bioik_problem* problemFor(const std::vector<const bio_ik::Goal*>& goals, const std::vector<std::string>& fixed) const {
+    const std::vector<bioik_problem*>& problemFor(const std::vector<const bio_ik::Goal*>& goals, const std::vector<std::string>& fixed) const {
         std::ostringstream key;
         key << std::hexfloat;
         for (auto* g : goals) key << g->gpuOpcode() << ':' << g->gpuLinkName() << ':' << g->gpuVariableName() << ':' << g->getWeight() << ':' << g->isSecondary() << ';';
@@ -312,10 +330,16 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         pd.n_group_joints = (uint32_t)group_joints.size(), pd.group_joints = group_joints.data();
         pd.n_goals = (uint32_t)gd.size(), pd.goals = gd.data();
         pd.n_fixed_joints = (uint32_t)fixed_idx.size(), pd.fixed_joints = fixed_idx.data();
-        bioik_problem* p = nullptr;
-        if (bioik_problem_create(model, &pd, &p) != BIOIK_OK) throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
-        problems[key.str()] = p;
-        return p;
+        std::vector<bioik_problem*> per_device;
+        for (auto* m : models) {
+            bioik_problem* p = nullptr;
+            if (bioik_problem_create(m, &pd, &p) != BIOIK_OK) {
+                for (auto* q : per_device) bioik_problem_destroy(q);
+                throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
+            }
+            per_device.push_back(p);
+        }
+        return problems[key.str()] = per_device;
     }
 
     // The batched core: n queries of one goal structure, ONE bioik_solve_batch call.  poses[k] (tips of query k; ignored with
@@ -324,7 +348,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
                     std::vector<std::vector<double>>& solutions, std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
                     const kinematics::KinematicsQueryOptions& options, const moveit::core::RobotState* context_state) const {
         std::lock_guard<std::mutex> lock(mutex);
-        if (!robot_model || !model) throw std::runtime_error("bio_ik (MI355X): plugin not initialised");
+        if (!robot_model || models.empty()) throw std::runtime_error("bio_ik (MI355X): plugin not initialised");
         auto* bio_ik_options = bio_ik::toBioIKKinematicsQueryOptions(&options);
         const size_t n = ik_seed_states.size(), V = robot_model->getVariableCount();
         // get variable default positions / context state, overwrite used variables with seed state (:465-485)
@@ -350,7 +374,8 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
             for (auto& goal : default_goals) all_goals.push_back(goal.get());
         if (bio_ik_options)
             for (auto& goal : bio_ik_options->goals) all_goals.push_back(goal.get());
-        bioik_problem* problem = problemFor(all_goals, bio_ik_options ? bio_ik_options->fixed_joints : std::vector<std::string>());
+        const std::vector<bioik_problem*>& shards = problemFor(all_goals, bio_ik_options ? bio_ik_options->fixed_joints : std::vector<std::string>());
+        bioik_problem* problem = shards.front();
         const size_t P = (size_t)bioik_problem_param_count(problem);
         // transform tips to the model frame (:487-502) and let every goal write its numbers
         Frame7 r;
@@ -389,7 +414,11 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         std::vector<int32_t> suc(n), steps(n);
         solutions.assign(n, std::vector<double>());
         error_codes.assign(n, moveit_msgs::MoveItErrorCodes());
-        if (bioik_solve_batch(problem, &sp, n, seeds.data(), params.data(), sol.data(), fit.data(), suc.data(), steps.data()) != BIOIK_OK) {
+        // one call for the whole batch: a single device, or contiguous shards over the configured devices (no exchange between shards)
+        const int rc = shards.size() == 1 ? bioik_solve_batch(problem, &sp, n, seeds.data(), params.data(), sol.data(), fit.data(), suc.data(), steps.data())
+                                          : bioik_solve_batch_multi(shards.data(), (int)shards.size(), &sp, n, seeds.data(), params.data(), sol.data(), fit.data(),
+                                                                    suc.data(), steps.data());
+        if (rc != BIOIK_OK) {
             for (auto& e : error_codes) e.val = moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;  // device errors never abort the caller
             return false;
         }

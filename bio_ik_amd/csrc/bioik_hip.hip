@@ -44,6 +44,7 @@ static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, byte
 typedef void* stream_t;
 static int be_device_count() { return 1; }
 static void be_set_device(int) {}
+static int be_get_device() { return 0; }
 static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 static void be_free(void* p) { std::free(p); }
 static void* be_alloc_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
@@ -53,6 +54,8 @@ static void be_free_async(void* p, stream_t) { std::free(p); }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
 static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
 static void be_sync(stream_t) {}
+static stream_t be_stream_create() { return nullptr; }
+static void be_stream_destroy(stream_t) {}
 template <class Body>
 static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body body) {
     std::vector<double> lds(lds_bytes / 8 + 2);
@@ -86,6 +89,11 @@ static int be_device_count() {
     return n;
 }
 static void be_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
+static int be_get_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
 static void* be_alloc(size_t bytes) {
     void* p = nullptr;
     HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
@@ -119,6 +127,14 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
 }
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 static void be_zero_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
+static stream_t be_stream_create() {
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+static void be_stream_destroy(stream_t s) {
+    if (s) (void)hipStreamDestroy(s);
+}
 
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3
@@ -188,6 +204,7 @@ struct bioik_problem {
     void* io_dev = nullptr;
     void* io_host = nullptr;
     size_t io_bytes = 0;
+    stream_t io_stream = nullptr;  // the handle's own stream: host-pointer solves of different handles overlap, also on one device
     uint64_t first_query = 0;
     // launch clocks of solves with a wall-clock timeout: a ring of words, one per launch in flight, zeroed in stream order
     unsigned long long* d_clocks = nullptr;
@@ -240,6 +257,23 @@ static int solve_threads(const DevSolveParams& sp, uint64_t units) {
     return t;
 }
 
+// every entry point runs on its handle's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+    int prev;
+    explicit DeviceGuard(int device) : prev(be_get_device()) {
+        if (prev != device) be_set_device(device);
+    }
+    ~DeviceGuard() {
+        if (be_get_device() != prev) {
+            try {
+                be_set_device(prev);
+            } catch (...) {
+            }
+        }
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+};
+
 struct DevBuf {
     void* p = nullptr;
     explicit DevBuf(size_t bytes) : p(be_alloc(bytes)) {}
@@ -264,6 +298,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const DevProblem& dp = p->host.dev;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
+    if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
     // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
     // and evaluated in pairs / kept / re-derived from the RNG, or 64 lanes (one wavefront, the species one after the other).  A CU
     // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
@@ -344,7 +379,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0;
     if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
         if (std::atoi(e) != 0) lean = false;
-    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered
+    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered; released on every path out
+    struct AsyncFree {
+        void*& p;
+        stream_t s;
+        ~AsyncFree() { be_free_async(p, s); }
+    } island_ws_guard{island_ws, stream};
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;
@@ -399,7 +439,6 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         hipLaunchKernelGGL(k_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s);
         HIP_CHECK(hipGetLastError());
 #endif
-        be_free_async(island_ws, stream);
     }
 }
 
@@ -446,10 +485,14 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     API_BEGIN
     if (!model || !desc || !out) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
+    if (desc->struct_size != sizeof(bioik_problem_desc)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_problem_desc: struct_size mismatch");
+    if ((desc->n_goals && !desc->goals) || (desc->n_group_joints && !desc->group_joints) || (desc->n_fixed_joints && !desc->fixed_joints))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_problem_desc: a count is non-zero but its array is null");
     std::unique_ptr<bioik_problem> p(new bioik_problem(model, *desc));
-    be_set_device(model->device);
+    DeviceGuard on_device(model->device);
     p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
     p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kClocks * sizeof(unsigned long long));
+    p->io_stream = be_stream_create();
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
     be_sync(0);
     *out = p.release();
@@ -459,6 +502,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
     be_free(p->d_clocks);
+    be_stream_destroy(p->io_stream);
     be_free(p->io_dev);
     be_free_pinned(p->io_host);
     delete p;
@@ -491,21 +535,18 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
     if (n && (!d_seeds || !d_solutions || !d_fitness || !d_success || !d_steps || (p->host.dev.P > 0 && !d_goal_params)))
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
     launch_solve(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream);
     API_END
 }
 
-int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
-                      double* fitness, int32_t* success, int32_t* steps) {
-    API_BEGIN
-    if (!p || !params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
-    if (n && (!seeds || !solutions || !fitness || !success || !steps || (p->host.dev.P > 0 && !goal_params)))
-        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
-    if (n == 0) return BIOIK_OK;
+// host arrays in, host arrays out: staged through the handle's page-locked arena, one DMA each way, on the handle's own stream
+static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint64_t first_query, size_t n, const double* seeds, const double* goal_params,
+                       double* solutions, double* fitness, int32_t* success, int32_t* steps) {
+    if (n == 0) return;
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const size_t V = p->host.dev.V, P = p->host.dev.P;
     // arena layout: [seeds | goal_params] in, [solutions | fitness | success | steps] out, every block 64-byte aligned
     auto up = [](size_t b) { return (b + 63) / 64 * 64; };
@@ -522,18 +563,70 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
     }
     char* hd = (char*)p->io_host;
     char* dd = (char*)p->io_dev;
+    const stream_t st = p->io_stream;
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
-    be_h2d(dd, hd, in_bytes, 0);
-    DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
+    be_h2d(dd, hd, in_bytes, st);
+    DevSolveParams sp = bioik::normalize_params(params, first_query);
     launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(dd + o_sol), (double*)(dd + o_fit), (int32_t*)(dd + o_suc),
-                 (int32_t*)(dd + o_steps), 0);
-    be_d2h(hd + o_sol, dd + o_sol, total - in_bytes, 0);
-    be_sync(0);
+                 (int32_t*)(dd + o_steps), st);
+    be_d2h(hd + o_sol, dd + o_sol, total - in_bytes, st);
+    be_sync(st);
     std::memcpy(solutions, hd + o_sol, n * V * 8);
     std::memcpy(fitness, hd + o_fit, n * 8);
     std::memcpy(success, hd + o_suc, n * 4);
     std::memcpy(steps, hd + o_steps, n * 4);
+}
+
+int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
+                      double* fitness, int32_t* success, int32_t* steps) {
+    API_BEGIN
+    if (!p || !params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n && (!seeds || !solutions || !fitness || !success || !steps || (p->host.dev.P > 0 && !goal_params)))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    solve_host(p, *params, p->first_query, n, seeds, goal_params, solutions, fitness, success, steps);
+    API_END
+}
+
+// One batch over several problem handles of the SAME template -- one per device of the node, or several on one device: shard r =
+// queries [r n / W, (r + 1) n / W), one host thread per handle, each on its handle's stream; no exchange between the shards (the
+// queries are independent), and the query-indexed random streams make the result identical to the unsharded solve.
+int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, const bioik_solve_params* params, size_t n, const double* seeds,
+                            const double* goal_params, double* solutions, double* fitness, int32_t* success, int32_t* steps) {
+    API_BEGIN
+    if (!problems || n_problems <= 0 || !params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    for (int r = 0; r < n_problems; r++) {
+        if (!problems[r]) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null problem handle");
+        const DevProblem &a = problems[0]->host.dev, &b = problems[r]->host.dev;
+        if (a.V != b.V || a.P != b.P || a.D != b.D || a.T != b.T || a.n_ops != b.n_ops)
+            throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_batch_multi: the handles were compiled from different problem templates");
+        for (int q = 0; q < r; q++)
+            if (problems[q] == problems[r]) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_batch_multi: the same handle twice");
+    }
+    const size_t V = problems[0]->host.dev.V, P = problems[0]->host.dev.P;
+    if (n && (!seeds || !solutions || !fitness || !success || !steps || (P > 0 && !goal_params))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    const uint64_t first = problems[0]->first_query;
+    const size_t W = (size_t)n_problems;
+    std::vector<int> status(W, BIOIK_OK);
+    std::vector<std::string> message(W);
+    std::vector<std::thread> workers;
+    for (size_t r = 0; r < W; r++) {
+        const size_t a = r * n / W, b = (r + 1) * n / W;
+        if (a == b) continue;
+        workers.emplace_back([&, r, a, b]() {
+            try {
+                solve_host(problems[r], *params, first + a, b - a, seeds + a * V, P ? goal_params + a * P : nullptr, solutions + a * V, fitness + a,
+                           success + a, steps + a);
+            } catch (const Error& e) {
+                status[r] = e.code, message[r] = e.what();
+            } catch (const std::exception& e) {
+                status[r] = BIOIK_ERR_INVALID_ARGUMENT, message[r] = e.what();
+            }
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (size_t r = 0; r < W; r++)
+        if (status[r] != BIOIK_OK) throw Error(status[r], "shard " + std::to_string(r) + ": " + message[r]);
     API_END
 }
 
@@ -551,7 +644,7 @@ int bioik_eval_fk(bioik_problem* p, size_t n, const double* seed, const double* 
     if (!p || !seed || (n && (!genes || !tip_frames))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return BIOIK_OK;
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const size_t V = p->host.dev.V, D = p->host.dev.D, T = p->host.dev.T;
     DevBuf dseed(V * 8), dgenes(n * D * 8), dout(n * T * 7 * 8);
     be_h2d(dseed.p, seed, V * 8, 0);
@@ -574,7 +667,7 @@ int bioik_eval_fitness(bioik_problem* p, int fk_mode, size_t n, const double* se
     if (p->host.dev.P > 0 && !goal_params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "goal_params required");
     if (n == 0) return BIOIK_OK;
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const size_t V = p->host.dev.V, D = p->host.dev.D, P = p->host.dev.P;
     DevBuf dseed(V * 8), dpar(P * 8), dbase(D * 8), dgenes(n * D * 8), d0(n * 8), d1(n * 8);
     be_h2d(dseed.p, seed, V * 8, 0);
@@ -596,7 +689,7 @@ int bioik_eval_approximator(bioik_problem* p, const double* seed, const double* 
     API_BEGIN
     if (!p || !seed || !base_genes || !tip_frames || !deltas) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const size_t V = p->host.dev.V, D = p->host.dev.D, T = p->host.dev.T;
     DevBuf dseed(V * 8), dbase(D * 8), d0(T * 7 * 8), d1(T * D * 7 * 8);
     be_h2d(dseed.p, seed, V * 8, 0);
@@ -616,7 +709,7 @@ int bioik_eval_reproduce(bioik_problem* p, int population, uint32_t rng_key, int
     API_BEGIN
     if (!p || !parents || !children_genes || !children_gradients || population <= 0) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const size_t D = p->host.dev.D, n = (size_t)population;
     DevBuf dpar(4 * D * 8), d0(n * D * 8), d1(n * D * 8);
     be_h2d(dpar.p, parents, 4 * D * 8, 0);
@@ -640,7 +733,7 @@ int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t 
     if (p->host.dev.P > 0 && !goal_params) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "goal_params required");
     if (n == 0) return BIOIK_OK;
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     DevSolveParams sp = bioik::normalize_params(*params, 0);
     const size_t V = p->host.dev.V, D = p->host.dev.D, P = p->host.dev.P;
     DevBuf dseed(V * 8), dpar(P * 8), dgenes(n * D * 8), dok(n * 4);
@@ -664,7 +757,7 @@ int bioik_stream_fitness_device(bioik_problem* p, size_t n_units, int population
     if (n_units && (!d_seeds || !d_genes || !d_fitness || (p->host.dev.P > 0 && !d_goal_params))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     if (n_units == 0) return BIOIK_OK;
     std::lock_guard<std::mutex> lock(p->mtx);
-    be_set_device(p->model->device);
+    DeviceGuard on_device(p->model->device);
     const int nth = population >= 256 ? 256 : (population + 63) / 64 * 64;
     StreamArgs a;
     a.pb = p->pb();

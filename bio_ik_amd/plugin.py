@@ -169,26 +169,15 @@ class BioIKKinematicsPlugin:
                     f[3:7] = q * (1.0 / np.sqrt(float(q @ q)))  # PoseGoal::setOrientation (goal_types.h:146, tf2 normalized()), :543-544
                     params[k, off:off + 7] = f
         sp = self._solve_params(timeout)
-        sol = np.zeros_like(state)
-        fit = np.zeros(n)
-        suc = np.zeros(n, dtype=np.int32)
-        bounds = np.linspace(0, n, len(devices) + 1).astype(int)
-
-        def run(di):
-            a, b = bounds[di], bounds[di + 1]
-            if a == b:
-                return
-            _, h = self._solver_for(goals, fixed, devices[di])
-            h.set_first_query(first_query + a)  # shards keep the RNG streams of the unsharded batch
-            s, f, u, _ = h.solve_batch(sp, state[a:b], params[a:b])
-            sol[a:b], fit[a:b], suc[a:b] = s, f, u
-
-        if len(devices) == 1:
-            run(0)
-        else:  # one host thread per GPU; the C call releases the GIL
-            th = [threading.Thread(target=run, args=(i,)) for i in range(len(devices))]
-            [t.start() for t in th]
-            [t.join() for t in th]
+        # one C-ABI call: a single device, or contiguous shards over the listed devices (bioik_solve_batch_multi: one host thread and stream
+        # per device inside the library, query-indexed RNG streams -> identical to the unsharded solve)
+        handles = [self._solver_for(goals, fixed, d)[1] for d in devices]
+        handles[0].set_first_query(first_query)
+        if len(handles) == 1:
+            sol, fit, suc, _ = handles[0].solve_batch(sp, state, params)
+        else:
+            sol, fit, suc, _ = handles[0].solve_batch_multi(handles[1:], sp, state, params)
+        handles[0].set_first_query(0)
         active = self._solver_for(goals, fixed, devices[0])[1].active_variables
         sol = self._wrap_angles(sol, state, active)
         solutions = sol[:, self._group_vars]  # kinematics_plugin.cpp:619-629

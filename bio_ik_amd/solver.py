@@ -25,7 +25,7 @@ EXPORTS = [
     "bioik_goal_param_count", "bioik_default_solve_params", "bioik_last_error", "bioik_abi_version", "bioik_device_count",
     "bioik_model_create", "bioik_model_destroy", "bioik_problem_create", "bioik_problem_destroy",
     "bioik_problem_active_variable_count", "bioik_problem_active_variables", "bioik_problem_tip_count", "bioik_problem_tip_links",
-    "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch",
+    "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch", "bioik_solve_batch_multi",
     "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
     "bioik_eval_check", "bioik_stream_fitness_device",
 ]
@@ -53,6 +53,7 @@ def _declare(L):
     L.bioik_default_solve_params.argtypes = [C.POINTER(abi.SolveParams)]
     L.bioik_default_solve_params.restype = None
     L.bioik_solve_batch.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi]
+    L.bioik_solve_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi]
     L.bioik_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
     L.bioik_eval_fk.argtypes = [C.c_void_p, C.c_size_t, _pd, _pd, _pd]
@@ -188,6 +189,20 @@ class HipSolver:
         suc = np.zeros(n, dtype=np.int32)
         steps = np.zeros(n, dtype=np.int32)
         self._chk(self.L.bioik_solve_batch(self.problem, C.byref(params), n, _d(s), _d(gp), _d(sol), _d(fit), _i(suc), _i(steps)))
+        return sol, fit, suc, steps
+
+    def solve_batch_multi(self, others, params, seeds, goal_params):
+        """One batch over this handle and `others` (HipSolver objects of the same template, e.g. one per GPU): contiguous shards, one host
+        thread and stream per handle inside the library (bioik_solve_batch_multi); equals solve_batch on one handle bit for bit."""
+        s = _f64(seeds).reshape(-1, self.V)
+        n = s.shape[0]
+        gp = self._gp(goal_params, n)
+        sol = np.zeros((n, self.V))
+        fit = np.zeros(n)
+        suc = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.int32)
+        handles = (C.c_void_p * (1 + len(others)))(self.problem, *[o.problem for o in others])
+        self._chk(self.L.bioik_solve_batch_multi(handles, 1 + len(others), C.byref(params), n, _d(s), _d(gp), _d(sol), _d(fit), _i(suc), _i(steps)))
         return sol, fit, suc, steps
 
     def solve_batch_device(self, params, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, stream=0):

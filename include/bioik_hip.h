@@ -218,6 +218,15 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
                       const double* goal_params, double* solutions, double* fitness, int32_t* success,
                       int32_t* steps);
 
+/* The same batch over several problem handles of ONE template — one handle per GPU of the node (the "device list" of the batched
+ * searchPositionIK()), or several handles on one device.  Shard r = queries [r n / W, (r + 1) n / W) goes
+ * to problems[r] on its own host thread and stream; there is no exchange between shards, and because the random stream of a query is
+ * keyed by its global index (the offset set on problems[0] + its position in this batch) the result equals the unsharded solve bit
+ * for bit.  Host pointers; returns when every shard is complete; the first failing shard's status is returned. */
+int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, const bioik_solve_params* params, size_t n,
+                            const double* seeds, const double* goal_params, double* solutions, double* fitness,
+                            int32_t* success, int32_t* steps);
+
 /* Device-pointer variant: all arrays already resident in HBM on the problem's device; enqueues on
  * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising.
  * Launches of ONE problem handle on different streams may be in flight together (their result arrays must differ, the

@@ -238,6 +238,24 @@ def test_full_size_mixed_batch_on_one_gpu(gpus, oracles, templates):
         assert perr[g[2] == 1].max() < POS_TOL and rerr[g[2] == 1].max() < ROT_TOL
 
 
+def test_solve_batch_multi_two_handles_on_one_gpu(gpus, templates):
+    """the C-ABI form of the multi-GPU split (bioik_solve_batch_multi): on this one-GPU box two handles on device 0 take the two shards
+    on their own host threads and streams; the result equals the single-handle solve bit for bit, and the caller's device is untouched"""
+    import torch
+    from bio_ik_amd.solver import HipSolver
+    h, t = gpus["c2"], templates["c2"]
+    other = HipSolver(t, device=0)
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 4096, seed=77)
+    p = abi.default_solve_params(population=128, max_steps=48, random_seed=6)
+    h.set_first_query(12345)
+    want = h.solve_batch(p, seeds, params)
+    got = h.solve_batch_multi([other], p, seeds, params)
+    h.set_first_query(0)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    assert got[2].mean() > 0.98
+    assert torch.cuda.current_device() == 0
+
+
 def test_sharded_batch_equals_whole_batch(gpus, templates):
     """the multi-GPU split: shards solved separately with their query offsets reproduce the unsharded batch"""
     h, t = gpus["c2"], templates["c2"]

@@ -205,3 +205,25 @@ def test_wall_clock_timeout(sims, oracles, templates):
     assert np.all(tight[3] == 1)  # one step each (`iteration != 0`), the state after that step is what comes back
     one = h.solve_batch(abi.default_solve_params(population=16, max_steps=1, random_seed=2), seeds, params)
     assert all(np.array_equal(a, b) for a, b in zip(tight, one))
+
+
+def test_solve_batch_multi_equals_single_handle(hostsim_lib, templates, sims):
+    """bioik_solve_batch_multi: three handles of one template (on a node: one per GPU), contiguous shards, one host thread each;
+    identical to the single-handle solve, also with a query offset and with fewer queries than handles"""
+    t = templates["c2"]
+    from bio_ik_amd.workload import make_queries
+    h0 = sims["c2"]
+    others = [HipSolver(t, lib=hostsim_lib) for _ in range(2)]
+    seeds, params, _ = make_queries(t, h0.active_variables, h0.fk_genes, 7, seed=31)
+    p = abi.default_solve_params(population=16, max_steps=3, random_seed=8)
+    for first in (0, 1000):
+        h0.set_first_query(first)
+        want = h0.solve_batch(p, seeds, params)
+        got = h0.solve_batch_multi(others, p, seeds, params)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        got2 = h0.solve_batch_multi(others, p, seeds[:2], params[:2])
+        assert all(np.array_equal(a[:2], b) for a, b in zip(want, got2))
+    h0.set_first_query(0)
+    from bio_ik_amd.solver import BioIKError
+    with pytest.raises(BioIKError):
+        h0.solve_batch_multi([sims["c3"]], p, seeds, params)  # another template
