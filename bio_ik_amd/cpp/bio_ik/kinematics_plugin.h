@@ -65,6 +65,7 @@ class BioIKKinematicsPlugin {
     }
     bioik_problem* problemFor(const std::vector<const bio_ik::Goal*>& goals, const std::vector<std::string>& fixed) const {
         std::ostringstream key;
+        key << std::hexfloat;  // exact weight bits: goals whose weights differ in any digit get their own compiled problem
         for (auto* g : goals) key << g->gpuOpcode() << ':' << g->gpuLinkName() << ':' << g->gpuVariableName() << ':' << g->getWeight() << ':' << g->isSecondary() << ';';
         for (auto& f : fixed) key << '#' << f;
         auto it = problems.find(key.str());
@@ -110,7 +111,8 @@ public:
         joint_names.clear(), group_vars.clear();
         for (int j : jmg.active_joints) {
             joint_names.push_back(rm.joint_names[j]);
-            group_vars.push_back(rm.joint_first_variable[j]);
+            const int nv = rm.joint_type[j] == BIOIK_JOINT_FLOATING ? 7 : (rm.joint_type[j] == BIOIK_JOINT_PLANAR ? 3 : 1);
+            for (int vi = 0; vi < nv; vi++) group_vars.push_back(rm.joint_first_variable[j] + vi);  // every variable of the joint (:473-484)
         }
         link_names = tip_frames;
         bioik_model_desc md = rm.desc();
@@ -201,13 +203,15 @@ public:
         bool all_ok = true;
         for (size_t k = 0; k < n; k++) {
             double* st = &sol[k * V];
-            // wrap angles (:580-613; no mimic joints on the device path)
+            // wrap angles (:580-613); skipped, as in the reference, for models with mimic joints (:583-584)
+            bool has_mimic = false;
+            for (int m : robot_model->joint_mimic) has_mimic = has_mimic || m >= 0;
             for (int ivar : active) {
                 double v = st[ivar];
                 bool revolute = false;
                 for (size_t l = 0; l < robot_model->joint_type.size(); l++)
                     if (robot_model->joint_first_variable[l] == ivar) revolute = robot_model->joint_type[l] == BIOIK_JOINT_REVOLUTE;
-                if (revolute) {
+                if (revolute && !has_mimic) {
                     double rr = state[k * V + ivar], lo = robot_model->var_min[ivar], hi = robot_model->var_max[ivar];
                     if (rr < v - M_PI || rr > v + M_PI) {
                         v -= rr, v /= (2 * M_PI), v += 0.5, v -= std::floor(v), v -= 0.5, v *= (2 * M_PI), v += rr;
@@ -219,8 +223,20 @@ public:
                 }
                 st[ivar] = v;
             }
-            for (size_t v = 0; v < V; v++)  // RobotModel::enforcePositionBounds (:616)
-                if (robot_model->var_bounded[v]) st[v] = std::min(std::max(st[v], robot_model->var_min[v]), robot_model->var_max[v]);
+            for (size_t v = 0; v < V; v++) {  // RobotModel::enforcePositionBounds (:616): clamp bounded variables, wrap continuous joints
+                if (robot_model->var_bounded[v]) {
+                    st[v] = std::min(std::max(st[v], robot_model->var_min[v]), robot_model->var_max[v]);
+                } else if (st[v] <= -M_PI || st[v] > M_PI) {
+                    bool revolute = false;
+                    for (size_t l = 0; l < robot_model->joint_type.size(); l++)
+                        if (robot_model->joint_first_variable[l] == (int)v) revolute = robot_model->joint_type[l] == BIOIK_JOINT_REVOLUTE;
+                    if (revolute) {
+                        st[v] = std::fmod(st[v], 2 * M_PI);
+                        if (st[v] <= -M_PI) st[v] += 2 * M_PI;
+                        else if (st[v] > M_PI) st[v] -= 2 * M_PI;
+                    }
+                }
+            }
             for (int gv : group_vars) solutions[k].push_back(st[gv]);  // :619-629
             bool ok = suc[k] || options.return_approximate_solution;  // :638-641
             error_codes[k].val = ok ? moveit_msgs::MoveItErrorCodes::SUCCESS : moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;

@@ -14,11 +14,6 @@
 #pragma once
 #include "bioik_platform.h"
 
-#if defined(BIOIK_HOSTSIM)
-#define BIOIK_FP_STRICT
-#else
-#define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
-#endif
 
 // goal opcodes / modes: numeric values of include/bioik_hip.h (kept in sync by a static_assert in bioik_hip.hip)
 enum {

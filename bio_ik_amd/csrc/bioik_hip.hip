@@ -1,9 +1,9 @@
 // bioik_hip.hip — the C-ABI of include/bioik_hip.h: __global__ entry points for gfx950 and the thin host shim
 // that owns device memory and launches them.  No torch, no C++ types across the boundary.
 //
-// The same file builds the test-only host simulator (tests/hostsim, -DBIOIK_HOSTSIM): there "device memory" is
-// host memory and a launch runs every workgroup as a gang of OS threads.  The product library is always built by
-// hipcc for gfx950 and refuses to do anything without a HIP device.
+// The library is built by hipcc for gfx950 and refuses to do anything without a HIP device; there is no CPU execution path in it.
+// (The test-suite compiles this file a second time with a substitute back end that lives under tests/hostsim and arrives through
+// BIOIK_BACKEND_HEADER / BIOIK_PLATFORM_HEADER; the product build defines neither.)
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -31,51 +31,8 @@ static thread_local std::string g_err;
 // ------------------------------------------------------------------------------------------------------------
 // back end: memory + launch
 // ------------------------------------------------------------------------------------------------------------
-#if defined(BIOIK_HOSTSIM)
-namespace sim {
-thread_local Block* blk = nullptr;
-thread_local int tid = 0;
-}  // namespace sim
-#include <chrono>
-unsigned long long sim_wall_clock() {
-    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
-}
-static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, bytes); }
-typedef void* stream_t;
-static int be_device_count() { return 1; }
-static void be_set_device(int) {}
-static int be_get_device() { return 0; }
-static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
-static void be_free(void* p) { std::free(p); }
-static void* be_alloc_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
-static void be_free_pinned(void* p) { std::free(p); }
-static void* be_alloc_async(size_t bytes, stream_t) { return std::malloc(bytes ? bytes : 1); }
-static void be_free_async(void* p, stream_t) { std::free(p); }
-static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
-static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }
-static void be_sync(stream_t) {}
-static stream_t be_stream_create() { return nullptr; }
-static void be_stream_destroy(stream_t) {}
-template <class Body>
-static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body body) {
-    std::vector<double> lds(lds_bytes / 8 + 2);
-    for (uint64_t b = 0; b < grid; b++) {
-        sim::Block blk;
-        blk.nthreads = block;
-        blk.block_id = (int)b;
-        blk.bar.reset(new std::barrier<>(block));
-        for (int w = 0; w < block / 64; w++) blk.wave_bar.emplace_back(new std::barrier<>(64));
-        blk.xchg.assign((size_t)block, 0);
-        std::vector<std::thread> th;
-        for (int t = 0; t < block; t++)
-            th.emplace_back([&, t]() {
-                sim::blk = &blk;
-                sim::tid = t;
-                body(b, lds.data());
-            });
-        for (auto& t : th) t.join();
-    }
-}
+#if defined(BIOIK_BACKEND_HEADER)
+#include BIOIK_BACKEND_HEADER  // test builds only (tests/hostsim): a substitute back end; the product never defines it
 #else
 typedef hipStream_t stream_t;
 #define HIP_CHECK(expr)                                                                                       \
@@ -174,17 +131,18 @@ __global__ void __launch_bounds__(256) k_stream_fitness(StreamArgs a) {
     extern __shared__ double lds[];
     stream_fitness_body(a, blockIdx.x, lds);
 }
-#endif
-
-// one launch macro for both back ends: BODYCALL is the kernel body as a function of (b_, l_) = (block index, LDS base)
-#if defined(BIOIK_HOSTSIM)
-#define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args) be_launch(grid, block, lds, stream, [&](uint64_t b_, double* l_) { BODYCALL; })
-#else
+// a launch: KERNEL with `args`; BODYCALL names the same kernel body as a function of (b_, l_) = (block index, LDS base) for back ends
+// that call it directly
 #define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args)                                      \
     do {                                                                                              \
         hipLaunchKernelGGL(KERNEL, dim3((unsigned)(grid)), dim3(block), lds, stream, args);           \
         HIP_CHECK(hipGetLastError());                                                                 \
     } while (0)
+// more than 64 KiB of dynamic LDS per workgroup must be allowed explicitly
+static void be_allow_lds(size_t bytes) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
@@ -370,12 +328,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                      dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, lds, (L.slots - L.xcol) * 8,
                      (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(160 * 1024 / lds), (int)(160 * 1024 / lds) * (nth / 64));
     }
-#if !defined(BIOIK_HOSTSIM)
-    if (lds > 64 * 1024) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-#endif
+    if (lds > 64 * 1024) be_allow_lds(lds);
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0;
     if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
         if (std::atoi(e) != 0) lean = false;
@@ -396,7 +349,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         a.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
         be_zero_async(a.launch_clock, sizeof(unsigned long long), stream);
     }
-#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+#if defined(BIOIK_PHASE_TIMING)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
     const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
     if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
@@ -417,7 +370,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         LAUNCH(k_solve_lean, solve_body<true>(a, b_, l_), units, nth, lds, stream, a);
     else
         LAUNCH(k_solve, solve_body<false>(a, b_, l_), units, nth, lds, stream, a);
-#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+#if defined(BIOIK_PHASE_TIMING)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
         std::vector<unsigned long long> h(units * PHASE_SLOTS);
         be_d2h(h.data(), phase_buf.p, h.size() * sizeof(unsigned long long), stream);
@@ -433,12 +386,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         s.islands = sp.islands, s.V = dp.V, s.n = n;
         s.isl_solutions = a.solutions, s.isl_fitness = a.fitness, s.isl_success = a.success, s.isl_steps = a.steps;
         s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
-#if defined(BIOIK_HOSTSIM)
-        for (uint64_t q = 0; q < n; q++) select_body(s, q);
-#else
-        hipLaunchKernelGGL(k_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s);
-        HIP_CHECK(hipGetLastError());
-#endif
+        LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
     }
 }
 

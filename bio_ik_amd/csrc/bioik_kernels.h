@@ -16,11 +16,6 @@
 
 #include "bioik_device.h"
 
-#if defined(BIOIK_HOSTSIM)
-#define BIOIK_HD inline
-#else
-#define BIOIK_HD __host__ __device__ inline
-#endif
 
 struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species group (stride g_stride)
     int seed, par, pop, sol, prefix, state, clip, xcol, slots, g_first, g_stride, total;

@@ -1,79 +1,16 @@
 // bioik_platform.h — the handful of execution-model primitives the kernels are written against.
 //
-// Product build (hipcc, gfx950): thin inline wrappers over the CDNA4 wave64 builtins.
-// BIOIK_HOSTSIM build (g++, tests/hostsim only): every lane of a workgroup is an OS thread and the cross-lane
-// primitives rendezvous on barriers, so the SAME kernel bodies can be stepped against the CPU oracle on a machine
-// without a GPU.  The simulator is test infrastructure; nothing in the product library is built with BIOIK_HOSTSIM.
+// They are thin inline wrappers over the CDNA4 wave64 builtins; this is the only execution model the product is built for
+// (hipcc, gfx950).  The kernel bodies are written against these names alone, which is what lets the test-suite compile the SAME
+// bodies with a substitute set of primitives (a host simulator that lives entirely under tests/hostsim and is injected through
+// BIOIK_PLATFORM_HEADER; the product build never defines it and contains no CPU execution path).
 #pragma once
 #include <stdint.h>
 
 #include "bioik_types.h"
 
-#if defined(BIOIK_HOSTSIM)
-// ------------------------------------------------------------------------------------------------------------
-#include <barrier>
-#include <cmath>
-#include <cstring>
-#include <memory>
-#include <vector>
-#define BIOIK_DEV inline
-#define BIOIK_CALL __attribute__((noinline)) inline
-typedef double lds_f64;
-#define BIOIK_CONTRACT_OFF
-typedef const DevProblem* ProbPtr;
-typedef const DevProblemLean* LeanProbPtr;
-
-namespace sim {
-struct Block {
-    int nthreads = 0;
-    int block_id = 0;
-    std::unique_ptr<std::barrier<>> bar;
-    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
-    std::vector<uint64_t> xchg;  // [waves][64]
-    char* lds = nullptr;
-};
-extern thread_local Block* blk;
-extern thread_local int tid;
-}  // namespace sim
-
-BIOIK_DEV int p_tid() { return sim::tid; }
-BIOIK_DEV int p_nthreads() { return sim::blk->nthreads; }
-BIOIK_DEV void p_barrier() { sim::blk->bar->arrive_and_wait(); }
-BIOIK_DEV void p_wave_sync() { sim::blk->wave_bar[sim::tid >> 6]->arrive_and_wait(); }
-template <class T>
-BIOIK_DEV T p_shfl(T v, int src_lane) {
-    static_assert(sizeof(T) <= 8, "");
-    int w = sim::tid >> 6, l = sim::tid & 63;
-    uint64_t bits = 0;
-    std::memcpy(&bits, &v, sizeof(T));
-    uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
-    x[l] = bits;
-    sim::blk->wave_bar[w]->arrive_and_wait();
-    uint64_t r = x[src_lane & 63];
-    sim::blk->wave_bar[w]->arrive_and_wait();
-    T out;
-    std::memcpy(&out, &r, sizeof(T));
-    return out;
-}
-template <class T>
-BIOIK_DEV T p_shfl_xor(T v, int mask) { return p_shfl(v, (sim::tid & 63) ^ mask); }
-template <int MASK, class T>
-BIOIK_DEV T p_quad_xor(T v) { return p_shfl_xor(v, MASK); }
-template <int HALF, class T>  // lane i <-> 15 - i of its row of 16 (HALF = 0) or 7 - i of its half row (HALF = 1)
-BIOIK_DEV T p_row_mirror(T v) {
-    const int l = sim::tid & 63;
-    return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))));
-}
-BIOIK_DEV int p_uniform(int v) { return v; }
-BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
-unsigned long long sim_wall_clock();  // 100 MHz ticks of a steady host clock (defined with the simulator's back end)
-BIOIK_DEV unsigned long long p_wall_clock() { return sim_wall_clock(); }
-BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned long long value) {  // first caller's value wins; returns the winner
-    unsigned long long expected = 0ull;
-    return __atomic_compare_exchange_n(word, &expected, value, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? value : expected;
-}
-#define P_INF (__builtin_inf())
-
+#if defined(BIOIK_PLATFORM_HEADER)
+#include BIOIK_PLATFORM_HEADER
 #else
 // ------------------------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
@@ -130,6 +67,8 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     return old ? old : value;
 }
 #define P_INF (__builtin_inf())
+#define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
+#define BIOIK_HD __host__ __device__ inline
 #endif
 
 // Kernel flavour, carried by the TYPE of the problem pointer so that it reaches every device function by argument deduction:
@@ -146,7 +85,7 @@ struct pb_flavour<LeanProbPtr> {
 
 // Phase profiler (the reference's BLOCKPROFILER taxonomy, src/ik_evolution_2.cpp:330-437,605): compiled in only with
 // -DBIOIK_PHASE_TIMING; lane 0 of the workgroup accumulates shader-clock cycles per phase.
-#if defined(BIOIK_PHASE_TIMING) && !defined(BIOIK_HOSTSIM)
+#if defined(BIOIK_PHASE_TIMING)
 #define PHASE_N 24      // phases (PH_*)
 #define PHASE_SLOTS 28  // PHASE_N phases, then: start / end of the workgroup on the 100 MHz wall clock, HW_ID | XCC_ID << 32, spare
 #define PHASE_DECL unsigned long long ph_t_[PHASE_N] = {0}, ph_last_ = __builtin_readcyclecounter(), ph_start_ = wall_clock64()

@@ -83,8 +83,9 @@ class BioIKKinematicsPlugin:
         self._lo = np.asarray(robot_model.var_min, dtype=np.float64)
         self._hi = np.asarray(robot_model.var_max, dtype=np.float64)
         self._revolute = np.array([robot_model.joint_type[self._joint_of_var(v)] == abi.JOINT_REVOLUTE for v in range(robot_model.n_variables)])
-        span = self._hi - self._lo
-        self._bounded = np.asarray(robot_model.var_bounded, dtype=bool) & ~(self._revolute & (span >= 2 * np.pi * 0.9999))
+        # MoveIt decides clamp-or-wrap by the variable's position_bounded flag (continuous joints are unbounded), not by the width of its
+        # limits (that rule belongs to RobotInfo's clip range, robot_info.h:82-90): a revolute joint with limits of +-3.2 rad is clamped
+        self._bounded = np.asarray(robot_model.var_bounded, dtype=bool)
         self._has_mimic = any(m >= 0 for m in robot_model.joint_mimic)
         return True
 
