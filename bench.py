@@ -12,11 +12,14 @@ of the next ones; `one_batch_at_a_time` holds the same measurement with strictly
 (profiles/r01_inflight_sweep.log: 1 / 2 / 3 in flight).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_solve against the HBM roofline: ALGORITHMIC bytes per launch (SURVEY.md §8d,
-               B_gen = 8*(pop*(3D+1) + 8D) per generation per species per query, from the device step counters)
-               / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s.  The fused kernel
-               keeps the population in LDS, so the measured HBM traffic (profiles/) is far below the algorithmic
-               figure; the kernel is FP64-VALU bound.
+  roofline     dominant kernel k_solve_lean against the roof that binds it, FP64 vector arithmetic: ALGORITHMIC flops per launch
+               (130 L_m + 40 R + 25 G_pose per exact-FK evaluation of an individual, times the evaluations counted by
+               the device step counters) / mean launch duration measured with HIP events on the launch stream, vs the 78.6 TFLOP/s
+               FP64 vector peak of MI355X.  `roofline.hbm` holds the HBM figure the same way (§8d B_gen = 8*(pop*(3D+1) + 8D)
+               bytes per generation per species per query vs 8 TB/s): the fused kernel keeps the population in LDS, so those bytes
+               are notional and `traffic` (measured, profiles/) is far below them.
+  configs      the other single-GPU configurations of BASELINE.json (c3: PR2 `all`, two tips + MinimalDisplacement; c4: 31-DOF snake,
+               pop=512 + AvoidJointLimits) at 4096 queries per launch: solves/s, success, ms per batch, their own roofline figures.
   cpu_baseline the reference's own CPU code (oracle/_ref: the reference sources compiled unmodified, Release flags) when the
                prebuilt library is present, else the oracle port; timed on this host, rank 0, N=1 only, one thread, on a
                bounded sample of the same queries.  The port at the GPU run's own parameters is reported beside it.
@@ -39,6 +42,126 @@ POP = int(os.environ.get("BIOIK_BENCH_POP", "128"))
 FK_MODE = os.environ.get("BIOIK_BENCH_FK", "exact")
 MAX_STEPS = int(os.environ.get("BIOIK_BENCH_MAX_STEPS", "64"))
 HBM_PEAK = 8.0e12
+FP64_PEAK = 78.6e12  # MI355X FP64 vector (non-matrix) peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_evaluation(n_moving, n_revolute, n_pose_goals):
+    """algorithmic flops of ONE exact-FK fitness evaluation of ONE individual"""
+    return 130.0 * n_moving + 40.0 * n_revolute + 25.0 * n_pose_goals
+
+
+def _timed_device_solves(h, p, n, d_seeds, d_params, bufs, streams, reps):
+    import torch
+    nfl = len(streams)
+    ev = []
+
+    def step(i):
+        o = bufs[i % nfl]
+        h.solve_batch_device(p, n, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+    for i in range(nfl):
+        step(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(streams[i % nfl])
+        step(i)
+        b.record(streams[i % nfl])
+        ev.append((a, b))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / reps
+    return dt, float(sum(a.elapsed_time(b) for a, b in ev) / len(ev))
+
+
+def other_configs(dev, nfl, streams):
+    """BASELINE.json configs[2] and configs[3] at 4096 queries per launch, the same issue pattern as the headline figure"""
+    import numpy as np
+    import torch
+
+    from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, ProblemTemplate, abi, pr2_like, snake
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.workload import make_queries
+    n = 4096
+    res = {}
+    for name, template, pop, max_steps, n_moving, n_rev, n_pose, reps in (
+            ("c3", ProblemTemplate(pr2_like(), "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]), 128, 128, 17, 14, 2, 6),
+            ("c4", ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]), 512, 32, 31, 31, 1, 6)):
+        h = HipSolver(template, device=dev.index)
+        seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=0xB101C)
+        p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=1)
+        ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
+        bufs = [(torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+                 torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(nfl)]
+        dt, kernel_ms = _timed_device_solves(h, p, n, ds, dp, bufs, streams, reps)
+        suc, steps = bufs[0][2].cpu().numpy(), bufs[0][3].cpu().numpy().astype(np.float64)
+        gens = steps.sum() * 16
+        evaluations = gens * pop + 4.0 * steps.sum()
+        flops = evaluations * flops_per_evaluation(n_moving, n_rev, n_pose)
+        b_gen = 8 * (pop * (3 * h.D + 1) + 8 * h.D)
+        res[name] = {"value": float(suc.sum()) / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "success_rate": float(suc.mean()), "mean_steps_per_solve": float(steps.mean()),
+                     "batch": n, "population": pop, "max_steps": max_steps, "D": h.D, "tips": h.T, "batches_in_flight": nfl, "kernel_ms": kernel_ms,
+                     "roofline": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                                  "frac": flops / (kernel_ms * 1e-3) / FP64_PEAK, "chip_level_frac": flops / dt / FP64_PEAK,
+                                  "hbm_notional_frac": gens * b_gen / (kernel_ms * 1e-3) / HBM_PEAK}}
+    return res
+
+
+def bench_c5(args, rank, world, gpu, dev):
+    """BASELINE.json configs[4]: one mixed batch of PR2 right-arm (pop=128) and 31-DOF snake (pop=512) queries held by rank 0, sorted by
+    model into two homogeneous blocks, each sharded over all ranks (scatter -> bioik_solve_batch_device on its own stream -> gather).
+    A step = the whole batch end to end; value = successes / wall time.  Strong scaling: the global batch is fixed."""
+    import numpy as np
+    import torch
+
+    from bio_ik_amd import AvoidJointLimitsGoal, PoseGoal, ProblemTemplate, abi, pr2_like, snake
+    from bio_ik_amd.batch import solve_mixed
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.workload import make_queries
+    total = int(os.environ.get("BIOIK_BENCH_C5_BATCH", "262144"))
+    t2 = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
+    t4 = ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()])
+    h2, h4 = HipSolver(t2, device=gpu), HipSolver(t4, device=gpu)
+    p2 = abi.default_solve_params(population=128, max_steps=64, random_seed=1)
+    p4 = abi.default_solve_params(population=512, max_steps=32, random_seed=1)
+    blocks = [(h2, p2, None, None), (h4, p4, None, None)]
+    if rank == 0:
+        s2, g2, _ = make_queries(t2, h2.active_variables, h2.fk_genes, total // 2, seed=0xB101C)
+        s4, g4, _ = make_queries(t4, h4.active_variables, h4.fk_genes, total - total // 2, seed=0xB101C + 1)
+        blocks = [(h2, p2, s2, g2), (h4, p4, s4, g4)]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    res = None
+    for _ in range(max(args.warmup, 1)):
+        res = solve_mixed(blocks, device=str(dev))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = solve_mixed(blocks, device=str(dev))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        n_success = float(res[0][2].sum() + res[1][2].sum())
+        out = {"metric": "IK solves/sec (mixed PR2 pop=128 / 31-DOF snake pop=512 batch, sharded end to end)", "value": n_success * args.steps / elapsed, "unit": "solves/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[4]: %d mixed queries (half PR2-like right arm 7-DOF PoseGoal pop=128, half 31-DOF snake PoseGoal + "
+                                      "AvoidJointLimits pop=512), sorted by model, every block sharded over all ranks; host arrays on rank 0 in and out" % total,
+                          "global_batch": total, "sharding": "scatter -> solve -> gather (torch.distributed; RCCL with N>1), no collective between shards"},
+               "success_rate": {"pr2": float(res[0][2].mean()), "snake": float(res[1][2].mean())},
+               "mean_steps_per_solve": {"pr2": float(res[0][3].mean()), "snake": float(res[1][3].mean())}}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def main():
@@ -51,6 +174,10 @@ def main():
                     help="only the warm-up and the K timed steps (no one-at-a-time leg, no secondary measurements): what the rocprofv3 kernel "
                          "statistics in profiles/ are taken over, so that their average duration is that of the timed launches")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"],
+                    help="c2 (default): BASELINE.json configs[1], the configuration the metric is quoted on.  c5: configs[4], a mixed PR2 / snake "
+                         "batch that rank 0 holds, sorted by model and sharded over all ranks end to end (scatter -> solve -> gather, "
+                         "bio_ik_amd.batch.solve_mixed); BIOIK_BENCH_C5_BATCH sets the global batch (default 262144)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "3")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other)")
     args = ap.parse_args()
@@ -83,6 +210,9 @@ def main():
             dist.init_process_group(backend=backend)
     dev = torch.device("cuda", gpu)
     torch.cuda.set_device(dev)
+
+    if args.config == "c5":
+        return bench_c5(args, rank, world, gpu, dev)
 
     template = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
     h = HipSolver(template, device=gpu)
@@ -165,6 +295,11 @@ def main():
     generations = float(steps_q.astype(np.float64).sum()) * gens_per_step
     alg_bytes = generations * b_gen + BATCH * (8 * (7 * T + V) + 8 * (V + 3))
     achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    # algorithmic flops of one launch: every child of every generation + the four exact evaluations of a step's species management
+    n_moving, n_rev = 8, 7  # PR2-like right arm: torso (prismatic, inactive) + 7 revolute joints on the chain
+    fpe = flops_per_evaluation(n_moving, n_rev, 1)
+    evaluations = generations * POP + 4.0 * float(steps_q.astype(np.float64).sum())
+    alg_flops = evaluations * fpe
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -194,16 +329,26 @@ def main():
         "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
         "max_pos_err_m_of_successes": pos_err,
         "max_rot_err_rad_of_successes": rot_err,
-        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "kernel": "k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "population is LDS-resident: measured HBM traffic << algorithmic bytes; kernel is FP64-VALU bound (DESIGN.md §6); "
-                             "kernel_ms is the event-bracketed duration of one launch while %d launches share the chip" % nfl,
-                     "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0},
+        "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic,
+                     "kernel": "k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": alg_flops,
+                     "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
+                     "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
+                     "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
+                     "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
+                             "formula x fitness evaluations counted on the device; kernel_ms is the event-bracketed duration of one launch while %d launches "
+                             "share the chip, so `frac` is per launch and `chip_level_frac` is all launches over the wall time; `traffic` = measured HBM "
+                             "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
+                     "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                             "algorithmic_bytes_per_launch": alg_bytes, "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0,
+                             "note": "notional: SURVEY.md section 8(d) B_gen bytes per generation if the population streamed through HBM; the population is "
+                                     "LDS-resident and the measured traffic is `roofline.traffic`"}},
         "results_identical_across_streams": identical,
     }
     if sequential is not None and world == 1:
         out["one_batch_at_a_time"] = {"value": n_success / sequential[0], "unit": "solves/s", "ms_per_step": sequential[0] * 1e3, "kernel_ms": sequential[1],
-                                      "roofline_frac": alg_bytes / (sequential[1] * 1e-3) / HBM_PEAK if sequential[1] > 0 else 0.0}
+                                      "roofline_frac": alg_flops / (sequential[1] * 1e-3) / FP64_PEAK if sequential[1] > 0 else 0.0,
+                                      "hbm_roofline_frac": alg_bytes / (sequential[1] * 1e-3) / HBM_PEAK if sequential[1] > 0 else 0.0}
 
     # Secondary measurement (north-star layout): the population genotype array resident in HBM, genes [unit][D][pop]
     # (individual index fastest), one launch = exact-FK fitness of every individual.  Reported next to the solver line;
@@ -285,6 +430,9 @@ def main():
                                  "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "batches_in_flight": nfl,
                                  "sample": "4096 queries, seed = target configuration + N(0, 0.1 rad) clipped to the joint limits"}
 
+    if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_CONFIGS", "1") != "0":
+        out["configs"] = other_configs(dev, nfl, streams)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle import orc, ref
         ns = min(args.cpu_sample, BATCH)
@@ -319,6 +467,32 @@ def main():
                   "sample": "the same 4096 queries, five passes, median pass; the reference's own bio2_memetic (oracle/_ref, reference Release flags), its "
                             "hard-coded population (2 species x (2+16)), linearised FK, 1 island, success test after every step, <= 512 steps, 1 thread",
                   "port_same_parameters": port}
+            # the reference's default of four island threads per query (ik_evolution_2.cpp:649) runs four CLONES of this island -- same
+            # seed, same random tables, same trajectory (src/ik_parallel.h:141-145) -- so its solves/s per query stream is this one-thread
+            # figure; what more host cores buy is more queries at once: the same code, one solver object per thread, queries split over them
+            try:
+                import threading
+                nt = min(ncpu, 32)
+                refs = [r] + [ref.Reference(template, pr, release=True) for _ in range(nt - 1)]
+                bounds = [(i * BATCH) // nt for i in range(nt + 1)]
+                got = [None] * nt
+
+                def work(i):
+                    got[i] = refs[i].solve_batch(seeds[bounds[i]:bounds[i + 1]], params[bounds[i]:bounds[i + 1]], 512)
+                for i in range(nt):
+                    refs[i].solve_batch(seeds[:2], params[:2], 512)
+                t1 = time.perf_counter()
+                th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                dtp = time.perf_counter() - t1
+                cb["query_parallel"] = {"value": float(sum(g[2].sum() for g in got)) / dtp, "cores": nt, "seconds": dtp,
+                                        "sample": "the same 4096 queries split over %d host threads, one reference solver object each" % nt}
+            except Exception as e:  # (the headline line must not depend on this leg)
+                cb["query_parallel"] = {"error": repr(e)}
+            cb["four_island_threads_note"] = ("reference default concurrency() = 4 island threads are identical clones (same RNG state): per-query "
+                                              "rate = the 1-thread figure; -march=native is not reported because the prebuilt reference library travels "
+                                              "between hosts of different micro-architectures")
         else:
             cb = dict(port)
             cb["host_cpus"] = ncpu

@@ -162,7 +162,11 @@ struct bioik_problem {
     void* io_dev = nullptr;
     void* io_host = nullptr;
     size_t io_bytes = 0;
-    stream_t io_stream = nullptr;  // the handle's own stream: host-pointer solves of different handles overlap, also on one device
+    // the handle's own stream: host-pointer solves of different handles overlap, also on one device.  Created at the first host-pointer
+    // solve, not with the handle: HIP multiplexes streams onto four hardware queues per device, and a stream that a device-pointer
+    // caller never uses would push one of the caller's own streams onto a shared queue (launches "in flight" would then serialise)
+    stream_t io_stream = nullptr;
+    bool io_stream_made = false;
     uint64_t first_query = 0;
     // launch clocks of solves with a wall-clock timeout: a ring of words, one per launch in flight, zeroed in stream order
     unsigned long long* d_clocks = nullptr;
@@ -440,7 +444,6 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     DeviceGuard on_device(model->device);
     p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
     p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kClocks * sizeof(unsigned long long));
-    p->io_stream = be_stream_create();
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
     be_sync(0);
     *out = p.release();
@@ -511,6 +514,7 @@ static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint6
     }
     char* hd = (char*)p->io_host;
     char* dd = (char*)p->io_dev;
+    if (!p->io_stream_made) p->io_stream = be_stream_create(), p->io_stream_made = true;
     const stream_t st = p->io_stream;
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);

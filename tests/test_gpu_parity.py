@@ -68,6 +68,33 @@ def test_mimic_joints():
     pc.trajectory(h2, o2, t2, n=16, pop=128, steps_list=(1, 6))
     pc.trajectory(h2, o2, t2, n=8, pop=70, steps_list=(3,), fk_mode=abi.FK_LINEAR)
 
+def test_urdf_loaded_model_solves_on_the_device():
+    """URDF + SRDF text -> bio_ik_amd.urdf.load_urdf -> flat model -> libbioik_hip.so: the device solves on a robot description that
+    never went through a hand-built fixture (mimic joints, nested SRDF groups), function level and whole solves against the oracle"""
+    from bio_ik_amd import MinimalDisplacementGoal, PoseGoal
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.urdf import load_urdf
+    from test_urdf import SRDF, URDF
+    m = load_urdf(URDF, SRDF)
+    sec = MinimalDisplacementGoal(weight=0.5)
+    sec.secondary_ = True
+    t = ProblemTemplate(m, "arm_chain", [PoseGoal("tool"), sec])
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == 5
+    pc.function_level(h, o, m, np.random.default_rng(15), n=400, exact_bits=True)
+    pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 5))
+    with pc.oracle_arithmetic(0):
+        seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 512, seed=33)
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=2)
+    sol, fit, suc, steps = h.solve_batch(p, seeds, params)
+    so = o.solve_batch(p, orc.RNG_COUNTER, seeds[:32], params[:32], n_threads=8)
+    assert np.array_equal(so[0], sol[:32]) and np.array_equal(so[2], suc[:32])
+    assert suc.mean() > 0.6  # (an arm whose second elbow follows the shoulder, with a secondary goal: about three in four within 64 steps)
+    with pc.oracle_arithmetic(0):
+        perr, rerr = pc.pose_errors(o, sol, params)
+    assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+
+
 def test_no_active_variable(pr2):
     """every joint of the group fixed: D = 0, the solve runs its budget and returns the seed, as the oracle does"""
     from bio_ik_amd import PoseGoal

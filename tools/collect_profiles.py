@@ -2,8 +2,8 @@
 import collections, csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(ROOT, "gpurun_out"); p = os.path.join(ROOT, "profiles"); rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-shutil.copy(os.path.join(g, "prof_r01", "r01_kernel_stats.csv"), os.path.join(p, rnd + "_kernel_stats.csv"))
-shutil.copy(os.path.join(g, "bench_r01.json"), os.path.join(p, rnd + "_bench.json"))
+shutil.copy(os.path.join(g, "prof_" + rnd, rnd + "_kernel_stats.csv"), os.path.join(p, rnd + "_kernel_stats.csv"))
+shutil.copy(os.path.join(g, "bench_" + rnd + ".json"), os.path.join(p, rnd + "_bench.json"))
 out = {}
 for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_collection.csv", "pmc_sq/sq_counter_collection.csv", "pmc_mem/mem_counter_collection.csv", "pmc_ic/ic_counter_collection.csv"):
     if not os.path.exists(os.path.join(g, f)): continue
@@ -20,7 +20,7 @@ summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format
            "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
                                     "total_corrected": 2 * fk * 1024 + wk * 1024,
                                     "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "
-                                            "WRITE_SIZE uncalibrated.  Almost all of it is register-spill (scratch) traffic: the query data are 1.4 MB."}}
+                                            "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; the rest is scratch traffic (register spills of cold paths)."}}
 json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
 json.dump({"k_solve_hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "source": "profiles/%s_pmc_k_solve.json" % rnd}, open(os.path.join(p, "traffic.json"), "w"), indent=1)
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):

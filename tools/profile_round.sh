@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session = everything the round's profiles/ need: the bench line, rocprofv3 kernel stats of the same command, and the
 # PMC passes (each counter group in its own run, with --kernel-trace only).  usage (on the GPU box, repo root): tools/profile_round.sh r01
-rnd=${1:-r01}
+rnd=${1:-r02}
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/bench_$rnd.json 2> $O/bench_$rnd.err
