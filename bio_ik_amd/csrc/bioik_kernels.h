@@ -32,7 +32,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.pop = o, o += 2 * 2 * 2 * 2 * m;  // [species][buffer][individual][genes|momentum][op]
     L.sol = o, o += m;
     L.prefix = o, o += 8;               // frame behind the leading non-gene joints (DevProblem::n_prefix), per query
-    L.state = o, o += 2 * 8 + 4;        // species bookkeeping exchanged between the two species groups + workgroup broadcast slots
+    L.state = o, o += 2 * 8 + 4 + 4;    // species bookkeeping [2][8], workgroup broadcast slots [4], fitness / success flag of the solution [2] (+2 spare)
     L.clip = o, o += 2 * m;             // RobotInfo clip_min | clip_max per op (robot_info.h:109-113), staged once per query
     L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
@@ -315,9 +315,25 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     }
     // the seed is the first solution; whether it already satisfies the goals is what the first success test will find
     const FitCheck fc0 = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
-    double sol_fit = fc0.fitness;
-    int sol_ok = fc0.ok;
-    SpeciesState A{P_INF, sol_fit, sol_fit, 0, 0, 0, 0, 0}, B{P_INF, sol_fit, sol_fit, 1, 1, 0, 0, 0};
+    double* s_solst = s_state + 20;  // [0] fitness, [1] success flag of the current solution
+    const double sol_fit = fc0.fitness;
+    // The bookkeeping of the two species lives in LDS between the phases of a step (s_state[rank][8], rank 0 = the leading species of
+    // the last ranking): it is a handful of numbers read a few times per step, and as per-lane registers it was what the register
+    // allocator spilled to scratch around every step.
+    auto species_load = [&](int r) {
+        const double* d = s_state + r * 8;
+        return SpeciesState{d[0], d[1], d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7]};
+    };
+    auto species_store = [&](int r, const SpeciesState& S) {
+        double* d = s_state + r * 8;
+        d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved, d[7] = (double)S.ok;
+    };
+    if (tid == 0) {
+        species_store(0, SpeciesState{P_INF, sol_fit, sol_fit, 0, 0, 0, 0, 0});
+        species_store(1, SpeciesState{P_INF, sol_fit, sol_fit, 1, 1, 0, 0, 0});
+        s_solst[0] = sol_fit, s_solst[1] = (double)fc0.ok;
+    }
+    p_barrier();
     const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
     PHASE_MARK(PH_INIT);
 
@@ -339,7 +355,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     double final_fit = BIOIK_DBL_MAX;
     for (int step = 0; step < sp.max_steps; step++) {
         for (int rank = rank_begin; rank < rank_end; rank++) {
-            SpeciesState S = rank == 0 ? A : B;
+            SpeciesState S = species_load(rank);
             double* popS = s_pop + S.slot * SP;
             if (!exact) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
@@ -658,21 +674,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 S.ok = fc.ok;
                 PHASE_MARK(PH_RANK);
             }
-            if (rank == 0) A = S; else B = S;
+            if (gtid == 0) species_store(rank, S);
         }
-        if (groups == 2) {  // each group publishes its species' bookkeeping, everybody reads both
-            if (gtid == 0) {
-                const SpeciesState& S = grp == 0 ? A : B;
-                double* d = s_state + grp * 8;
-                d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved, d[7] = (double)S.ok;
-            }
-            p_barrier();
-            A = SpeciesState{s_state[0], s_state[1], s_state[2], (int)s_state[3], (int)s_state[4], (int)s_state[5], (int)s_state[6], (int)s_state[7]};
-            B = SpeciesState{s_state[8], s_state[9], s_state[10], (int)s_state[11], (int)s_state[12], (int)s_state[13], (int)s_state[14], (int)s_state[15]};
-            p_barrier();
-        }
+        p_barrier();  // both species are ranked and their bookkeeping is in LDS
 
         // species management (:617-645)
+        SpeciesState A = species_load(0), B = species_load(1);
         if (B.fit < A.fit) {
             SpeciesState tmp = A;
             A = B;
@@ -705,17 +712,21 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         steps++;
         PHASE_COUNT(PH_N_STEPS);
         PHASE_MARK(PH_SPECIES);
-        if (A.fit < sol_fit) {
+        const bool better = A.fit < s_solst[0];
+        if (better) {
             const double* cb = s_pop + A.slot * SP + A.cur * BF;
             p_barrier();
             for (int k = tid; k < n_ops; k += nth) s_sol[k] = cb[k];
-            sol_fit = A.fit;
-            sol_ok = A.ok;
-            p_barrier();
         }
+        p_barrier();  // every lane has read the bookkeeping; lane 0 files the new ranking (and the new solution's figures) for the next step
+        if (tid == 0) {
+            species_store(0, A), species_store(1, B);
+            if (better) s_solst[0] = A.fit, s_solst[1] = (double)A.ok;
+        }
+        p_barrier();
         // ik_parallel.h:173-181: fitness and success test of the solution = those of the elite it was copied from (or of the seed)
-        final_fit = sol_fit;
-        success = sol_ok != 0;
+        final_fit = s_solst[0];
+        success = s_solst[1] != 0.0;
         PHASE_MARK(PH_CHECK);
         if (success) break;
         if (sp.timeout_ticks != 0ull) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
