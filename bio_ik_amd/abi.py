@@ -21,11 +21,11 @@ JOINT_VAR_COUNT = {JOINT_FIXED: 0, JOINT_REVOLUTE: 1, JOINT_PRISMATIC: 1, JOINT_
 # ---- goal opcodes (reference include/bio_ik/goal_types.h) ----
 (GOAL_POSITION, GOAL_ORIENTATION, GOAL_POSE, GOAL_LOOK_AT, GOAL_MAX_DISTANCE, GOAL_MIN_DISTANCE, GOAL_LINE, GOAL_PLANE,
  GOAL_AVOID_JOINT_LIMITS, GOAL_CENTER_JOINTS, GOAL_REGULARIZATION, GOAL_MINIMAL_DISPLACEMENT, GOAL_JOINT_VARIABLE,
- GOAL_SIDE, GOAL_DIRECTION, GOAL_CONE) = range(16)
+ GOAL_SIDE, GOAL_DIRECTION, GOAL_CONE, GOAL_BALANCE) = range(17)
 GOAL_PARAM_COUNT = {GOAL_POSITION: 3, GOAL_ORIENTATION: 4, GOAL_POSE: 8, GOAL_LOOK_AT: 6, GOAL_MAX_DISTANCE: 4,
                     GOAL_MIN_DISTANCE: 4, GOAL_LINE: 6, GOAL_PLANE: 6, GOAL_AVOID_JOINT_LIMITS: 0, GOAL_CENTER_JOINTS: 0,
                     GOAL_REGULARIZATION: 0, GOAL_MINIMAL_DISPLACEMENT: 0, GOAL_JOINT_VARIABLE: 1, GOAL_SIDE: 6,
-                    GOAL_DIRECTION: 6, GOAL_CONE: 11}
+                    GOAL_DIRECTION: 6, GOAL_CONE: 11, GOAL_BALANCE: 6}
 
 # ---- solver modes (IKFactory names, reference src/ik_evolution_2.cpp:652-654) ----
 MODE_BIO2, MODE_BIO2_MEMETIC, MODE_BIO2_MEMETIC_L = 0, 1, 2
@@ -42,7 +42,7 @@ class ModelDesc(C.Structure):
                 ("link_parent", _pi), ("link_origin", _pd), ("joint_type", _pi), ("joint_axis", _pd),
                 ("joint_first_variable", _pi), ("joint_mimic", _pi), ("joint_mimic_factor", _pd),
                 ("joint_mimic_offset", _pd), ("var_min", _pd), ("var_max", _pd), ("var_bounded", _pu8),
-                ("var_max_velocity", _pd)]
+                ("var_max_velocity", _pd), ("link_mass", _pd), ("link_center", _pd)]
 
 
 class GoalDesc(C.Structure):

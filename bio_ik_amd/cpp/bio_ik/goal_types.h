@@ -225,7 +225,21 @@ public:
     }
 };
 
-// host-callback goals of the reference (TouchGoal :330-377, JointFunctionGoal :501-546, LinkFunctionGoal :548-583,
-// BalanceGoal) keep gpuOpcode() == -1: the plugin refuses them with BIOIK_ERR_UNSUPPORTED.
+// host-callback goals of the reference (TouchGoal :330-377, JointFunctionGoal :501-546, LinkFunctionGoal :548-583) keep
+// gpuOpcode() == -1: the plugin refuses them with BIOIK_ERR_UNSUPPORTED.
+
+class BalanceGoal : public Goal {  // goal_types.h:540-566, goal_types.cpp:231-272
+    Vector3 target_{0, 0, 0}, axis_{0, 0, 1};
+
+public:
+    BalanceGoal() {}
+    BalanceGoal(const Vector3& target, double weight = 1.0) : target_(target) { weight_ = weight; }
+    const Vector3& getTarget() const { return target_; }
+    const Vector3& getAxis() const { return axis_; }
+    void setTarget(const Vector3& target) { target_ = target; }
+    void setAxis(const Vector3& axis) { axis_ = axis; }
+    int gpuOpcode() const override { return BIOIK_GOAL_BALANCE; }
+    void gpuParams(std::vector<double>& o) const override { o.insert(o.end(), {target_.x, target_.y, target_.z, axis_.x, axis_.y, axis_.z}); }
+};
 
 }  // namespace bio_ik

@@ -23,6 +23,7 @@ public:
     std::vector<std::string> link_names, joint_names, variable_names;
     std::vector<int32_t> link_parent, joint_type, joint_first_variable, joint_mimic;
     std::vector<double> link_origin, joint_axis, joint_mimic_factor, joint_mimic_offset, var_min, var_max, var_max_velocity;
+    std::vector<double> link_mass, link_center;  // urdf <inertial> mass / origin xyz per link (BalanceGoal); empty = none
     std::vector<uint8_t> var_bounded;
     std::map<std::string, JointModelGroup> groups;
 
@@ -76,6 +77,11 @@ public:
         }
         return idx;
     }
+    void setInertial(const std::string& link, double mass, double cx, double cy, double cz) {  // urdf <inertial>
+        link_mass.resize(link_names.size(), 0.0), link_center.resize(3 * link_names.size(), 0.0);
+        const int i = linkIndex(link);
+        link_mass[i] = mass, link_center[3 * i] = cx, link_center[3 * i + 1] = cy, link_center[3 * i + 2] = cz;
+    }
     void addChainGroup(const std::string& name, const std::string& base, const std::string& tip) {
         JointModelGroup g;
         g.name = name;
@@ -111,6 +117,7 @@ public:
         d.joint_first_variable = joint_first_variable.data(), d.joint_mimic = joint_mimic.data();
         d.joint_mimic_factor = joint_mimic_factor.data(), d.joint_mimic_offset = joint_mimic_offset.data();
         d.var_min = var_min.data(), d.var_max = var_max.data(), d.var_bounded = var_bounded.data(), d.var_max_velocity = var_max_velocity.data();
+        if (link_mass.size() == link_names.size() && link_center.size() == 3 * link_names.size()) d.link_mass = link_mass.data(), d.link_center = link_center.data();
         return d;
     }
     // frame algebra for the plugin boundary (goal poses into the model frame, kinematics_plugin.cpp:487-502)

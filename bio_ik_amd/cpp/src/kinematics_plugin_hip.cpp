@@ -84,7 +84,7 @@ int solverMode(const std::string& name) {  // IKFactory names (src/ik_evolution_
 // include/bio_ik/robot_info.h:70-106), flattened for bioik_model_create.  Link i carries its parent joint.
 struct FlatModel {
     std::vector<int32_t> link_parent, joint_type, joint_first_variable, joint_mimic;
-    std::vector<double> link_origin, joint_axis, joint_mimic_factor, joint_mimic_offset, var_min, var_max, var_max_velocity;
+    std::vector<double> link_origin, joint_axis, joint_mimic_factor, joint_mimic_offset, var_min, var_max, var_max_velocity, link_mass, link_center;
     std::vector<uint8_t> var_bounded;
     explicit FlatModel(const moveit::core::RobotModel& rm) {
         const auto& links = rm.getLinkModels();
@@ -118,6 +118,17 @@ struct FlatModel {
             joint_mimic.push_back(j->getMimic() ? (int32_t)j->getMimic()->getChildLinkModel()->getLinkIndex() : -1);
             joint_mimic_factor.push_back(j->getMimicFactor());
             joint_mimic_offset.push_back(j->getMimicOffset());
+            // urdf <inertial> of the link, what BalanceGoal::describe reads (src/goal_types.cpp:236-247)
+            double mass = 0.0, c[3] = {0, 0, 0};
+            if (rm.getURDF()) {
+                auto link_urdf = rm.getURDF()->getLink(l->getName());
+                if (link_urdf && link_urdf->inertial) {
+                    mass = link_urdf->inertial->mass;
+                    c[0] = link_urdf->inertial->origin.position.x, c[1] = link_urdf->inertial->origin.position.y, c[2] = link_urdf->inertial->origin.position.z;
+                }
+            }
+            link_mass.push_back(mass);
+            link_center.insert(link_center.end(), c, c + 3);
         }
         for (const std::string& name : rm.getVariableNames()) {
             const moveit::core::VariableBounds& b = rm.getVariableBounds(name);
@@ -134,6 +145,7 @@ struct FlatModel {
         d.joint_first_variable = joint_first_variable.data(), d.joint_mimic = joint_mimic.data();
         d.joint_mimic_factor = joint_mimic_factor.data(), d.joint_mimic_offset = joint_mimic_offset.data();
         d.var_min = var_min.data(), d.var_max = var_max.data(), d.var_bounded = var_bounded.data(), d.var_max_velocity = var_max_velocity.data();
+        d.link_mass = link_mass.data(), d.link_center = link_center.data();
         return d;
     }
 };

@@ -9,6 +9,30 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+// stand-in for urdf_model: the inertial of a link, which BalanceGoal reads through RobotModel::getURDF() (src/goal_types.cpp:236-247)
+namespace urdf {
+struct Vector3 {
+    double x = 0, y = 0, z = 0;
+};
+struct Pose {
+    Vector3 position;
+};
+struct Inertial {
+    Pose origin;
+    double mass = 0;
+};
+struct Link {
+    std::shared_ptr<Inertial> inertial;
+};
+struct ModelInterface {
+    std::map<std::string, std::shared_ptr<Link>> links_;
+    std::shared_ptr<const Link> getLink(const std::string& name) const {
+        auto it = links_.find(name);
+        return it == links_.end() ? std::shared_ptr<const Link>() : std::shared_ptr<const Link>(it->second);
+    }
+};
+typedef std::shared_ptr<ModelInterface> ModelInterfaceSharedPtr;
+}  // namespace urdf
 namespace moveit {
 namespace core {
 struct VariableBounds {
@@ -90,8 +114,16 @@ class RobotModel {
     std::vector<std::string> variable_names_;
     std::vector<const JointModel*> joint_of_variable_;
     std::map<std::string, std::unique_ptr<JointModelGroup>> groups_;
+    urdf::ModelInterfaceSharedPtr urdf_ = std::make_shared<urdf::ModelInterface>();
 
 public:
+    const urdf::ModelInterfaceSharedPtr& getURDF() const { return urdf_; }
+    void setInertial(const std::string& link, double mass, double cx, double cy, double cz) {  // stand-in only (a real model parses <inertial>)
+        auto l = std::make_shared<urdf::Link>();
+        l->inertial = std::make_shared<urdf::Inertial>();
+        l->inertial->mass = mass, l->inertial->origin.position.x = cx, l->inertial->origin.position.y = cy, l->inertial->origin.position.z = cz;
+        urdf_->links_[link] = l;
+    }
     const std::string& getName() const {
         static const std::string n = "robot";
         return n;

@@ -58,6 +58,7 @@ int goal_param_count(int type) {
         case BIOIK_GOAL_SIDE: return 6;
         case BIOIK_GOAL_DIRECTION: return 6;
         case BIOIK_GOAL_CONE: return 11;
+        case BIOIK_GOAL_BALANCE: return 6;
     }
     return -1;
 }
@@ -96,6 +97,9 @@ HostModel::HostModel(const bioik_model_desc& d) {
         l.mimic_factor = (l.mimic >= 0 && d.joint_mimic_factor) ? d.joint_mimic_factor[i] : 1.0;
         l.mimic_offset = (l.mimic >= 0 && d.joint_mimic_offset) ? d.joint_mimic_offset[i] : 0.0;
         if (l.mimic >= (int)d.n_links || l.mimic == (int)i) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "mimic joint index out of range");
+        l.mass = d.link_mass ? d.link_mass[i] : 0.0;
+        if (d.link_mass && !d.link_center) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_model_desc: link_mass without link_center");
+        for (int c = 0; c < 3; c++) l.center[c] = d.link_center ? d.link_center[3 * i + c] : 0.0;
         if (l.var_count > 0) {
             if (l.first_var < 0 || l.first_var + l.var_count > (int)d.n_variables) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "joint variable index out of range");
             for (int v = 0; v < l.var_count; v++) var_joint[l.first_var + v] = (int)i;
@@ -166,6 +170,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         int secondary, param_off;
     };
     std::vector<G> goals;
+    double balance_total = 0.0;
+    int n_balance_goals = 0;
     for (uint32_t gi = 0; gi < d.n_goals; gi++) {
         const bioik_goal_desc& g = d.goals[gi];
         int np = goal_param_count(g.type);
@@ -178,6 +184,15 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         if (g.variable >= 0) {
             if (g.variable >= nv) throw Error(BIOIK_ERR_NOT_FOUND, "joint variable not found");
             info.var = add_active_variable(g.variable);
+        }
+        if (g.type == BIOIK_GOAL_BALANCE) {  // BalanceGoal::describe (goal_types.cpp:231-255): every link with mass becomes a tip, in link order
+            if (g.secondary) throw Error(BIOIK_ERR_UNSUPPORTED, "BalanceGoal cannot be a secondary goal (the reference's has no such constructor)");
+            double total = 0.0;
+            for (int l = 0; l < nl; l++)
+                if (m->links[l].mass > 0) total += m->links[l].mass, add_tip_link(l);
+            if (!(total > 0)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "BalanceGoal: the model has no link with a positive mass (bioik_model_desc::link_mass)");
+            balance_total = total;
+            n_balance_goals++;
         }
         param_count += np;
         goals.push_back(info);
@@ -377,7 +392,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         ops[k].mimic_src = value_op_of_var[sv];
     }
     if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 moving joints on the goal chains");
-    if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 8 tip links");
+    if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 tip links");
+    if (n_balance_goals > BIOIK_MAX_BALANCE) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 4 BalanceGoals");
     for (size_t k = 0; k < ops.size(); k++) {
         DevOp& op = ops[k];
         const HostModel::Var& vi = m->vars[op.var];
@@ -418,6 +434,12 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         for (int l = tip_links[tt[t].pub]; l >= 0; l = m->links[l].parent)
             if (op_of_link[l] >= 0) mask |= 1ull << op_of_link[l];
         dt.dep_mask = mask;
+        dt.bal_w = 0.0;
+        if (n_balance_goals > 0 && m->links[tip_links[tt[t].pub]].mass > 0) {
+            const HostModel::Link& L = m->links[tip_links[tt[t].pub]];
+            dt.bal_w = L.mass / balance_total;  // goal_types.cpp:252-254
+            for (int c = 0; c < 3; c++) dt.bal_c[c] = L.center[c];
+        }
         if (dt.src < 0) {
             dev.n_root_tips++;
         } else {
@@ -453,7 +475,9 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
     dev.n_link_primary = np;
     for (const G& g : goals) {
-        if (g.secondary) {
+        if (g.type == BIOIK_GOAL_BALANCE) {  // reads many tips: kept apart from the per-tip and the gene-only goals
+            dev.balance[dev.n_balance++] = to_dev(g);
+        } else if (g.secondary) {
             if (ns >= BIOIK_MAX_GOALS) throw Error(BIOIK_ERR_UNSUPPORTED, "too many goals");
             dev.secondary[ns++] = to_dev(g);
         } else if (g.tip < 0) {

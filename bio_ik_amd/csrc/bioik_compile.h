@@ -27,6 +27,7 @@ struct HostModel {
         Frame origin;
         double axis[3];
         double mimic_factor, mimic_offset;
+        double mass, center[3];  // urdf inertial (BalanceGoal)
     };
     struct Var {
         double clip_min, clip_max, span, vmin, vmax, max_velocity_rcp;

@@ -307,6 +307,36 @@ BIOIK_DEV double nonlink_primary(ProbPtr pb, const XV& x, const QueryCtx& qc) {
                pb->primary[g].weight_sq;
     return sum;
 }
+// BalanceGoal (goal_types.cpp:257-272): the centre of mass of the robot = sum over the links with mass of (frame o centre) * share; the
+// walk feeds every such tip into `acc` as its frame completes, and the goals finish on the sum.  Only the general kernel flavour carries
+// it (a problem with a BalanceGoal is never handed to the lean one).
+template <class PB>
+BIOIK_DEV void balance_tip(PB pb, int t, const F7& f, V3& acc) {
+    if constexpr (pb_flavour<PB>::general) {
+        const double w = pb->tips[t].bal_w;
+        if (w != 0.0) {
+            BIOIK_FP_STRICT
+            V3 c = qrot(f.q, v3(pb->tips[t].bal_c[0], pb->tips[t].bal_c[1], pb->tips[t].bal_c[2]));
+            c = c + f.p;
+            acc = acc + c * w;
+        }
+    }
+}
+template <class PB>
+BIOIK_DEV double balance_goal_cost(PB pb, int g, const V3& acc, const QueryCtx& qc) {  // one BalanceGoal, weighted
+    const double* P = qc.par + pb->balance[g].param_off;
+    V3 center = acc - v3(P[0], P[1], P[2]);
+    const V3 axis = v3(P[3], P[4], P[5]);
+    center = center - axis * dot3(axis, center);
+    return len2(center) * pb->balance[g].weight_sq;
+}
+template <class PB>
+BIOIK_DEV double balance_cost(PB pb, const V3& acc, const QueryCtx& qc) {
+    double sum = 0.0;
+    if constexpr (pb_flavour<PB>::general)
+        for (int g = 0; g < pb->n_balance; g++) sum += balance_goal_cost(pb, g, acc, qc);
+    return sum;
+}
 // secondary goals see genes only; link goals marked secondary read null frames (ik_base.h:163)
 template <bool JS_INLINE = false>
 BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) {
@@ -489,8 +519,13 @@ BIOIK_DEV F7 fk_prefix(ProbPtr pb, const XV& x) {
 template <class PB>
 BIOIK_DEV double eval_exact_primary(PB pb, const XV& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
     double sum = 0.0;
-    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) { sum += tip_goals(pb, t, f, x, qc); }, prefix);
+    V3 bal = v3(0.0, 0.0, 0.0);
+    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
+        sum += tip_goals(pb, t, f, x, qc);
+        balance_tip(pb, t, f, bal);
+    }, prefix);
     sum += nonlink_primary(pb, x, qc);
+    sum += balance_cost(pb, bal, qc);
     return sum;
 }
 
@@ -605,9 +640,12 @@ BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_st
 template <int N, class PB>
 BIOIK_DEV void eval_exact_primary_n(PB pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
                                     const double* prefix = nullptr) {
+    V3 bal[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) out[j] = 0.0;
+    for (int j = 0; j < N; j++) out[j] = 0.0, bal[j] = v3(0.0, 0.0, 0.0);
     fk_walk_n<N>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
+#pragma unroll
+        for (int j = 0; j < N; j++) balance_tip(pb, t, f[j], bal[j]);
         // the goals of the tip, each evaluated for the N individuals (per individual: the summation order of tip_goals)
         const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
         for (int g = g0; g < g1; g++) {
@@ -619,7 +657,7 @@ BIOIK_DEV void eval_exact_primary_n(PB pb, const XV (&x)[N], const QueryCtx& qc,
         }
     }, prefix);
 #pragma unroll
-    for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc);
+    for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc), out[j] += balance_cost(pb, bal[j], qc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -677,8 +715,14 @@ template <class PB>
 BIOIK_DEV double eval_linear_primary(PB pb, const XV& x, const QueryCtx& qc, const LinModel& lm) {
     double sum = 0.0;
     const int T = pb->T;
-    for (int t = 0; t < T; t++) sum += tip_goals(pb, t, linear_tip(pb, t, x, lm), x, qc);
+    V3 bal = v3(0.0, 0.0, 0.0);
+    for (int t = 0; t < T; t++) {
+        const F7 f = linear_tip(pb, t, x, lm);
+        sum += tip_goals(pb, t, f, x, qc);
+        balance_tip(pb, t, f, bal);
+    }
     sum += nonlink_primary(pb, x, qc);
+    sum += balance_cost(pb, bal, qc);
     return sum;
 }
 
@@ -1047,17 +1091,24 @@ BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* sl
                                             const double* prefix = nullptr) {
     bool good = true;
     double sum = 0.0;
+    V3 bal = v3(0.0, 0.0, 0.0);
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
         sum += tip_goals(pb, t, f, x, qc);
+        balance_tip(pb, t, f, bal);
         if (do_check) {
             const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
             for (int g = g0; g < g1; g++) good = check_goal(pb, g, f, x, qc, dpos, drot, dtwist) && good;
         }
     }, prefix);
     sum += nonlink_primary(pb, x, qc);
+    sum += balance_cost(pb, bal, qc);
     if (do_check) {
         const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         for (int g = pb->n_link_primary; g < pb->n_primary; g++) good = check_goal(pb, g, zero, x, qc, dpos, drot, dtwist) && good;
+        if constexpr (pb_flavour<PB>::general) {  // a goal type the success test does not know: weighted cost < min(dpos, dtwist)^2 (problem.cpp:327-334)
+            const double dmax = fmin(BIOIK_DBL_MAX, fmin(dpos, dtwist));
+            for (int g = 0; g < pb->n_balance; g++) good = (balance_goal_cost(pb, g, bal, qc) < dmax * dmax) && good;
+        }
     }
     return FitCheck{sum, good ? 1 : 0};
 }

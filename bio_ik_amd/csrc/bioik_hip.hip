@@ -333,7 +333,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                      (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(160 * 1024 / lds), (int)(160 * 1024 / lds) * (nth / 64));
     }
     if (lds > 64 * 1024) be_allow_lds(lds);
-    bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0;
+    bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
     if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
         if (std::atoi(e) != 0) lean = false;
     void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered; released on every path out

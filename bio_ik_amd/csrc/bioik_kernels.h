@@ -553,6 +553,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     // goal fitness of the lane's frames `fc` (+ its gene's delta * step): (primary, all goals); x: what joint-value goals read
                     auto goals_on = [&](const double* fc, int dop, double dstep, const XV& x, double& prim, double& all) {
                         double acc = 0.0;
+                        V3 bal = v3(0.0, 0.0, 0.0);
                         for (int t = 0; t < T; t++) {
                             F7 f = frame_of(fc, t);
                             if (dstep != 0.0) {
@@ -565,8 +566,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                                        {BK_FMA(d[3], dstep, f.q.x), BK_FMA(d[4], dstep, f.q.y), BK_FMA(d[5], dstep, f.q.z), BK_FMA(d[6], dstep, f.q.w)}};
                             }
                             acc += tip_goals(pb, t, f, x, qc);
+                            balance_tip(pb, t, f, bal);
                         }
                         acc += nonlink_primary(pb, x, qc);
+                        acc += balance_cost(pb, bal, qc);
                         prim = acc;
                         all = acc + secondary_fitness(pb, x, qc);
                     };

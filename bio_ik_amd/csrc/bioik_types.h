@@ -8,7 +8,8 @@
 #include <stdint.h>
 
 #define BIOIK_MAX_OPS 64    // moving joints on the union of the root->tip chains (+ off-chain goal variables)
-#define BIOIK_MAX_TIPS 8
+#define BIOIK_MAX_TIPS 64  // (a BalanceGoal makes every link with mass a tip)
+#define BIOIK_MAX_BALANCE 4
 #define BIOIK_MAX_GOALS 24  // per class (primary / secondary)
 
 enum { BIOIK_OP_NONE = 0, BIOIK_OP_REVOLUTE = 1, BIOIK_OP_PRISMATIC = 2, BIOIK_OP_FLOATING = 3, BIOIK_OP_PLANAR = 4 };
@@ -47,6 +48,8 @@ struct DevTip {
     int32_t out_index;                 // index in Problem::tip_link_indices (order of the public API)
     int32_t goal_first, goal_count;    // primary link goals reading this tip: DevProblem::primary[goal_first..)
     uint64_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
+    double bal_w;                      // BalanceGoal: the link's share of the robot's mass (goal_types.cpp:246-254), 0 = none
+    double bal_c[3];                   // BalanceGoal: the link's centre of mass in the link frame (urdf inertial origin)
 };
 
 struct DevGoal {
@@ -78,6 +81,7 @@ struct DevProblem {
     int32_t n_link_primary;  // primary[0..n_link_primary) are link goals grouped by tip; the rest read genes only
     int32_t n_primary;
     int32_t n_secondary;
+    int32_t n_balance;     // BalanceGoals (goal_types.cpp:231-272): they read every tip with bal_w != 0; balance[0..n_balance)
     uint64_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
     double multi_c[7];     // constant frame in front of the floating / planar joint
     int32_t quat_op[4];    // op index of the first of the four orientation value ops
@@ -88,6 +92,7 @@ struct DevProblem {
     DevTip tips[BIOIK_MAX_TIPS];
     DevGoal primary[BIOIK_MAX_GOALS];
     DevGoal secondary[BIOIK_MAX_GOALS];
+    DevGoal balance[BIOIK_MAX_BALANCE];  // params: target[3] axis[3]
 };
 
 // Same block, read by the lean kernel flavour (bioik_platform.h: pb_flavour): the host hands it out only for problems without

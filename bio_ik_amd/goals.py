@@ -3,7 +3,7 @@
 Same class names, constructor arguments, setters and normalisation behaviour as the reference; instead of a
 virtual `evaluate` every built-in goal serialises itself into (opcode, link/variable, weight, secondary) for the
 problem template and a flat parameter vector per query (`params()`), which is what the device evaluates.
-Goals that need host callbacks or FCL (JointFunctionGoal, LinkFunctionGoal, TouchGoal, BalanceGoal) have no
+Goals that need host callbacks or FCL (JointFunctionGoal, LinkFunctionGoal, TouchGoal) have no
 device opcode; constructing a problem with them raises NotImplementedError.
 """
 import math
@@ -352,6 +352,34 @@ class ConeGoal(LinkGoalBase):
 
     def params(self):
         return np.concatenate([self.position, [self.position_weight], self.axis, self.direction, [self.angle]])
+
+
+class BalanceGoal(Goal):
+    """goal_types.h:540-566, goal_types.cpp:231-272: keeps the centre of mass of the whole robot (every link with a URDF <inertial>)
+    over `target`, measured perpendicular to `axis` (the direction of gravity).  The link masses are part of the robot model
+    (RobotModel.add_link(mass=, com=) / the URDF reader); every link with mass becomes a tip of the problem."""
+    opcode = abi.GOAL_BALANCE
+
+    def __init__(self, target=(0, 0, 0), weight=1.0):
+        super().__init__()
+        self.target = _vec3(target)
+        self.axis = _vec3((0, 0, 1))
+        self.weight_ = float(weight)
+
+    def getTarget(self):
+        return self.target
+
+    def getAxis(self):
+        return self.axis
+
+    def setTarget(self, t):
+        self.target = _vec3(t)
+
+    def setAxis(self, a):
+        self.axis = _vec3(a)  # (the reference's setter does not normalise, goal_types.h:562)
+
+    def params(self):
+        return np.concatenate([self.target, self.axis])
 
 
 class _HostOnlyGoal(Goal):

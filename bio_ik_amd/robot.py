@@ -41,6 +41,8 @@ class RobotModel:
         self.joint_names = []
         self.link_parent = []
         self.link_origin = []
+        self.link_mass = []     # urdf <inertial> mass per link (0 = none)
+        self.link_center = []   # urdf <inertial> origin xyz per link
         self.joint_type = []
         self.joint_axis = []
         self.joint_first_variable = []
@@ -57,9 +59,10 @@ class RobotModel:
 
     # ---- construction ----
     def add_link(self, link_name, parent=None, joint_name=None, joint_type="fixed", xyz=(0, 0, 0), rpy=(0, 0, 0),
-                 axis=(0, 0, 1), lower=0.0, upper=0.0, velocity=0.0, mimic=None, quat=None):
+                 axis=(0, 0, 1), lower=0.0, upper=0.0, velocity=0.0, mimic=None, quat=None, mass=0.0, com=(0, 0, 0)):
         """Add `link_name` attached to `parent` through joint `joint_name` (URDF semantics).
-        joint_type: fixed | revolute | continuous | prismatic | floating | planar.  mimic = (joint, factor, offset)."""
+        joint_type: fixed | revolute | continuous | prismatic | floating | planar.  mimic = (joint, factor, offset).
+        mass / com: the link's URDF <inertial> mass and origin position (BalanceGoal, goal_types.cpp:236-247)."""
         if link_name in self.link_names:
             raise ValueError("duplicate link %r" % link_name)
         if parent is None:
@@ -76,6 +79,8 @@ class RobotModel:
         self.joint_names.append(joint_name or (link_name + "_joint"))
         self.link_parent.append(pidx)
         self.link_origin.append([float(xyz[0]), float(xyz[1]), float(xyz[2]), q[0], q[1], q[2], q[3]])
+        self.link_mass.append(float(mass))
+        self.link_center.append([float(com[0]), float(com[1]), float(com[2])])
         self.joint_type.append(jt)
         a = np.asarray(axis, dtype=np.float64)
         if jt in (abi.JOINT_REVOLUTE, abi.JOINT_PRISMATIC):
@@ -198,6 +203,8 @@ class RobotModel:
             k["var_max"] = np.asarray(self.var_max, dtype=np.float64)
             k["var_bounded"] = np.asarray(self.var_bounded, dtype=np.uint8)
             k["var_max_velocity"] = np.asarray(self.var_max_velocity, dtype=np.float64)
+            k["link_mass"] = np.asarray(self.link_mass, dtype=np.float64)
+            k["link_center"] = np.asarray(self.link_center, dtype=np.float64).reshape(-1, 3)
             self._keep = k
         return self._keep
 
@@ -220,6 +227,9 @@ class RobotModel:
         d.var_max = abi.dptr(k["var_max"])
         d.var_bounded = abi.u8ptr(k["var_bounded"])
         d.var_max_velocity = abi.dptr(k["var_max_velocity"])
+        if np.any(k["link_mass"] > 0.0):
+            d.link_mass = abi.dptr(k["link_mass"])
+            d.link_center = abi.dptr(k["link_center"])
         return d
 
 

@@ -10,7 +10,7 @@ src/kinematics_plugin.cpp:167-189) is built here from the robot description itse
     <end_effector parent_link parent_group> supplies the tips of a group without a chain;
     <virtual_joint name type parent_frame child_link> (fixed | floating | planar) puts a new root link `parent_frame` in front of
     the URDF's root, as MoveIt does for a mobile or free-flying base.
-Not read: inertials (BalanceGoal), collision / visual geometry, transmissions, <safety_controller>, xacro macros."""
+Read as well: <inertial> mass and origin of every link (BalanceGoal, goal_types.cpp:236-247).  Not read: collision / visual geometry, transmissions, <safety_controller>, xacro macros."""
 import xml.etree.ElementTree as ET
 
 from .robot import RobotModel
@@ -31,6 +31,12 @@ def load_urdf(urdf_xml, srdf_xml=None):
     if root.tag != "robot":
         raise ValueError("not a URDF: root element is <%s>" % root.tag)
     links = [l.get("name") for l in root.findall("link")]
+    inertial = {}
+    for l in root.findall("link"):
+        ine = l.find("inertial")
+        if ine is not None and ine.find("mass") is not None:
+            o = ine.find("origin")
+            inertial[l.get("name")] = (float(ine.find("mass").get("value", 0.0)), _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0)))
     joints = []
     for j in root.findall("joint"):
         jt = j.get("type")
@@ -96,6 +102,10 @@ def load_urdf(urdf_xml, srdf_xml=None):
             m.joint_mimic[i] = m.joint_names.index(j["mimic"][0])
             m.joint_mimic_factor[i] = j["mimic"][1]
             m.joint_mimic_offset[i] = j["mimic"][2]
+    for name, (mass, com) in inertial.items():
+        i = m.link_names.index(name)
+        m.link_mass[i] = mass
+        m.link_center[i] = [float(com[0]), float(com[1]), float(com[2])]
     m._keep = None
     if srdf_xml is not None:
         add_srdf_groups(m, srdf_xml)

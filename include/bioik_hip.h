@@ -76,9 +76,11 @@ enum {
     BIOIK_GOAL_SIDE = 13,                /* goal_types.h:585-614  params: axis[3] direction[3]                    */
     BIOIK_GOAL_DIRECTION = 14,           /* goal_types.h:616-644  params: axis[3] direction[3]                    */
     BIOIK_GOAL_CONE = 15,                /* goal_types.h:646-712  params: position[3] position_weight axis[3] direction[3] angle */
-    BIOIK_GOAL_TYPE_COUNT = 16
-    /* TouchGoal (FCL), JointFunctionGoal / LinkFunctionGoal (std::function), BalanceGoal (URDF inertials)
-     * have no device opcode in this round: DESIGN.md §7. */
+    BIOIK_GOAL_BALANCE = 16,             /* goal_types.h:540-566, goal_types.cpp:231-272  params: target[3] axis[3].  Reads the frames of
+                                            EVERY link of the model with a positive mass (bioik_model_desc::link_mass), each of which
+                                            becomes a tip of the problem, as BalanceGoal::describe does                              */
+    BIOIK_GOAL_TYPE_COUNT = 17
+    /* TouchGoal (FCL), JointFunctionGoal / LinkFunctionGoal (std::function) have no device opcode: DESIGN.md §7. */
 };
 
 /* number of per-query parameter doubles of a goal opcode, or -1 for an unknown opcode */
@@ -120,6 +122,9 @@ typedef struct bioik_model_desc {
     const double* var_max;               /* [n_variables] VariableBounds::max_position_                  */
     const uint8_t* var_bounded;          /* [n_variables] VariableBounds::position_bounded_              */
     const double* var_max_velocity;      /* [n_variables] VariableBounds::max_velocity_                  */
+    const double* link_mass;             /* [n_links] urdf::Link::inertial->mass, 0 where the link has no <inertial>; NULL: no link
+                                            has one (only BIOIK_GOAL_BALANCE reads it, goal_types.cpp:236-247)                  */
+    const double* link_center;           /* [n_links*3] urdf::Link::inertial->origin.position (link frame); NULL with link_mass   */
 } bioik_model_desc;
 
 /* ---- one goal of the problem template (structure shared by every query of a batch; the numeric
@@ -187,7 +192,7 @@ void bioik_model_destroy(bioik_model* m);
 /* replaces Problem::initialize + IKBase::initialize(problem) -> RobotFK::initialize(tips)
  * (problem.cpp:72-228, ik_base.h:154-161, forward_kinematics.h:253-330, 566-599).
  * Size limits of one problem (BIOIK_ERR_UNSUPPORTED beyond them): 64 moving joints on the union of the goal chains (a short
- * chain in front of a branch counts once per branch), 63 active variables, 8 tip links, 24 primary + 24 secondary goals. */
+ * chain in front of a branch counts once per branch), 63 active variables, 64 tip links, 24 primary + 24 secondary goals. */
 int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bioik_problem** out);
 void bioik_problem_destroy(bioik_problem* p);
 

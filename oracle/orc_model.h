@@ -35,6 +35,8 @@ struct Link {
     int var_count;
     int mimic;     // link index of the mimicked joint or -1
     double mimic_factor, mimic_offset;
+    double mass;   // urdf::Link::inertial->mass (0: no inertial), goal_types.cpp:236-247
+    Vec3 center;   // urdf::Link::inertial->origin.position
 };
 
 // robot_info.h:48-55
@@ -75,6 +77,8 @@ struct Model {
             l.mimic = d.joint_mimic ? d.joint_mimic[i] : -1;
             l.mimic_factor = d.joint_mimic_factor ? d.joint_mimic_factor[i] : 1.0;
             l.mimic_offset = d.joint_mimic_offset ? d.joint_mimic_offset[i] : 0.0;
+            l.mass = d.link_mass ? d.link_mass[i] : 0.0;
+            l.center = d.link_center ? Vec3{d.link_center[3 * i], d.link_center[3 * i + 1], d.link_center[3 * i + 2]} : Vec3{0.0, 0.0, 0.0};
             if (l.var_count > 0) {
                 if (l.first_var < 0 || l.first_var + l.var_count > (int)d.n_variables) throw std::runtime_error("joint variable index out of range");
                 for (int v = 0; v < l.var_count; v++) var_joint[l.first_var + v] = (int)i;

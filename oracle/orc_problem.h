@@ -32,6 +32,7 @@ inline int goal_param_count(int type) {
         case BIOIK_GOAL_SIDE: return 6;
         case BIOIK_GOAL_DIRECTION: return 6;
         case BIOIK_GOAL_CONE: return 11;
+        case BIOIK_GOAL_BALANCE: return 6;
     }
     return -1;
 }
@@ -49,6 +50,11 @@ struct GoalInfo {
     double weight, weight_sq;
     bool secondary;
     int param_offset;
+    // BalanceGoal (goal_types.h:544-549): one entry per link with mass, in model link order -- its problem tip index, its centre of mass
+    // in the link frame and its share of the total mass
+    std::vector<long> balance_tips;
+    std::vector<Vec3> balance_centers;
+    std::vector<double> balance_weights;
 };
 
 struct Problem {
@@ -116,6 +122,18 @@ struct Problem {
             if (g.variable >= 0) {
                 if (g.variable >= (int)nv) throw std::runtime_error("joint variable not found");
                 info.variable_index = add_active_variable(g.variable);
+            }
+            if (g.type == BIOIK_GOAL_BALANCE) {  // BalanceGoal::describe, goal_types.cpp:231-255
+                double total = 0.0;
+                for (size_t l = 0; l < nl; l++) {
+                    const double mass = m->links[l].mass;
+                    if (!(mass > 0)) continue;
+                    info.balance_centers.push_back(m->links[l].center);
+                    info.balance_weights.push_back(mass);
+                    total += mass;
+                    info.balance_tips.push_back((long)add_tip_link((int)l));
+                }
+                for (double& w : info.balance_weights) w /= total;
             }
             info.weight = g.weight;
             info.weight_sq = info.weight * info.weight;
@@ -253,6 +271,20 @@ struct Problem {
                 Vec3 v;
                 quat_mul_vec(fbp->rot, Vec3{P[0], P[1], P[2]}, v);
                 return distance2(v, Vec3{P[3], P[4], P[5]});
+            }
+            case BIOIK_GOAL_BALANCE: {  // goal_types.cpp:257-272
+                Vec3 center = {0.0, 0.0, 0.0};
+                for (size_t i = 0; i < g.balance_tips.size(); i++) {
+                    const Frame& frame = tip_frames[g.balance_tips[i]];
+                    Vec3 c = g.balance_centers[i];
+                    quat_mul_vec(frame.rot, c, c);
+                    c = c + frame.pos;
+                    center = center + c * g.balance_weights[i];
+                }
+                Vec3 target = {P[0], P[1], P[2]}, axis = {P[3], P[4], P[5]};
+                center = center - target;
+                center = center - axis * dot(axis, center);
+                return length2(center);
             }
             case BIOIK_GOAL_CONE: {  // :700-711
                 double sum = 0.0;

@@ -86,6 +86,14 @@ std::shared_ptr<moveit::core::RobotModel> build_model(const bioik_model_desc& d)
         m->joints_.emplace_back(j), m->links_.emplace_back(l);
         m->joint_ptrs_.push_back(j), m->link_ptrs_.push_back(l);
         m->joint_names_.push_back(j->name_), m->link_names_.push_back(l->name_);
+        auto ul = std::make_shared<urdf::Link>();  // the URDF side of the link: its <inertial>, if it has one
+        if (d.link_mass && d.link_mass[i] != 0.0) {
+            ul->inertial = std::make_shared<urdf::Inertial>();
+            ul->inertial->mass = d.link_mass[i];
+            ul->inertial->origin.position.x = d.link_center[3 * i], ul->inertial->origin.position.y = d.link_center[3 * i + 1];
+            ul->inertial->origin.position.z = d.link_center[3 * i + 2];
+        }
+        m->urdf_->links_[l->name_] = ul;
     }
     for (uint32_t i = 0; i < d.n_links; i++) {
         if (d.joint_mimic && d.joint_mimic[i] >= 0) {
@@ -143,6 +151,12 @@ struct Ref {
             case BIOIK_GOAL_SIDE: need_primary(); return new SideGoal(link, v3(p), v3(p + 3), g.weight);
             case BIOIK_GOAL_DIRECTION: need_primary(); return new DirectionGoal(link, v3(p), v3(p + 3), g.weight);
             case BIOIK_GOAL_CONE: need_primary(); return new ConeGoal(link, v3(p), p[3], v3(p + 4), v3(p + 7), p[10], g.weight);
+            case BIOIK_GOAL_BALANCE: {
+                need_primary();
+                auto* x = new BalanceGoal(v3(p), g.weight);
+                x->setAxis(v3(p + 3));
+                return x;
+            }
         }
         throw std::runtime_error("unknown goal opcode");
     }
@@ -172,8 +186,8 @@ std::vector<double> full_vars(const Ref& r, const double* seed, const double* ge
 
 // bioik_goal_param_count lives in the product library; the reference driver carries its own copy of the table
 extern "C" int bioik_goal_param_count(int t) {
-    static const int n[16] = {3, 4, 8, 6, 4, 4, 6, 6, 0, 0, 0, 0, 1, 6, 6, 11};
-    return (t >= 0 && t < 16) ? n[t] : -1;
+    static const int n[17] = {3, 4, 8, 6, 4, 4, 6, 6, 0, 0, 0, 0, 1, 6, 6, 11, 6};
+    return (t >= 0 && t < 17) ? n[t] : -1;
 }
 
 #define TRY try {

@@ -8,6 +8,30 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+// stand-in for urdf_model: what BalanceGoal::describe reads (src/goal_types.cpp:236-247)
+namespace urdf {
+struct Vector3 {
+    double x = 0, y = 0, z = 0;
+};
+struct Pose {
+    Vector3 position;
+};
+struct Inertial {
+    Pose origin;
+    double mass = 0;
+};
+struct Link {
+    std::shared_ptr<Inertial> inertial;
+};
+struct ModelInterface {
+    std::map<std::string, std::shared_ptr<Link>> links_;
+    std::shared_ptr<const Link> getLink(const std::string& name) const {
+        auto it = links_.find(name);
+        return it == links_.end() ? std::shared_ptr<const Link>() : std::shared_ptr<const Link>(it->second);
+    }
+};
+typedef std::shared_ptr<ModelInterface> ModelInterfaceSharedPtr;
+}  // namespace urdf
 namespace moveit {
 namespace core {
 struct VariableBounds {
@@ -104,6 +128,8 @@ public:
     std::vector<std::string> link_names_, joint_names_, variable_names_;
     std::map<std::string, int> variable_index_;
     std::map<std::string, std::unique_ptr<JointModelGroup>> groups_;
+    urdf::ModelInterfaceSharedPtr urdf_ = std::make_shared<urdf::ModelInterface>();
+    const urdf::ModelInterfaceSharedPtr& getURDF() const { return urdf_; }
     const std::string& getName() const { static std::string n = "robot"; return n; }
     size_t getVariableCount() const { return variable_names_.size(); }
     size_t getJointModelCount() const { return joint_ptrs_.size(); }

@@ -120,6 +120,28 @@ def mimic_robot():
     return m
 
 
+def balance_robot():
+    """A small two-armed torso whose links carry URDF inertials (test fixture only): BalanceGoal reads the frame of EVERY link with a
+    positive mass (goal_types.cpp:231-255) -- links on the arms, a link behind a fixed joint, the root itself, and a link on a branch
+    no other goal touches (`ballast`, moved by a joint of the group)."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("balance")
+    m.add_link("pelvis", mass=6.0, com=(0.01, 0.0, 0.05))
+    m.add_link("torso", "pelvis", "waist", "revolute", xyz=(0.0, 0.0, 0.2), axis=(0, 0, 1), lower=-1.5, upper=1.5, velocity=1.5, mass=9.0, com=(0.0, 0.01, 0.25))
+    m.add_link("pack", "torso", "pack_joint", "fixed", xyz=(-0.15, 0.0, 0.3), rpy=(0.0, 0.2, 0.0), mass=3.0, com=(-0.05, 0.0, 0.0))
+    for side, sgn in (("a", 1.0), ("b", -1.0)):
+        m.add_link(side + "_upper", "torso", side + "_shoulder", "revolute", xyz=(0.0, sgn * 0.2, 0.45), rpy=(sgn * 0.3, 0.0, 0.0), axis=(0, 1, 0), lower=-2.0, upper=2.0,
+                   velocity=2.0, mass=2.0, com=(0.12, 0.0, 0.0))
+        m.add_link(side + "_lower", side + "_upper", side + "_elbow", "revolute", xyz=(0.3, 0.0, 0.0), axis=(0, 0.6, 0.8), lower=-2.2, upper=0.4, velocity=2.5,
+                   mass=1.2, com=(0.1, 0.01, 0.0))
+        m.add_link(side + "_hand", side + "_lower", side + "_wrist", "continuous", xyz=(0.25, 0.0, 0.0), axis=(1, 0, 0), velocity=3.0, mass=0.4, com=(0.04, 0.0, 0.0))
+        m.add_link(side + "_tool", side + "_hand", side + "_tool_joint", "fixed", xyz=(0.08, 0.0, 0.0))
+    m.add_link("ballast", "pelvis", "ballast_slide", "prismatic", xyz=(0.0, 0.0, -0.1), axis=(1, 0, 0), lower=-0.3, upper=0.3, velocity=0.5, mass=4.0, com=(0.0, 0.0, -0.05))
+    joints = ["waist", "a_shoulder", "a_elbow", "a_wrist", "b_shoulder", "b_elbow", "b_wrist", "ballast_slide"]
+    m.add_group("body", joints=joints, tips=["a_tool", "b_tool"])
+    return m
+
+
 def gnarly_goals():
     """one goal of every device opcode, spread over four tips (one of them the joint-less `plate`)"""
     from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, ConeGoal, DirectionGoal, JointVariableGoal, LineGoal, LookAtGoal,

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, ProblemTemplate, abi, pr2_like, snake  # noqa: E402
+from bio_ik_amd import AvoidJointLimitsGoal, BalanceGoal, MinimalDisplacementGoal, PoseGoal, ProblemTemplate, abi, pr2_like, snake  # noqa: E402
 from bio_ik_amd.workload import make_queries  # noqa: E402
-from conftest import gnarly_goals, gnarly_robot, random_configuration  # noqa: E402
+from conftest import balance_robot, gnarly_goals, gnarly_robot, random_configuration  # noqa: E402
 from oracle import orc, ref  # noqa: E402
 
 
@@ -25,6 +25,7 @@ def templates():
         "c3": ProblemTemplate(pr2, "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]),
         "c4": ProblemTemplate(sn, "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]),
         "gnarly": ProblemTemplate(gn, "body", gnarly_goals()),
+        "balance": ProblemTemplate(balance_robot(), "body", [PoseGoal("a_tool"), BalanceGoal((0.02, -0.01, 0.0), weight=0.8)]),
     }
 
 
@@ -49,7 +50,7 @@ def main():
                     name + "/params": par, name + "/primary_exact": pe, name + "/secondary_exact": se, name + "/near": near,
                     name + "/primary_linear": pl, name + "/base_tips": bt, name + "/linear_frames": lin,
                     name + "/check": r.check(seed, raw, genes), name + "/active_variables": r.active_variables, name + "/tip_links": r.tip_links})
-        if name == "gnarly":
+        if name in ("gnarly", "balance"):
             continue
         # whole trajectories of the reference solver (reference RNG: std::minstd_rand + tables, seed 5), 3 queries x 10 steps
         seeds, params, _ = make_queries(t, r.active_variables, o.fk_genes, 3, seed=3)

@@ -102,3 +102,48 @@ def pose_errors(o, sol, params, tip=0, off=0):
     dots = np.abs(np.einsum("ij,ij->i", tips[:, tip, 3:], params[:, off + 3:off + 7]))
     rerr = 2 * np.arccos(np.minimum(1.0, dots))
     return perr, rerr
+
+
+def balance_queries(template, o, n, seed=5):
+    """FK -> IK -> FK round trip with a BalanceGoal: goals [PoseGoal(tip), BalanceGoal]; the pose AND the centre-of-mass target are those of
+    a random reachable configuration (oracle FK), the seed is another random configuration.  Returns seeds, params, (pose offset, balance offset)."""
+    model = template.model
+    seeds, params, targets = make_queries(template, o.active_variables, o.fk_genes, n, seed=seed)
+    mass = np.asarray(model.link_mass)
+    share = mass / mass.sum()
+    centers = np.asarray(model.link_center)
+    from bio_ik_amd.robot import quat_rotate
+    off = [off for g, off in zip(template.goals, template.param_offsets) if g.opcode == abi.GOAL_BALANCE][0]
+    full = np.tile(model.default_positions(), (n, 1))
+    full[:, o.active_variables] = targets
+    tips = o.fk(full)
+    tip_of_link = {int(l): i for i, l in enumerate(o.tip_links)}
+    for k in range(n):
+        com = np.zeros(3)
+        for l in np.nonzero(mass > 0)[0]:
+            f = tips[k, tip_of_link[int(l)]]
+            com += (f[:3] + quat_rotate(f[3:], centers[l])) * share[l]
+        params[k, off:off + 3] = com
+    return seeds, params, off
+
+
+def balance_errors(template, o, sol, params, off):
+    """horizontal distance [m] of the centre of mass of the returned configurations from the balance target, under the ORACLE's FK"""
+    model = template.model
+    mass = np.asarray(model.link_mass)
+    share = mass / mass.sum()
+    centers = np.asarray(model.link_center)
+    from bio_ik_amd.robot import quat_rotate
+    tips = o.fk(sol)
+    tip_of_link = {int(l): i for i, l in enumerate(o.tip_links)}
+    err = np.zeros(sol.shape[0])
+    for k in range(sol.shape[0]):
+        com = np.zeros(3)
+        for l in np.nonzero(mass > 0)[0]:
+            f = tips[k, tip_of_link[int(l)]]
+            com += (f[:3] + quat_rotate(f[3:], centers[l])) * share[l]
+        d = com - params[k, off:off + 3]
+        ax = params[k, off + 3:off + 6]
+        d = d - ax * (ax @ d)
+        err[k] = np.linalg.norm(d)
+    return err

@@ -95,6 +95,37 @@ def test_urdf_loaded_model_solves_on_the_device():
     assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
 
 
+def test_balance_goal():
+    """BalanceGoal on the device (goal_types.cpp:231-272): ten links with mass = ten more tips, centre of mass accumulated along the
+    chain walk.  Function level against the reference-pinned oracle arithmetic, and 512 FK -> IK -> FK round trips on pose + balance."""
+    from bio_ik_amd import AvoidJointLimitsGoal, BalanceGoal, PoseGoal
+    from bio_ik_amd.solver import BioIKError, HipSolver
+    from conftest import balance_robot
+    m = balance_robot()
+    for goals in ([PoseGoal("a_tool"), BalanceGoal((0.02, -0.01, 0.0), weight=0.8)], [BalanceGoal((0.0, 0.0, 0.0))],
+                  [BalanceGoal((0.01, 0.0, 0.0)), PoseGoal("b_tool"), AvoidJointLimitsGoal(weight=0.2)]):
+        t = ProblemTemplate(m, "body", goals)
+        h, o = HipSolver(t), orc.Oracle(t)
+        assert h.T == o.T >= 10 and np.array_equal(h.tip_links, o.tip_links)
+        for mode in (0, 1):
+            with pc.oracle_arithmetic(mode):
+                pc.function_level(h, o, m, np.random.default_rng(15), n=1000, frame_tol=1e-12, fit_rtol=1e-10)
+    t = ProblemTemplate(m, "body", [PoseGoal("a_tool"), BalanceGoal(weight=1.0)])
+    h, o = HipSolver(t), orc.Oracle(t)
+    with pc.oracle_arithmetic(0):
+        seeds, params, off = pc.balance_queries(t, o, 512, seed=8)
+    sol, fit, suc, steps = h.solve_batch(abi.default_solve_params(population=128, max_steps=96, random_seed=4), seeds, params)
+    assert suc.mean() > 0.8
+    with pc.oracle_arithmetic(0):
+        perr, rerr = pc.pose_errors(o, sol, params)
+        berr = pc.balance_errors(t, o, sol, params, off)
+    assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL and berr[suc == 1].max() < POS_TOL
+    from bio_ik_amd import pr2_like
+    with pytest.raises(BioIKError) as e:  # a model without inertials cannot carry a BalanceGoal
+        HipSolver(ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link"), BalanceGoal()]))
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT
+
+
 def test_no_active_variable(pr2):
     """every joint of the group fixed: D = 0, the solve runs its budget and returns the seed, as the oracle does"""
     from bio_ik_amd import PoseGoal

@@ -227,3 +227,30 @@ def test_solve_batch_multi_equals_single_handle(hostsim_lib, templates, sims):
     from bio_ik_amd.solver import BioIKError
     with pytest.raises(BioIKError):
         h0.solve_batch_multi([sims["c3"]], p, seeds, params)  # another template
+
+
+def test_balance_goal(hostsim_lib):
+    """BalanceGoal (goal_types.cpp:231-272): every link with a URDF mass is a tip; the device accumulates the centre of mass as the
+    walk reaches the tips.  Function level against both oracle arithmetics (the device visits the tips in walk order, the reference in
+    link order: sums agree to rounding), and a small FK -> IK -> FK round trip on pose + balance."""
+    from bio_ik_amd import AvoidJointLimitsGoal, BalanceGoal, PoseGoal
+    from conftest import balance_robot
+    m = balance_robot()
+    for goals in ([PoseGoal("a_tool"), BalanceGoal((0.02, -0.01, 0.0), weight=0.8)], [BalanceGoal((0.0, 0.0, 0.0))],
+                  [BalanceGoal((0.01, 0.0, 0.0)), PoseGoal("b_tool"), AvoidJointLimitsGoal(weight=0.2)]):
+        t = ProblemTemplate(m, "body", goals)
+        h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+        assert h.T == o.T >= 10
+        for mode in (0, 1):
+            with pc.oracle_arithmetic(mode):
+                pc.function_level(h, o, m, np.random.default_rng(15), n=40, frame_tol=1e-12, fit_rtol=1e-10)
+    t = ProblemTemplate(m, "body", [PoseGoal("a_tool"), BalanceGoal(weight=1.0)])
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    with pc.oracle_arithmetic(0):
+        seeds, params, off = pc.balance_queries(t, o, 3, seed=8)
+    sol, fit, suc, steps = h.solve_batch(abi.default_solve_params(population=24, max_steps=80, random_seed=4), seeds, params)
+    assert suc.sum() >= 2
+    with pc.oracle_arithmetic(0):
+        perr, rerr = pc.pose_errors(o, sol, params)
+        berr = pc.balance_errors(t, o, sol, params, off)
+    assert perr[suc == 1].max() < 1e-4 and rerr[suc == 1].max() < 1e-3 and berr[suc == 1].max() < 1e-4
