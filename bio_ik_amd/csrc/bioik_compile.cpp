@@ -485,6 +485,19 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             dev.primary[np++] = to_dev(g);
         }
     }
+    {   // `jac`: tipObjectives[goal.tip_index] = goal.frame over the primary goals in order (ik_gradient.cpp:64-66); a goal without a link
+        // has tip_index 0 and an identity frame (problem.cpp:152-155), so it resets tip 0's objective
+        std::vector<int> obj_type(T, -1), obj_off(T, -1);
+        for (const G& g : goals) {
+            if (g.secondary) continue;
+            const int pub = g.tip >= 0 ? g.tip : 0;
+            if (pub >= T) continue;
+            const bool framed = g.tip >= 0 && (g.type == BIOIK_GOAL_POSITION || g.type == BIOIK_GOAL_ORIENTATION || g.type == BIOIK_GOAL_POSE);
+            obj_type[pub] = framed ? g.type : -1;
+            obj_off[pub] = framed ? g.param_off : -1;
+        }
+        for (int pub = 0; pub < T; pub++) dev.tips[dev.tip_of_out[pub]].obj_type = obj_type[pub], dev.tips[dev.tip_of_out[pub]].obj_param_off = obj_off[pub];
+    }
     dev.n_primary = np;
     dev.n_secondary = ns;
     dev.n_ops = (int)ops.size();
@@ -521,13 +534,16 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.dpos = thr(p.dpos), o.drot = thr(p.drot), o.dtwist = thr(p.dtwist);
     o.random_seed = p.random_seed;
     o.first_query = first_query;
-    if (p.mode != BIOIK_MODE_BIO2 && p.mode != BIOIK_MODE_BIO2_MEMETIC && p.mode != BIOIK_MODE_BIO2_MEMETIC_L)
+    if (p.mode != BIOIK_MODE_BIO2 && p.mode != BIOIK_MODE_BIO2_MEMETIC && p.mode != BIOIK_MODE_BIO2_MEMETIC_L && p.mode != BIOIK_MODE_GD_C &&
+        p.mode != BIOIK_MODE_JAC)
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown solver mode");
     o.memetic = p.mode == BIOIK_MODE_BIO2 ? 0 : (p.mode == BIOIK_MODE_BIO2_MEMETIC_L ? 'l' : 'q');
+    o.solver = p.mode == BIOIK_MODE_GD_C ? 1 : (p.mode == BIOIK_MODE_JAC ? 2 : 0);
     if (p.fk_mode != BIOIK_FK_LINEAR && p.fk_mode != BIOIK_FK_EXACT) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown fk_mode");
     o.fk_mode = p.fk_mode;
     o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
     o.islands = p.islands > 0 ? p.islands : 1;
+    if (o.solver != 0) o.islands = 1;  // gd_c / jac run one island started at the seed (the reference's further threads start at random points)
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
     if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
         const double ticks = p.timeout * 1e8;

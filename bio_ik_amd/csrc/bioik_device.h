@@ -832,6 +832,44 @@ BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, con
     out7[6] = dq.w - tf.q.w;
 }
 
+// The raw Jacobian column of gene op k for tip t (RobotFK_Jacobian::computeJacobian, forward_kinematics.h:600-730): tip-local linear and
+// angular velocity, the six numbers the `jac` solver stacks into its least-squares system (ik_gradient.cpp:97-113).  Same frames, same
+// arithmetic as approximator_entry up to the point where that one turns the column into a world-frame delta.
+template <class PB>
+BIOIK_DEV void jacobian_entry6(PB pb, int t, int k, const double* frames, const double* tips, double* out6, const double* base) {
+    BIOIK_FP_STRICT
+    const uint64_t dep_mask = pb->tips[t].dep_mask;
+    const int n_chain = pb->n_chain_ops;
+    const bool gene = pb->ops[k].gene >= 0;
+    const int jop = pb_flavour<PB>::general ? pb->ops[k].joint_op : -1;
+    for (int c = 0; c < 6; c++) out6[c] = 0.0;
+    if (jop >= 0) {
+        if (!gene || ((dep_mask >> jop) & 1ull) == 0) return;
+        const int type = pb->ops[jop].type, vf = pb->ops[jop].val_first;
+        const F7 cf = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
+        F7 values_2 = multi_joint_values(type, XV{base, 1}, vf);
+        multi_joint_bump(values_2, k - vf, 0.00001);
+        const Twist6 tw = jacobian_numeric(type, cf, values_2, f7_load(frames + jop * 7), f7_load(tips + t * 7));
+        for (int c = 0; c < 6; c++) out6[c] = tw.v[c];
+        return;
+    }
+    const bool own = gene && k < n_chain && ((dep_mask >> k) & 1ull) != 0;
+    const uint64_t followers = gene ? pb->mimic_followers[k] & dep_mask : 0ull;
+    if (!own && followers == 0ull) return;
+    const F7 tf = f7_load(tips + t * 7);
+    V3 vel = v3(0.0, 0.0, 0.0), om = v3(0.0, 0.0, 0.0);
+    if (own) jacobian_column(pb, k, f7_load(frames + k * 7), tf, vel, om);
+    for (uint64_t rest = followers; rest != 0ull; rest &= rest - 1ull) {
+        const int m = __builtin_ctzll(rest);
+        V3 v2, o2;
+        jacobian_column(pb, m, f7_load(frames + m * 7), tf, v2, o2);
+        const double scale = pb->ops[m].mimic_factor;
+        vel = v3(vel.x + v2.x * scale, vel.y + v2.y * scale, vel.z + v2.z * scale);
+        om = v3(om.x + o2.x * scale, om.y + o2.y * scale, om.z + o2.z * scale);
+    }
+    out6[0] = vel.x, out6[1] = vel.y, out6[2] = vel.z, out6[3] = om.x, out6[4] = om.y, out6[5] = om.z;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // reproduction of ONE child (ik_evolution_2.cpp:263-300) with the counter RNG; bit-exact against the oracle.
 //   p0g / p0d / p1d: LDS, op-indexed genes of parent 0 and momentum ("gradients") of parents 0 and 1

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bioik_compile.h"
+#include "bioik_gradient.h"
 #include "bioik_kernels.h"
 
 static_assert((int)G_POSITION == (int)BIOIK_GOAL_POSITION && (int)G_POSE == (int)BIOIK_GOAL_POSE && (int)G_CONE == (int)BIOIK_GOAL_CONE &&
@@ -105,6 +106,11 @@ __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve(Solve
 __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true>(a, blockIdx.x, lds);
+}
+// the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
+__global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
+    extern __shared__ double lds[];
+    point_body(a, blockIdx.x, lds);
 }
 __global__ void k_select(SelectArgs a) { select_body(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void __launch_bounds__(256) k_eval_fk(EvalArgs a) {
@@ -261,6 +267,20 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
+    if (sp.solver != 0) {  // gd_c / jac: one wavefront per query, its own (small) LDS layout
+        const size_t lds_point = (size_t)make_point_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, dp.D, 64).total * 8;
+        if (lds_point > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem too large for the gd_c / jac kernels (more than 64 KiB of LDS per query)");
+        SolveArgs pa;
+        pa.pb = p->pb(), pa.sp = sp, pa.seeds = d_seeds, pa.params = d_params;
+        pa.solutions = d_solutions, pa.fitness = d_fitness, pa.success = d_success, pa.steps = d_steps;
+        pa.phase_cycles = nullptr, pa.launch_clock = nullptr;
+        if (sp.timeout_ticks != 0) {
+            pa.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
+            be_zero_async(pa.launch_clock, sizeof(unsigned long long), stream);
+        }
+        LAUNCH(k_solve_point, point_body(pa, b_, l_), n, 64, lds_point, stream, pa);
+        return;
+    }
     // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
     // and evaluated in pairs / kept / re-derived from the RNG, or 64 lanes (one wavefront, the species one after the other).  A CU
     // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU

@@ -48,6 +48,8 @@ struct DevTip {
     int32_t out_index;                 // index in Problem::tip_link_indices (order of the public API)
     int32_t goal_first, goal_count;    // primary link goals reading this tip: DevProblem::primary[goal_first..)
     uint64_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
+    int32_t obj_type;                  // `jac` solver: what last wrote tipObjectives[tip] (ik_gradient.cpp:64-66): BIOIK_GOAL_POSITION /
+    int32_t obj_param_off;             // ORIENTATION / POSE with its parameter offset, -1 = an identity frame
     double bal_w;                      // BalanceGoal: the link's share of the robot's mass (goal_types.cpp:246-254), 0 = none
     double bal_c[3];                   // BalanceGoal: the link's centre of mass in the link frame (urdf inertial origin)
 };
@@ -106,6 +108,8 @@ struct DevSolveParams {
     uint64_t first_query;       // global index of query 0 of this launch (multi-GPU shards keep their RNG streams)
     uint64_t timeout_ticks;     // wall-clock budget of the launch in ticks of the 100 MHz device clock, 0 = none (ik_parallel.h:160)
     int32_t memetic;            // 0, 'q', 'l'
+    int32_t solver;             // 0: the bio2 family (k_solve), 1: gd_c, 2: jac (k_solve_point, src/ik_gradient.cpp)
+    int32_t pad0;
     int32_t fk_mode;            // BIOIK_FK_*
     int32_t lambda;             // children per species per generation
     int32_t islands;

@@ -90,7 +90,12 @@ int bioik_goal_param_count(int goal_type);
 enum {
     BIOIK_MODE_BIO2 = 0,            /* "bio2":           16 generations per step, no memetic phase      */
     BIOIK_MODE_BIO2_MEMETIC = 1,    /* "bio2_memetic":   8 generations + quadratic ('q') line search    */
-    BIOIK_MODE_BIO2_MEMETIC_L = 2   /* "bio2_memetic_l": 8 generations + linear ('l') line search       */
+    BIOIK_MODE_BIO2_MEMETIC_L = 2,  /* "bio2_memetic_l": 8 generations + linear ('l') line search       */
+    /* IKFactory names of reference src/ik_gradient.cpp:254-292 (one island, started at the seed; population / fk_mode are not used) */
+    BIOIK_MODE_GD_C = 3,            /* "gd_c": gradient descent by central differences of the exact fitness, linear step estimate,
+                                       always continue (ik_gradient.cpp:136-251, if_stuck = 'c')                                   */
+    BIOIK_MODE_JAC = 4              /* "jac":  pseudo-inverse-Jacobian steps on the twists between the tips and their pose goals
+                                       (ik_gradient.cpp:42-133, 269-292)                                                          */
 };
 
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */

@@ -402,6 +402,8 @@ struct OrcSolver {
     int rng_mode;
     std::unique_ptr<Evolution2<ReferenceRandom>> ref;
     std::unique_ptr<Evolution2<CounterRandom>> ctr;
+    std::unique_ptr<GradientDescent> gd;   // BIOIK_MODE_GD_C
+    std::unique_ptr<JacobianSolver> jac;   // BIOIK_MODE_JAC
     std::vector<double> seed, params;
 };
 
@@ -415,7 +417,13 @@ void* orc_solver_create(void* problem, const bioik_solve_params* params, int rng
         s->params.assign(goal_params, goal_params + p.param_count);
         s->params.push_back(0.0);
         Query q{s->seed.data(), s->params.data()};
-        if (rng_mode == ORC_RNG_REFERENCE) {
+        if (params->mode == BIOIK_MODE_GD_C) {
+            s->gd.reset(new GradientDescent(&p, *params, 'c'));
+            s->gd->initialize(q);
+        } else if (params->mode == BIOIK_MODE_JAC) {
+            s->jac.reset(new JacobianSolver(&p, *params));
+            s->jac->initialize(q);
+        } else if (rng_mode == ORC_RNG_REFERENCE) {
             s->ref.reset(new Evolution2<ReferenceRandom>(&p, ReferenceRandom(rng_key), *params));
             s->ref->initialize(q);
         } else {
@@ -436,6 +444,8 @@ int orc_solver_step(void* solver) {
         auto* s = (OrcSolver*)solver;
         if (s->ref) s->ref->step();
         if (s->ctr) s->ctr->step();
+        if (s->gd) s->gd->step();
+        if (s->jac) s->jac->step();
         return 0;
     } catch (const std::exception& e) {
         return fail(e);
@@ -445,6 +455,11 @@ int orc_solver_state(void* solver, double* species_genes, double* species_fitnes
     auto* s = (OrcSolver*)solver;
     if (s->ref) dump_state(*s->ref, species_genes, species_fitness, solution, solution_fitness);
     if (s->ctr) dump_state(*s->ctr, species_genes, species_fitness, solution, solution_fitness);
+    if (s->gd || s->jac) {  // point solvers: only the solution (getSolution(), ik_gradient.cpp:160, 287)
+        const std::vector<double>& v = s->gd ? s->gd->get_solution() : s->jac->get_solution();
+        for (size_t i = 0; i < v.size(); i++) solution[i] = v[i];
+        *solution_fitness = 0.0;
+    }
     return 0;
 }
 int orc_solver_check(void* solver, int32_t* success, double* fitness) {
@@ -453,6 +468,8 @@ int orc_solver_check(void* solver, int32_t* success, double* fitness) {
     double f = 0;
     if (s->ref) s->ref->check(ok, f);
     if (s->ctr) s->ctr->check(ok, f);
+    if (s->gd) s->gd->check(ok, f);
+    if (s->jac) s->jac->check(ok, f);
     *success = ok ? 1 : 0;
     *fitness = f;
     return 0;

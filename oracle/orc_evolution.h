@@ -16,6 +16,7 @@
 #include <limits>
 #include <vector>
 
+#include "orc_gradient.h"
 #include "orc_problem.h"
 #include "orc_rng.h"
 
@@ -368,6 +369,8 @@ struct Evolution2 {
         step_index++;
     }
 
+    const std::vector<double>& get_solution() const { return solution; }
+
     // ik_parallel.h:173-181: exact FK of getSolution(), checkSolution, computeFitness
     void check(bool& success, double& fitness) {
         fk.apply_configuration(solution);
@@ -385,13 +388,13 @@ struct IslandResult {
 };
 
 // one island of ik_parallel.h:148-190; budget mode (timeout_s<=0): check after every step, at most max_steps steps;
-// wall-clock mode: the reference's loop (1 step + up to 3 more while time remains, then check).
-template <class Rng>
-IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_params& sp, const Query& q, double timeout_s) {
+// wall-clock mode: the reference's loop (1 step + up to 3 more while time remains, then check).  Any solver with
+// initialize(q) / step() / check(success, fitness) / get_solution().
+template <class Solver>
+IslandResult run_island_loop(Solver& ik, size_t n_vars, const bioik_solve_params& sp, const Query& q, double timeout_s) {
     using clock = std::chrono::steady_clock;
-    Evolution2<Rng> ik(problem, rng, sp);
     IslandResult r;
-    r.solution.assign(q.initial_guess, q.initial_guess + problem->model->vars.size());
+    r.solution.assign(q.initial_guess, q.initial_guess + n_vars);
     ik.initialize(q);
     auto t_end = clock::now() + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 0));
     bool wall = timeout_s > 0;
@@ -413,11 +416,27 @@ IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_param
         double fitness;
         ik.check(success, fitness);
         r.success = success;
-        r.solution = ik.solution;
+        r.solution = ik.get_solution();
         r.fitness = fitness;
         if (success) break;
     }
     return r;
+}
+
+// the solver behind an IKFactory name (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292)
+template <class Rng>
+IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_params& sp, const Query& q, double timeout_s) {
+    const size_t nv = problem->model->vars.size();
+    if (sp.mode == BIOIK_MODE_GD_C) {
+        GradientDescent ik(problem, sp, 'c');
+        return run_island_loop(ik, nv, sp, q, timeout_s);
+    }
+    if (sp.mode == BIOIK_MODE_JAC) {
+        JacobianSolver ik(problem, sp);
+        return run_island_loop(ik, nv, sp, q, timeout_s);
+    }
+    Evolution2<Rng> ik(problem, rng, sp);
+    return run_island_loop(ik, nv, sp, q, timeout_s);
 }
 
 }  // namespace orc

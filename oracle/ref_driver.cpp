@@ -227,6 +227,8 @@ void* ref_create(const bioik_model_desc* md, const bioik_problem_desc* pd, const
     r->ikparams.robot_model = r->model;
     r->ikparams.joint_model_group = g;
     r->ikparams.solver_class_name = sp && sp->mode == BIOIK_MODE_BIO2 ? "bio2" : (sp && sp->mode == BIOIK_MODE_BIO2_MEMETIC_L ? "bio2_memetic_l" : "bio2_memetic");
+    if (sp && sp->mode == BIOIK_MODE_GD_C) r->ikparams.solver_class_name = "gd_c";  // src/ik_gradient.cpp:263
+    if (sp && sp->mode == BIOIK_MODE_JAC) r->ikparams.solver_class_name = "jac";    // src/ik_gradient.cpp:289
     r->ikparams.enable_counter = false;
     r->ikparams.thread_count = 1;
     r->ikparams.random_seed = sp ? (int)sp->random_seed : 0;
@@ -436,6 +438,7 @@ void* ref_solver_create(void* h, const double* seed, const double* params) {
     s->ref = &r;
     s->ik.reset(IKFactory::create(r.ikparams.solver_class_name, r.ikparams));  // src/utils.h:398-444, ik_evolution_2.cpp:652-654
     s->ik->canceled = false;  // IKParallel::solve does this before every run (src/ik_parallel.h:211-212); IKBase leaves it uninitialised
+    s->ik->thread_index = 0;  // IKParallel numbers its solver clones (src/ik_parallel.h:127); IKBase leaves it uninitialised
     s->ik->initialize(r.problem);
     return s;
     CATCH(nullptr)
@@ -461,6 +464,7 @@ int ref_solve_batch(void* h, size_t n, const double* seeds, const double* params
     size_t V = r.model->getVariableCount(), P = (size_t)r.P;
     if (!r.batch_solver) r.batch_solver.reset(IKFactory::create(r.ikparams.solver_class_name, r.ikparams));  // once, like the plugin
     IKSolver* ik = r.batch_solver.get();
+    ik->thread_index = 0;
     std::vector<double> zero(1, 0.0);
     for (size_t q = 0; q < n; q++) {
         r.set_query(seeds + q * V, P ? params + q * P : zero.data());

@@ -126,6 +126,21 @@ def test_balance_goal():
     assert e.value.code == abi.ERR_INVALID_ARGUMENT
 
 
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_gradient_descent_and_jacobian_solvers(gpus, oracles, templates, cfg):
+    """modes gd_c and jac (reference src/ik_gradient.cpp:136-251, 42-133) on the device, one wavefront per query (k_solve_point)"""
+    h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+    pc.point_solvers(h, o, t, n=64, exact_jac=False)
+    if cfg == "c2":  # result level: jac converges on tracking queries; every success reproduces its pose under the reference-pinned FK
+        with pc.oracle_arithmetic(0):
+            seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2048, seed=17, kind="tracking")
+        sol, fit, suc, steps = h.solve_batch(abi.default_solve_params(mode="jac", max_steps=32), seeds, params)
+        assert suc.mean() > 0.9
+        with pc.oracle_arithmetic(0):
+            perr, rerr = pc.pose_errors(o, sol, params)
+        assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+
+
 def test_no_active_variable(pr2):
     """every joint of the group fixed: D = 0, the solve runs its budget and returns the seed, as the oracle does"""
     from bio_ik_amd import PoseGoal

@@ -254,3 +254,11 @@ def test_balance_goal(hostsim_lib):
         perr, rerr = pc.pose_errors(o, sol, params)
         berr = pc.balance_errors(t, o, sol, params, off)
     assert perr[suc == 1].max() < 1e-4 and rerr[suc == 1].max() < 1e-3 and berr[suc == 1].max() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3", "c4"])
+def test_gradient_descent_and_jacobian_solvers(sims, oracles, templates, cfg):
+    """modes gd_c and jac (reference src/ik_gradient.cpp:136-251, 42-133): the kernel bodies against the oracle, bit for bit"""
+    out = pc.point_solvers(sims[cfg], oracles[cfg], templates[cfg], n=3)
+    if cfg == "c2":
+        assert out[2].all()  # jac reaches a pose goal near its seed within ten steps
