@@ -12,6 +12,8 @@
 //   src/problem.cpp:244-341                        computeGoalFitness, checkSolutionActiveVariables
 //   src/ik_evolution_2.cpp:242-326                 reproduce
 #pragma once
+#include <type_traits>
+
 #include "bioik_platform.h"
 
 
@@ -199,9 +201,10 @@ BIOIK_CALL double goal_eval_link_rare(int type, const lds_f64* P, F7 fb) {
 }
 // The goals over the joint values (goal_types.h:387-498): one out-of-line copy; x and the seed are LDS pointers that cross the
 // call with their address space spelled out.
-BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
+// x: any "one value per op" accessor (an LDS vector / column, or a child computed where it is read)
+template <class XA>
+BIOIK_DEV double goal_eval_joint_set_x(ProbPtr pb, int type, int var_op, int var_seed, double p0, const XA& x, const lds_f64* seed) {
     const int n_ops = pb->n_ops;
-    auto x = [&](int k) -> double { return xp[(size_t)k * xs]; };
     switch (type) {
         case G_AVOID_JOINT_LIMITS: {  // :387-401
             double sum = 0.0;
@@ -252,12 +255,20 @@ BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int v
     return 0.0;
 }
 
+struct LdsX {  // an op-indexed vector in LDS with its address space spelled out (crosses a call boundary)
+    const lds_f64* p;
+    int s;
+    BIOIK_DEV double operator()(int k) const { return p[(size_t)k * s]; }
+};
+BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
+    return goal_eval_joint_set_x(pb, type, var_op, var_seed, p0, LdsX{xp, xs}, seed);
+}
 BIOIK_CALL double goal_eval_joint_set(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
     return goal_eval_joint_set_inl(pb, type, var_op, var_seed, p0, xp, xs, seed);
 }
 // JS_INLINE: the goals over the joint values are inlined (the one hot site: secondary fitness of every child in the pre-selection)
-template <bool JS_INLINE = false>
-BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XV& x, const QueryCtx& qc) {
+template <bool JS_INLINE = false, class XA = XV>
+BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XA& x, const QueryCtx& qc) {
     const int n_ops = pb->n_ops;
     switch (type) {
         case G_POSITION:  // goal_types.h:96
@@ -280,9 +291,13 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
         case G_REGULARIZATION:
         case G_MINIMAL_DISPLACEMENT:
         case G_JOINT_VARIABLE:
-            if (JS_INLINE)
-                return goal_eval_joint_set_inl(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
-            return goal_eval_joint_set(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
+            if constexpr (!std::is_same<XA, XV>::value) {  // a computed accessor cannot cross a call: inline
+                return goal_eval_joint_set_x(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, x, (const lds_f64*)qc.seed);
+            } else {
+                if (JS_INLINE)
+                    return goal_eval_joint_set_inl(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
+                return goal_eval_joint_set(pb, type, var_op, var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, (const lds_f64*)x.p, x.s, (const lds_f64*)qc.seed);
+            }
         default:  // the remaining link goals
             return goal_eval_link_rare(type, (const lds_f64*)P, fb);
     }
@@ -290,20 +305,22 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
 }
 
 // Σ weight² · e over the primary link goals of one tip (problem.cpp:244-257, grouped by tip)
-BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XV& x, const QueryCtx& qc) {
+template <class XA>
+BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XA& x, const QueryCtx& qc) {
     double sum = 0.0;
     const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
     for (int g = g0; g < g1; g++)
-        sum += goal_eval(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, f, x, qc) *
+        sum += goal_eval<false, XA>(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, f, x, qc) *
                pb->primary[g].weight_sq;
     return sum;
 }
 // primary goals that read no link
-BIOIK_DEV double nonlink_primary(ProbPtr pb, const XV& x, const QueryCtx& qc) {
+template <class XA>
+BIOIK_DEV double nonlink_primary(ProbPtr pb, const XA& x, const QueryCtx& qc) {
     double sum = 0.0;
     const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     for (int g = pb->n_link_primary; g < pb->n_primary; g++)
-        sum += goal_eval(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, zero, x, qc) *
+        sum += goal_eval<false, XA>(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, zero, x, qc) *
                pb->primary[g].weight_sq;
     return sum;
 }
@@ -338,12 +355,12 @@ BIOIK_DEV double balance_cost(PB pb, const V3& acc, const QueryCtx& qc) {
     return sum;
 }
 // secondary goals see genes only; link goals marked secondary read null frames (ik_base.h:163)
-template <bool JS_INLINE = false>
-BIOIK_DEV double secondary_fitness(ProbPtr pb, const XV& x, const QueryCtx& qc) {
+template <bool JS_INLINE = false, class XA = XV>
+BIOIK_DEV double secondary_fitness(ProbPtr pb, const XA& x, const QueryCtx& qc) {
     double sum = 0.0;
     const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     for (int g = 0; g < pb->n_secondary; g++)
-        sum += goal_eval<JS_INLINE>(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
+        sum += goal_eval<JS_INLINE, XA>(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
                pb->secondary[g].weight_sq;
     return sum;
 }
@@ -401,7 +418,8 @@ BIOIK_DEV void multi_joint_prologue(ProbPtr pb, const XV& x, double* slots_of_ch
 
 // value of the joint of op k in the individual x: its own entry, or for a mimic joint factor * (entry of the joint it
 // follows) + offset (RobotFK_Fast_Base::updateMimic, forward_kinematics.h:230-246; a plain multiply and add)
-BIOIK_DEV double joint_value(const XV& x, int k, int mimic_src, double mimic_factor, double mimic_offset) {
+template <class XA>
+BIOIK_DEV double joint_value(const XA& x, int k, int mimic_src, double mimic_factor, double mimic_offset) {
     BIOIK_FP_STRICT
     double v = x(k);
     if (mimic_src >= 0) v = x(mimic_src) * mimic_factor + mimic_offset;
@@ -413,8 +431,8 @@ BIOIK_DEV double joint_value(const XV& x, int k, int mimic_src, double mimic_fac
 #endif
 //   prefix     LDS or null, [7]: the frame behind ops[0..n_prefix), which is the same for every individual of the query; the
 //              walk then starts at op n_prefix (the kernels that own a query compute it once, fk_prefix)
-template <class PB, class TipFn>
-BIOIK_DEV void fk_walk(PB pb, const XV& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
+template <class PB, class XA, class TipFn>
+BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f = f7_identity();
@@ -435,7 +453,7 @@ BIOIK_DEV void fk_walk(PB pb, const XV& x, double* slots, double* frames_out, Ti
         k_begin = pb->n_prefix;
         if (k_begin > 0) f = f7_load(prefix);
     }
-    if constexpr (pb_flavour<PB>::general) multi_joint_prologue(pb, x, slots);
+    if constexpr (pb_flavour<PB>::general && std::is_same<XA, XV>::value) multi_joint_prologue(pb, x, slots);
     for (int k0 = k_begin; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
         double xv[BIOIK_FK_BLOCK], sn[BIOIK_FK_BLOCK], cs[BIOIK_FK_BLOCK];
 #pragma unroll
@@ -516,8 +534,8 @@ BIOIK_DEV F7 fk_prefix(ProbPtr pb, const XV& x) {
     return f;
 }
 
-template <class PB>
-BIOIK_DEV double eval_exact_primary(PB pb, const XV& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
+template <class PB, class XA>
+BIOIK_DEV double eval_exact_primary(PB pb, const XA& x, const QueryCtx& qc, double* slots, const double* prefix = nullptr) {
     double sum = 0.0;
     V3 bal = v3(0.0, 0.0, 0.0);
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
@@ -676,8 +694,8 @@ struct LinModel {
 // d = 0, an exact no-op).  Where the ops meet the genes in that same order (DevProblem::genes_follow_ops: every robot without
 // floating / planar joints so far) the walk is over the ops and needs no gene -> op look-up; otherwise over op_of_gene.
 // Four entries per trip: their 4 + 4 + 28 LDS operands are requested together and waited for once; padding contributes d * 0.0.
-template <class PB>
-BIOIK_DEV F7 linear_tip(PB pb, int t, const XV& x, const LinModel& lm) {
+template <class PB, class XA>
+BIOIK_DEV F7 linear_tip(PB pb, int t, const XA& x, const LinModel& lm) {
     const int n_ops = pb->n_ops;
     const bool by_op = pb_flavour<PB>::general ? pb->genes_follow_ops != 0 : true;
     const int cnt = by_op ? n_ops : pb->D;
@@ -711,8 +729,8 @@ BIOIK_DEV F7 linear_tip(PB pb, int t, const XV& x, const LinModel& lm) {
     return F7{{px, py, pz}, {rx, ry, rz, rw}};
 }
 
-template <class PB>
-BIOIK_DEV double eval_linear_primary(PB pb, const XV& x, const QueryCtx& qc, const LinModel& lm) {
+template <class PB, class XA>
+BIOIK_DEV double eval_linear_primary(PB pb, const XA& x, const QueryCtx& qc, const LinModel& lm) {
     double sum = 0.0;
     const int T = pb->T;
     V3 bal = v3(0.0, 0.0, 0.0);
@@ -985,6 +1003,54 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
     if constexpr (pb_flavour<PB>::general)
         for (int i = 0; i < N; i++) renormalize_quaternion_genes(pb, xo[i], xs);
 }
+// A child of the current generation as a FUNCTION of (parents, counter): operator()(k) computes the value of op k where it is read --
+// the same operations, in the same order, as reproduce_children writes into a genotype column -- so a child needs no column in LDS.
+// For problems whose columns are what limits the wavefronts per CU (many joints, large populations) the launcher picks this form: every
+// gene is then hashed twice when secondary goals pre-select the children (once for the secondary fitness, once for the chain walk),
+// which costs a few dozen integer instructions per gene against 8 * n_ops bytes of LDS per lane.  Lean flavour only (no quaternion genes).
+template <class PB>
+struct ChildX {
+    PB pb;
+    const double *p0g, *p0d, *p1d;  // LDS, op-indexed: genes of parent 0, momentum of parents 0 and 1
+    uint32_t base;                  // (child << 8) * 0x9E3779B1 + stream
+    double mutation_rate, fmix, gradient_factor;
+    BIOIK_DEV double operator()(int k) const {
+        BIOIK_FP_STRICT
+        const int g = pb->ops[k].gene;
+        const double parent_gene = p0g[k];
+        if (g < 0) return parent_gene;  // inactive op: the seed's value, carried by every elite
+        const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
+        const double d0 = p0d[k], d1 = p1d[k];
+        const uint32_t word = rng_mix32(base + (uint32_t)(g + 1) * 0x9E3779B1u);
+        double r = rng_gauss32(word);
+        double f = mutation_rate * span;
+        double gn = parent_gene;
+        gn += r * f;
+        double parent_gradient = d0 * (1.0 - fmix) + d1 * fmix;
+        double g2 = parent_gradient * gradient_factor;
+        gn += g2;
+        gn = fmin(fmax(gn, cmin), cmax);
+        return gn;
+    }
+};
+template <class PB>
+BIOIK_DEV ChildX<PB> make_child_x(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d) {
+    ChildX<PB> c;
+    c.pb = pb, c.p0g = p0g, c.p0d = p0d, c.p1d = p1d;
+    c.base = (child_index << 8) * 0x9E3779B1u + rng_child_stream(key, ctr1);
+    c.mutation_rate = (double)(1u << (rng_mix32(c.base) & 15u)) * (1.0 / (double)(1 << 23));
+    c.fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
+    c.gradient_factor = (double)(child_index % 3u);
+    return c;
+}
+// the elite with ONE gene advanced by a step (the memetic phase's finite differences), read where it is needed
+struct PerturbX {
+    const double* el;
+    int op;
+    double step;
+    BIOIK_DEV double operator()(int k) const { return k == op ? el[k] + step : el[k]; }
+};
+
 template <class PB>
 BIOIK_DEV void reproduce_child(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d,
                                double* xo, int xs, double* go, int gs) {

@@ -291,20 +291,25 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (!std::getenv("BIOIK_SOLVE_THREADS") && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
     const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
     const bool manual = std::getenv("BIOIK_SOLVE_THREADS") || std::getenv("BIOIK_SOLVE_STORE_CHILDREN") || std::getenv("BIOIK_SOLVE_CHILD_PAIRS") ||
-                        std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL");
+                        std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL") || std::getenv("BIOIK_SOLVE_COLUMNLESS");
+    // children computed where they are read (no genotype columns in LDS): the lean flavour can, whenever it is chosen below
+    const bool can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !std::getenv("BIOIK_SOLVE_GENERAL");
+    sp.columnless = 0;
     if (!manual && nth == 128) {
         struct Cand {
-            int nth, store, pairs;
+            int nth, store, pairs, columnless;
         };
-        const Cand cands[] = {{128, 1, 1}, {128, 1, 0}, {128, 0, 0}, {64, 0, 0}};
+        // richest first: children kept in LDS and scored in pairs / kept / computed where they are read / one reusable column per lane
+        const Cand cands[] = {{128, 1, 1, 0}, {128, 1, 0, 0}, {128, 0, 0, 1}, {128, 0, 0, 0}, {64, 0, 0, 1}, {64, 0, 0, 0}};
         const int kCuWaves = 4 * BIOIK_SOLVE_WAVES_PER_SIMD;  // wavefronts a CU holds at this kernel's register budget
         int best = -1, best_waves = -1;
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 6; i++) {
             const Cand& c = cands[i];
             if ((c.store || c.pairs) && quat) continue;
+            if (c.columnless && !can_columnless) continue;
             if (c.pairs && sp.fk_mode != BIOIK_FK_EXACT) continue;
             const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
-            const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : 1;
+            const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : (c.columnless ? 0 : 1);
             if (c.pairs && cols < 2) continue;
             const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact);
             if (bytes > 160 * 1024) continue;
@@ -319,6 +324,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const int G_b = nth / (sp.species_parallel ? 2 : 1);
         sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
         sp.child_pairs = cands[best].pairs;
+        sp.columnless = cands[best].columnless;
     } else {
         while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2, 1, exact) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
         // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
@@ -341,15 +347,17 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
             if (std::atoi(e) == 0) sp.child_pairs = 0;
     }
+    if (const char* e = std::getenv("BIOIK_SOLVE_COLUMNLESS"))
+        if (std::atoi(e) != 0 && can_columnless) sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 0;
     const int groups = sp.species_parallel ? 2 : 1;
-    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact);
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
     if (std::getenv("BIOIK_SOLVE_REPORT")) {  // diagnostics: the lane mapping and the residency it gives
-        const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.child_cols, groups,
-                                        sp.child_pairs ? 2 : 1);
-        std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d | LDS %zu B "
+        const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
+                                        groups, sp.child_pairs ? 2 : 1);
+        std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d columnless %d | LDS %zu B "
                      "(genotype columns %d, parked frames %d, per-group %d x %d) -> %d workgroups = %d wavefronts per CU\n",
-                     dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, lds, (L.slots - L.xcol) * 8,
+                     dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, sp.columnless, lds, (L.slots - L.xcol) * 8,
                      (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(160 * 1024 / lds), (int)(160 * 1024 / lds) * (nth / 64));
     }
     if (lds > 64 * 1024) be_allow_lds(lds);

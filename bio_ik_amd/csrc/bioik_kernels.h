@@ -34,7 +34,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.prefix = o, o += 8;               // frame behind the leading non-gene joints (DevProblem::n_prefix), per query
     L.state = o, o += 2 * 8 + 4 + 4;    // species bookkeeping [2][8], workgroup broadcast slots [4], fitness / success flag of the solution [2] (+2 spare)
     L.clip = o, o += 2 * m;             // RobotInfo clip_min | clip_max per op (robot_info.h:109-113), staged once per query
-    L.xcol = o, o += m * nthreads * (child_cols > 0 ? child_cols : 1);  // genotype columns: [col][op][lane]
+    L.xcol = o, o += m * nthreads * (child_cols >= 0 ? child_cols : 1);  // genotype columns: [col][op][lane]; none when children are computed where they are read
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
     int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
     L.xn = g, g += m;
@@ -210,12 +210,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const bool has_sec = pb->n_secondary > 0;
     const bool exact = sp.fk_mode == FK_EXACT;
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
+    const bool columnless = LEAN && sp.columnless != 0;  // (the general flavour keeps its columns: quaternion genes are renormalised in place)
     // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
     const int groups = sp.species_parallel ? 2 : 1;
     const int G = nth / groups;        // lanes per species group (a multiple of 64)
     const int grp = tid / G, gtid = tid - grp * G;
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, n_cols, groups, sp.child_pairs ? 2 : 1);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, sp.child_pairs ? 2 : 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -373,8 +374,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 if (has_sec) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
                     for (int c = gtid; c < lambda; c += G) {
-                        reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
-                        s_sec[c] = secondary_fitness<true>(pb, xl, qc);
+                        if (columnless) {
+                            s_sec[c] = secondary_fitness<true>(pb, make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d), qc);
+                        } else {
+                            reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
+                            s_sec[c] = secondary_fitness<true>(pb, xl, qc);
+                        }
                     }
                     group_sync(G);
                     for (int c = gtid; c < lambda; c += G) {
@@ -397,7 +402,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 int b1p = 0x7fffffff, b2p = 0x7fffffff;
                 // every child keeps its own column until selection; not with quaternion genes: a winner's momentum is taken from the
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
-                const bool stored = n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
+                const bool stored = !columnless && n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
                 if (stored && sp.child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
@@ -416,6 +421,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         PHASE_MARK(PH_FITNESS);
                         offer(f[0], r + 2);
                         if (two) offer(f[1], r1 + 2);
+                    }
+                } else if (columnless) {
+                    for (int r = gtid; r < n_eval; r += G) {
+                        const int c = has_sec ? s_order[r] : r;
+                        const auto cx = make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d);
+                        PHASE_MARK(PH_REPRODUCE);
+                        const double f = exact ? eval_exact_primary(pb, cx, qc, s_slots, s_prefix) : eval_linear_primary(pb, cx, qc, lm);
+                        PHASE_MARK(PH_FITNESS);
+                        offer(f, r + 2);
                     }
                 } else {
                     for (int r = gtid, j = 0; r < n_eval; r += G, j++) {
@@ -513,7 +527,6 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1((uint32_t)step * 16u, (uint32_t)S.id, RNG_MEMETIC_SIGN), o0, o1);
                         if (rng_uniform(o0, o1) < 0.5) dp = -dp;
                     }
-                    const bool xgoals = pb->n_primary > pb->n_link_primary || pb->n_secondary > 0;  // goals that read the joint values
                     const bool by_op = pb_flavour<PB>::general ? pb->genes_follow_ops != 0 : true;
                     const int cnt = by_op ? n_ops : D;
                     const int my_op = gtid < D ? pb->op_of_gene[gtid] : -1;  // lane i differentiates gene i, lane D holds the elite itself
@@ -551,7 +564,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                     };
                     auto frame_of = [&](const double* fc, int t) { return f7_load(fc + t * 8); };
                     // goal fitness of the lane's frames `fc` (+ its gene's delta * step): (primary, all goals); x: what joint-value goals read
-                    auto goals_on = [&](const double* fc, int dop, double dstep, const XV& x, double& prim, double& all) {
+                    auto goals_on = [&](const double* fc, int dop, double dstep, const PerturbX& x, double& prim, double& all) {
                         double acc = 0.0;
                         V3 bal = v3(0.0, 0.0, 0.0);
                         for (int t = 0; t < T; t++) {
@@ -624,16 +637,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                             p_wave_sync();
                             PHASE_MARK(PH_MEM_SUPPORT_COLS);
                             chains(dv0, fc0, round == 1 ? dv0 + M : nullptr, fc0 + FB);
-                            XV xq = XV{round == 2 ? s_x4 : (odd ? s_xp : s_xm), 1};
-                            if (round == 0) {
-                                xq = xe;
-                                if (xgoals) {  // the lane's own vector (the elite with its gene advanced by dp), as a column
-                                    for (int k = 0; k < n_ops; k++) xcol[(size_t)k * nth] = (k == my_op) ? el[k] + dp : el[k];
-                                    xq = xl;
-                                }
-                            }
                             p_wave_sync();
                             double vprim, vall;
+                            // what joint-value goals read: the lane's own vector -- in the gradient round the elite with its gene advanced by dp
+                            // (computed where it is read, no column), else the shared support point / candidate
+                            const PerturbX xq{round == 0 ? el : (round == 2 ? s_x4 : (odd ? s_xp : s_xm)), round == 0 ? my_op : -1, round == 0 ? dp : 0.0};
                             goals_on(fc0 + ((round == 1 && odd) ? FB : 0), round == 0 ? my_op : -1, round == 0 ? dp : 0.0, xq, vprim, vall);
                             PHASE_MARK(PH_MEM_SUPPORT_EVAL);
                             if (round == 0) {

@@ -231,6 +231,10 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_GENERAL": "1"},           # the kernel flavour that also carries floating / planar joints
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1"},   # one wavefront, the species on its two halves
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "1"},        # children computed where they are read: no genotype columns in LDS
+    {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_COLUMNLESS": "1"},
+    {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_COLUMNLESS": "1"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "0", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
 ])
 def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
     """the same solve under every lane <-> work mapping the launcher can choose"""
