@@ -551,8 +551,8 @@ BIOIK_DEV double eval_exact_primary(PB pb, const XA& x, const QueryCtx& qc, doub
 // dependency chains, so that the scalar loads of a joint's constants, the LDS reads of the gene values and the latency of the
 // polynomial chains are paid once per joint instead of once per joint and child.  Arithmetic per individual is identical
 // to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
-template <int N, class PB, class TipFn>
-BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
+template <int N, class PB, class XA, class TipFn>
+BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f[N];
@@ -580,7 +580,7 @@ BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_st
             for (int j = 0; j < N; j++) f[j] = f0;
         }
     }
-    if constexpr (pb_flavour<PB>::general)
+    if constexpr (pb_flavour<PB>::general && std::is_same<XA, XV>::value)
         for (int j = 0; j < N; j++) multi_joint_prologue(pb, x[j], slots + (size_t)j * slot_set_stride);
     for (int k = k_begin; k < n_chain; k++) {
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
@@ -655,8 +655,8 @@ BIOIK_DEV void fk_walk_n(PB pb, const XV (&x)[N], double* slots, int slot_set_st
         }
     }
 }
-template <int N, class PB>
-BIOIK_DEV void eval_exact_primary_n(PB pb, const XV (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
+template <int N, class PB, class XA>
+BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
                                     const double* prefix = nullptr) {
     V3 bal[N];
 #pragma unroll
@@ -671,7 +671,7 @@ BIOIK_DEV void eval_exact_primary_n(PB pb, const XV (&x)[N], const QueryCtx& qc,
             const double w = pb->primary[g].weight_sq;
             const double* P = qc.par + po;
 #pragma unroll
-            for (int j = 0; j < N; j++) out[j] += goal_eval(pb, type, var_op, var_seed, P, f[j], x[j], qc) * w;
+            for (int j = 0; j < N; j++) out[j] += goal_eval<false, XA>(pb, type, var_op, var_seed, P, f[j], x[j], qc) * w;
         }
     }, prefix);
 #pragma unroll

@@ -300,17 +300,19 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             int nth, store, pairs, columnless;
         };
         // richest first: children kept in LDS and scored in pairs / kept / computed where they are read / one reusable column per lane
-        const Cand cands[] = {{128, 1, 1, 0}, {128, 1, 0, 0}, {128, 0, 0, 1}, {128, 0, 0, 0}, {64, 0, 0, 1}, {64, 0, 0, 0}};
+        const Cand cands[] = {{128, 1, 1, 0}, {128, 1, 0, 0}, {128, 0, 1, 1}, {128, 0, 0, 1}, {128, 0, 0, 0}, {64, 0, 1, 1}, {64, 0, 0, 1}, {64, 0, 0, 0}};
         const int kCuWaves = 4 * BIOIK_SOLVE_WAVES_PER_SIMD;  // wavefronts a CU holds at this kernel's register budget
         int best = -1, best_waves = -1;
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 8; i++) {
             const Cand& c = cands[i];
             if ((c.store || c.pairs) && quat) continue;
             if (c.columnless && !can_columnless) continue;
             if (c.pairs && sp.fk_mode != BIOIK_FK_EXACT) continue;
             const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
             const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : (c.columnless ? 0 : 1);
-            if (c.pairs && cols < 2) continue;
+            if (c.pairs && !c.columnless && cols < 2) continue;
+            // (computed children in pairs: measured +1.5 % with eight children per lane and generation (C4), -4 % with two (C3))
+            if (c.pairs && c.columnless && sp.lambda < 4 * G_c) continue;
             const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact);
             if (bytes > 160 * 1024) continue;
             int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
@@ -348,7 +350,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             if (std::atoi(e) == 0) sp.child_pairs = 0;
     }
     if (const char* e = std::getenv("BIOIK_SOLVE_COLUMNLESS"))
-        if (std::atoi(e) != 0 && can_columnless) sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 0;
+        if (std::atoi(e) != 0 && can_columnless) {
+            sp.columnless = 1, sp.child_cols = 1;
+            sp.child_pairs = (std::atoi(e) == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
+        }
     const int groups = sp.species_parallel ? 2 : 1;
     const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");

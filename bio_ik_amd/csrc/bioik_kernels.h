@@ -422,6 +422,22 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
                         offer(f[0], r + 2);
                         if (two) offer(f[1], r1 + 2);
                     }
+                } else if (columnless && sp.child_pairs && exact) {
+                    // two children per trip, both computed where they are read: two independent dependency chains per lane
+                    for (int r = gtid; r < n_eval; r += 2 * G) {
+                        const int r1 = r + G;
+                        const bool two = r1 < n_eval;
+                        const int c0 = has_sec ? s_order[r] : r;
+                        const int c1 = two ? (has_sec ? s_order[r1] : r1) : c0;
+                        const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1, (uint32_t)c0 + 2u, p0g, p0d, p1d),
+                                                  make_child_x(pb, key, ctr1, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
+                        PHASE_MARK(PH_REPRODUCE);
+                        double f[2];
+                        eval_exact_primary_n<2>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                        PHASE_MARK(PH_FITNESS);
+                        offer(f[0], r + 2);
+                        if (two) offer(f[1], r1 + 2);
+                    }
                 } else if (columnless) {
                     for (int r = gtid; r < n_eval; r += G) {
                         const int c = has_sec ? s_order[r] : r;

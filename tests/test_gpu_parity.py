@@ -233,6 +233,7 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "1"},        # children computed where they are read: no genotype columns in LDS
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_COLUMNLESS": "1"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "2"},       # ... and scored two at a time
     {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_COLUMNLESS": "1"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "0", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
 ])

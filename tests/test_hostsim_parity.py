@@ -77,6 +77,7 @@ def test_trajectory_two_wavefronts_and_islands(sims, oracles, templates, monkeyp
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "1"},       # children computed where they are read: no genotype columns in LDS
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_COLUMNLESS": "1"},
+    {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "2"},       # ... and scored two at a time
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "0", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
 ])
 def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, env):
