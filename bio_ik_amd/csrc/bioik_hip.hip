@@ -107,6 +107,11 @@ __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean(
     extern __shared__ double lds[];
     solve_body<true>(a, blockIdx.x, lds);
 }
+// the lean flavour with the children computed where they are read (no genotype columns in LDS: the LDS-bound problems, C3 / C4)
+__global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_cl(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true>(a, blockIdx.x, lds);
+}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -148,6 +153,7 @@ __global__ void __launch_bounds__(256) k_stream_fitness(StreamArgs a) {
 static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -403,7 +409,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         a.success = (int32_t*)w, w += units * 4;
         a.steps = (int32_t*)w;
     }
-    if (lean)
+    if (lean && sp.columnless)
+        LAUNCH(k_solve_lean_cl, (solve_body<true, true>(a, b_, l_)), units, nth, lds, stream, a);
+    else if (lean)
         LAUNCH(k_solve_lean, solve_body<true>(a, b_, l_), units, nth, lds, stream, a);
     else
         LAUNCH(k_solve, solve_body<false>(a, b_, l_), units, nth, lds, stream, a);

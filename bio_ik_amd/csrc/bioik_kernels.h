@@ -197,9 +197,13 @@ struct SpeciesState {
     int ok;           // success test of the first elite (it is what becomes the solution when the species leads)
 };
 
-// LEAN: the flavour without floating / planar joints (see pb_flavour); the launcher picks it whenever the problem allows
-template <bool LEAN>
+// LEAN: the flavour without floating / planar joints (see pb_flavour); the launcher picks it whenever the problem allows.
+// CL: children computed where they are read (no genotype columns, sp.columnless) — a kernel of its own, so that the accessor-templated
+// copies of the chain walk do not weigh on the register allocation of the column kernels (with both in one kernel the lean flavour
+// spilled 74 instead of 32 VGPRs and lost 4 % on C2)
+template <bool LEAN, bool CL = false>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
+    static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
@@ -210,7 +214,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const bool has_sec = pb->n_secondary > 0;
     const bool exact = sp.fk_mode == FK_EXACT;
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
-    const bool columnless = LEAN && sp.columnless != 0;  // (the general flavour keeps its columns: quaternion genes are renormalised in place)
+    constexpr bool columnless = CL;
     // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
     const int groups = sp.species_parallel ? 2 : 1;

@@ -23,6 +23,13 @@ summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format
                                             "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; the rest is scratch traffic (register spills of cold paths)."}}
 json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
 json.dump({"k_solve_hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "source": "profiles/%s_pmc_k_solve.json" % rnd}, open(os.path.join(p, "traffic.json"), "w"), indent=1)
+# bench.py reads `roofline.traffic` from profiles/traffic.json as it was BEFORE this session's PMC passes ran; the copy kept under
+# profiles/ carries the figure of its own session (same library, same box), with the value the line was printed with beside it
+b = json.load(open(os.path.join(p, rnd + "_bench.json")))
+if isinstance(b.get("roofline"), dict):
+    b["roofline"]["traffic_as_printed"] = b["roofline"].get("traffic")
+    b["roofline"]["traffic"] = 2 * fk * 1024 + wk * 1024
+    json.dump(b, open(os.path.join(p, rnd + "_bench.json"), "w"))
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
     print(k, "%.4g" % out[k]["mean_per_launch"])
 print("hbm bytes/launch %.4g" % summary["hbm_bytes_per_launch"]["total_corrected"], out["dispatch"])

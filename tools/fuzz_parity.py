@@ -44,7 +44,7 @@ def main():
     for case in range(n_cases):
         name = rng.choice(list(T))
         t, h, o = T[name], H[name], O[name]
-        pop = int(rng.choice([8, 16, 24, 33, 64, 70, 128, 200]))
+        pop = int(rng.choice([8, 16, 24, 33, 64, 70, 128, 200, 512]))
         mode = str(rng.choice(["bio2", "bio2_memetic", "bio2_memetic_l"]))
         fk = int(rng.choice([abi.FK_EXACT, abi.FK_LINEAR]))
         if name in ("floating", "planar") and mode != "bio2":
@@ -67,6 +67,8 @@ def main():
             env = {"BIOIK_SOLVE_GENERAL": "1"}
         if rng.random() < 0.2:
             env["BIOIK_SOLVE_STORE_CHILDREN"] = "0"
+        elif rng.random() < 0.35 and "BIOIK_SOLVE_GENERAL" not in env:  # children computed where they are read (round 2), singly or in pairs
+            env["BIOIK_SOLVE_COLUMNLESS"] = str(rng.choice(["1", "2"]))
         kw = {"no_wipeout": int(rng.random() < 0.2)}
         seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=int(rng.integers(1 << 30)), kind=str(rng.choice(["global", "tracking"])))
         p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=int(rng.integers(1 << 30)), mode=mode, fk_mode=fk, islands=islands, **kw)
