@@ -90,8 +90,8 @@ public:
             if (l < 0) throw std::runtime_error(base + " is not an ancestor of " + tip);
             links.insert(links.begin(), l);
         }
-        for (int l : links)
-            if (joint_type[l] != BIOIK_JOINT_FIXED) g.active_joints.push_back(l);
+        for (int l : links)  // JointModelGroup::getActiveJointModels: neither fixed nor mimic joints
+            if (joint_type[l] != BIOIK_JOINT_FIXED && joint_mimic[l] < 0) g.active_joints.push_back(l);
         g.tips.push_back(linkIndex(tip));
         groups[name] = g;
     }

@@ -1,0 +1,343 @@
+// bio_ik/urdf.h — URDF / SRDF text -> bio_ik::RobotModel, for hosts that run the solver without MoveIt (with MoveIt the plugin TU
+// src/kinematics_plugin_hip.cpp fills the same arrays from moveit::core::RobotModel).
+//
+// What the reference gets from moveit::core::RobotModel / JointModelGroup (src/forward_kinematics.h:192-213,
+// include/bio_ik/robot_info.h:70-106, src/kinematics_plugin.cpp:167-189) is built from the robot description itself, with the same
+// conventions as the Python reader (bio_ik_amd/urdf.py; tests/test_cpp_urdf.py holds the two against each other):
+//   * links in the order RobotModel::buildRecursive visits them (depth first from the root, children in file order), so link and
+//     variable indices match a MoveIt-loaded model of the same URDF;
+//   * joints: fixed | revolute | continuous | prismatic, <origin xyz rpy>, <axis> (URDF default 1 0 0), <limit lower upper velocity>,
+//     <mimic joint multiplier offset> (the followed joint may come later in the file); <inertial> mass and origin (BalanceGoal);
+//   * SRDF <group>: <chain base_link tip_link>, <joint name>, <link name> (= its parent joint), nested <group name>; <end_effector
+//     parent_link parent_group> names the tips of a group without a chain; a fixed <virtual_joint> puts `parent_frame` in front of the root.
+// Not read: collision / visual geometry, transmissions, xacro; floating / planar joints (URDF or virtual) are refused here — the C-ABI
+// takes them (include/bioik_hip.h), this flat C++ model does not describe multi-variable joints.
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <set>
+#include <sstream>
+
+#include "robot_model.h"
+
+namespace bio_ik {
+namespace urdf_detail {
+
+struct XmlNode {
+    std::string tag;
+    std::vector<std::pair<std::string, std::string>> attributes;
+    std::vector<XmlNode> children;
+    const std::string* find(const std::string& name) const {
+        for (auto& a : attributes)
+            if (a.first == name) return &a.second;
+        return nullptr;
+    }
+    std::string get(const std::string& name, const std::string& fallback = "") const {
+        const std::string* v = find(name);
+        return v ? *v : fallback;
+    }
+    const XmlNode* child(const std::string& t) const {
+        for (auto& c : children)
+            if (c.tag == t) return &c;
+        return nullptr;
+    }
+    std::vector<const XmlNode*> all(const std::string& t) const {
+        std::vector<const XmlNode*> out;
+        for (auto& c : children)
+            if (c.tag == t) out.push_back(&c);
+        return out;
+    }
+};
+
+// elements and attributes only (what a robot description consists of): prolog, comments, CDATA and text are skipped
+class XmlReader {
+    const std::string& s;
+    size_t i = 0;
+    [[noreturn]] void fail(const std::string& what) const { throw std::runtime_error("XML: " + what + " at offset " + std::to_string(i)); }
+    static std::string decode(const std::string& v) {
+        std::string o;
+        for (size_t k = 0; k < v.size(); k++) {
+            if (v[k] != '&') {
+                o += v[k];
+                continue;
+            }
+            static const std::pair<const char*, char> ent[] = {{"&lt;", '<'}, {"&gt;", '>'}, {"&amp;", '&'}, {"&quot;", '"'}, {"&apos;", '\''}};
+            bool hit = false;
+            for (auto& e : ent)
+                if (v.compare(k, std::char_traits<char>::length(e.first), e.first) == 0) {
+                    o += e.second, k += std::char_traits<char>::length(e.first) - 1, hit = true;
+                    break;
+                }
+            if (!hit) o += v[k];
+        }
+        return o;
+    }
+    void skipSpace() {
+        while (i < s.size() && std::isspace((unsigned char)s[i])) i++;
+    }
+    bool skipMisc() {  // <?...?>, <!--...-->, <![CDATA[...]]>, <!DOCTYPE...>, text: true when positioned at an element's '<' or at the end
+        for (;;) {
+            while (i < s.size() && s[i] != '<') i++;
+            if (i >= s.size()) return false;
+            if (s.compare(i, 4, "<!--") == 0) {
+                size_t e = s.find("-->", i + 4);
+                if (e == std::string::npos) fail("unterminated comment");
+                i = e + 3;
+            } else if (s.compare(i, 9, "<![CDATA[") == 0) {
+                size_t e = s.find("]]>", i + 9);
+                if (e == std::string::npos) fail("unterminated CDATA");
+                i = e + 3;
+            } else if (s.compare(i, 2, "<?") == 0) {
+                size_t e = s.find("?>", i + 2);
+                if (e == std::string::npos) fail("unterminated processing instruction");
+                i = e + 2;
+            } else if (s.compare(i, 2, "<!") == 0) {
+                size_t e = s.find('>', i + 2);
+                if (e == std::string::npos) fail("unterminated declaration");
+                i = e + 1;
+            } else {
+                return true;
+            }
+        }
+    }
+    std::string name() {
+        size_t b = i;
+        while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-' || s[i] == ':' || s[i] == '.')) i++;
+        if (i == b) fail("name expected");
+        return s.substr(b, i - b);
+    }
+    XmlNode element() {  // at '<' of a start tag
+        i++;
+        XmlNode n;
+        n.tag = name();
+        for (;;) {
+            skipSpace();
+            if (i >= s.size()) fail("unterminated tag <" + n.tag);
+            if (s[i] == '/') {
+                if (i + 1 >= s.size() || s[i + 1] != '>') fail("'/>' expected");
+                i += 2;
+                return n;
+            }
+            if (s[i] == '>') {
+                i++;
+                break;
+            }
+            std::string key = name();
+            skipSpace();
+            if (i >= s.size() || s[i] != '=') fail("'=' expected after attribute " + key);
+            i++;
+            skipSpace();
+            if (i >= s.size() || (s[i] != '"' && s[i] != '\'')) fail("quoted value expected for attribute " + key);
+            const char q = s[i++];
+            size_t e = s.find(q, i);
+            if (e == std::string::npos) fail("unterminated value of attribute " + key);
+            n.attributes.emplace_back(key, decode(s.substr(i, e - i)));
+            i = e + 1;
+        }
+        for (;;) {  // content
+            if (!skipMisc()) fail("missing </" + n.tag + ">");
+            if (s.compare(i, 2, "</") == 0) {
+                i += 2;
+                if (name() != n.tag) fail("mismatched end tag, <" + n.tag + "> is open");
+                skipSpace();
+                if (i >= s.size() || s[i] != '>') fail("'>' expected");
+                i++;
+                return n;
+            }
+            n.children.push_back(element());
+        }
+    }
+
+public:
+    explicit XmlReader(const std::string& text) : s(text) {}
+    XmlNode root() {
+        if (!skipMisc()) fail("no root element");
+        return element();
+    }
+};
+
+inline std::vector<double> numbers(const std::string* text, size_t n, std::initializer_list<double> fallback) {
+    if (!text) return std::vector<double>(fallback);
+    std::vector<double> v;
+    std::istringstream in(*text);
+    std::string tok;
+    while (in >> tok) {
+        char* end = nullptr;
+        v.push_back(std::strtod(tok.c_str(), &end));
+        if (end == tok.c_str() || *end) throw std::runtime_error("not a number: '" + tok + "'");
+    }
+    if (v.size() != n) throw std::runtime_error("expected " + std::to_string(n) + " numbers, got '" + *text + "'");
+    return v;
+}
+inline double number(const XmlNode* n, const std::string& attribute, double fallback) {
+    if (!n || !n->find(attribute)) return fallback;
+    return numbers(n->find(attribute), 1, {fallback})[0];
+}
+
+struct UrdfJoint {
+    std::string name, type, parent, child, mimic;
+    std::vector<double> xyz, rpy, axis;
+    double lower = 0, upper = 0, velocity = 0, mimic_factor = 1, mimic_offset = 0;
+};
+
+}  // namespace urdf_detail
+
+// SRDF groups (and nothing else of the SRDF) onto an existing model; joints in model order, fixed and mimic joints are not active
+// (JointModelGroup::getActiveJointModels)
+inline void addSRDFGroups(RobotModel& m, const std::string& srdf_xml) {
+    using namespace urdf_detail;
+    const XmlNode s = XmlReader(srdf_xml).root();
+    std::vector<const XmlNode*> order;
+    std::map<std::string, const XmlNode*> raw;
+    for (const XmlNode* g : s.all("group"))
+        if (!g->children.empty()) raw[g->get("name")] = g, order.push_back(g);  // (<group name=".."/> inside a group is a reference)
+    struct Members {
+        std::vector<int> joints;
+        std::vector<std::string> tips;
+    };
+    std::function<Members(const std::string&, std::vector<std::string>)> members = [&](const std::string& name, std::vector<std::string> seen) {
+        if (std::find(seen.begin(), seen.end(), name) != seen.end()) throw std::runtime_error("SRDF groups include each other: " + name);
+        auto it = raw.find(name);
+        if (it == raw.end()) throw std::runtime_error("SRDF: unknown group " + name);
+        seen.push_back(name);
+        Members out;
+        for (const XmlNode& c : it->second->children) {
+            if (c.tag == "chain") {
+                const int b = m.linkIndex(c.get("base_link"));
+                out.tips.push_back(c.get("tip_link"));
+                for (int l = m.linkIndex(c.get("tip_link")); l != b; l = m.link_parent[l]) {
+                    if (l < 0) throw std::runtime_error("group " + name + ": " + c.get("base_link") + " is not an ancestor of " + c.get("tip_link"));
+                    out.joints.push_back(l);
+                }
+            } else if (c.tag == "joint") {
+                out.joints.push_back(m.jointIndex(c.get("name")));
+            } else if (c.tag == "link") {
+                out.joints.push_back(m.linkIndex(c.get("name")));  // the link's parent joint
+            } else if (c.tag == "group") {
+                const Members sub = members(c.get("name"), seen);
+                out.joints.insert(out.joints.end(), sub.joints.begin(), sub.joints.end());
+                out.tips.insert(out.tips.end(), sub.tips.begin(), sub.tips.end());
+            }
+        }
+        return out;
+    };
+    for (const XmlNode* g : order) {
+        const std::string name = g->get("name");
+        Members mem = members(name, {});
+        std::set<int> unique;
+        for (int i : mem.joints)
+            if (m.link_parent[i] >= 0) unique.insert(i);
+        std::vector<std::string> tips = mem.tips;
+        if (tips.empty())
+            for (const XmlNode* e : s.all("end_effector"))
+                if (e->get("parent_group") == name) tips.push_back(e->get("parent_link"));
+        if (tips.empty()) {  // leaves of the group's joint set
+            std::set<int> inner;
+            for (int i : unique) inner.insert(m.link_parent[i]);
+            for (int i : unique)
+                if (!inner.count(i)) tips.push_back(m.link_names[i]);
+        }
+        JointModelGroup grp;
+        grp.name = name;
+        for (int i : unique)
+            if (m.joint_type[i] != BIOIK_JOINT_FIXED && m.joint_mimic[i] < 0) grp.active_joints.push_back(i);
+        for (auto& t : tips) grp.tips.push_back(m.linkIndex(t));
+        m.groups[name] = grp;
+    }
+}
+
+// urdf_xml / srdf_xml: XML text (not file names)
+inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const std::string& srdf_xml = "") {
+    using namespace urdf_detail;
+    const XmlNode root = XmlReader(urdf_xml).root();
+    if (root.tag != "robot") throw std::runtime_error("not a URDF: root element is <" + root.tag + ">");
+    std::vector<std::string> links;
+    for (const XmlNode* l : root.all("link")) links.push_back(l->get("name"));
+    auto known = [&](const std::string& l) { return std::find(links.begin(), links.end(), l) != links.end(); };
+    std::vector<UrdfJoint> joints;
+    for (const XmlNode* j : root.all("joint")) {
+        UrdfJoint u;
+        u.name = j->get("name"), u.type = j->get("type");
+        if (u.type == "floating" || u.type == "planar") throw std::runtime_error("joint " + u.name + ": " + u.type + " joints are not described by this C++ model (use the C-ABI arrays)");
+        if (u.type != "fixed" && u.type != "revolute" && u.type != "continuous" && u.type != "prismatic")
+            throw std::runtime_error("joint " + u.name + ": unsupported type " + u.type);
+        if (!j->child("parent") || !j->child("child")) throw std::runtime_error("joint " + u.name + ": <parent> / <child> missing");
+        u.parent = j->child("parent")->get("link"), u.child = j->child("child")->get("link");
+        const XmlNode *o = j->child("origin"), *lim = j->child("limit"), *ax = j->child("axis"), *mim = j->child("mimic");
+        u.xyz = numbers(o ? o->find("xyz") : nullptr, 3, {0, 0, 0});
+        u.rpy = numbers(o ? o->find("rpy") : nullptr, 3, {0, 0, 0});
+        u.axis = numbers(ax ? ax->find("xyz") : nullptr, 3, {1, 0, 0});
+        u.lower = number(lim, "lower", 0.0), u.upper = number(lim, "upper", 0.0), u.velocity = number(lim, "velocity", 0.0);
+        if (mim) u.mimic = mim->get("joint"), u.mimic_factor = number(mim, "multiplier", 1.0), u.mimic_offset = number(mim, "offset", 0.0);
+        joints.push_back(u);
+    }
+    std::map<std::string, std::vector<const UrdfJoint*>> children;
+    std::set<std::string> is_child;
+    for (const UrdfJoint& j : joints) {
+        if (!known(j.parent) || !known(j.child)) throw std::runtime_error("joint " + j.name + " references an unknown link");
+        children[j.parent].push_back(&j);
+        if (!is_child.insert(j.child).second) throw std::runtime_error("link " + j.child + " has two parent joints");
+    }
+    std::vector<std::string> roots;
+    for (auto& l : links)
+        if (!is_child.count(l)) roots.push_back(l);
+    if (roots.size() != 1) throw std::runtime_error("a URDF tree has exactly one root link, found " + std::to_string(roots.size()));
+    auto m = std::make_shared<RobotModel>();
+    const double zero[3] = {0, 0, 0}, z_axis[3] = {0, 0, 1};
+    const XmlNode* virt = nullptr;
+    XmlNode srdf;
+    if (!srdf_xml.empty()) {
+        srdf = XmlReader(srdf_xml).root();
+        const auto vj = srdf.all("virtual_joint");
+        if (vj.size() > 1) throw std::runtime_error("more than one <virtual_joint>");
+        if (!vj.empty()) {
+            virt = vj[0];
+            if (virt->get("child_link") != roots[0]) throw std::runtime_error("<virtual_joint> child_link " + virt->get("child_link") + " is not the root link " + roots[0]);
+            if (virt->get("type") != "fixed") throw std::runtime_error("<virtual_joint> type " + virt->get("type") + ": only fixed in this C++ model");
+        }
+    }
+    if (virt) {
+        m->addLink(virt->get("parent_frame"), "", "", "fixed", zero, zero, z_axis);
+        m->addLink(roots[0], virt->get("parent_frame"), virt->get("name"), "fixed", zero, zero, z_axis);
+    } else {
+        m->addLink(roots[0], "", "", "fixed", zero, zero, z_axis);
+    }
+    std::vector<std::pair<const std::vector<const UrdfJoint*>*, size_t>> stack;  // depth first, children in file order
+    static const std::vector<const UrdfJoint*> none;
+    auto kids = [&](const std::string& l) -> const std::vector<const UrdfJoint*>* {
+        auto it = children.find(l);
+        return it == children.end() ? &none : &it->second;
+    };
+    stack.emplace_back(kids(roots[0]), 0);
+    while (!stack.empty()) {
+        auto& top = stack.back();
+        if (top.second >= top.first->size()) {
+            stack.pop_back();
+            continue;
+        }
+        const UrdfJoint& j = *(*top.first)[top.second++];
+        const double xyz[3] = {j.xyz[0], j.xyz[1], j.xyz[2]}, rpy[3] = {j.rpy[0], j.rpy[1], j.rpy[2]}, axis[3] = {j.axis[0], j.axis[1], j.axis[2]};
+        m->addLink(j.child, j.parent, j.name, j.type, xyz, rpy, axis, j.lower, j.upper, j.velocity);
+        stack.emplace_back(kids(j.child), 0);
+    }
+    for (const UrdfJoint& j : joints)
+        if (!j.mimic.empty()) {
+            const int i = m->jointIndex(j.name);
+            m->joint_mimic[i] = m->jointIndex(j.mimic);  // throws for an unknown joint
+            m->joint_mimic_factor[i] = j.mimic_factor, m->joint_mimic_offset[i] = j.mimic_offset;
+        }
+    for (const XmlNode* l : root.all("link")) {
+        const XmlNode* ine = l->child("inertial");
+        if (!ine || !ine->child("mass")) continue;
+        const XmlNode* o = ine->child("origin");
+        const std::vector<double> c = numbers(o ? o->find("xyz") : nullptr, 3, {0, 0, 0});
+        m->setInertial(l->get("name"), number(ine->child("mass"), "value", 0.0), c[0], c[1], c[2]);
+    }
+    if (!srdf_xml.empty()) addSRDFGroups(*m, srdf_xml);
+    return m;
+}
+
+}  // namespace bio_ik

@@ -1,0 +1,117 @@
+// C++ driver of bio_ik/urdf.h: loads a URDF (+ SRDF) from files and prints the flat model in a canonical text form that
+// tests/test_cpp_urdf.py compares with what the Python reader (bio_ik_amd/urdf.py) builds from the same text; with a third argument
+// (group name) and a fourth (tip link) it also solves one FK -> IK -> FK round trip through the plugin mirror on the loaded model.
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include <bio_ik/kinematics_plugin.h>
+#include <bio_ik/urdf.h>
+
+#ifndef TEST_TIMEOUT
+#define TEST_TIMEOUT 0.25
+#endif
+
+static std::string slurp(const char* path) {
+    std::ifstream f(path);
+    std::stringstream s;
+    s << f.rdbuf();
+    return s.str();
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--errors") {  // malformed descriptions are refused with an exception, never a crash
+        const char* bad[] = {"<robot><link name='a'/><link name='b'/></robot>",
+                             "<robot><link name='a'/><link name='b'/><joint name='j' type='screw'><parent link='a'/><child link='b'/></joint></robot>",
+                             "<robot><link name='a'/><joint name='j' type='fixed'><parent link='a'/><child link='zz'/></joint></robot>",
+                             "<robot><link name='a'></robot>", "<notarobot/>", "<robot><link name='a'/><link name=b/></robot>"};
+        for (const char* text : bad) {
+            try {
+                bio_ik::loadURDF(text);
+                std::printf("accepted: %s\n", text);
+                return 1;
+            } catch (const std::exception&) {
+            }
+        }
+        std::printf("ok\n");
+        return 0;
+    }
+    std::shared_ptr<bio_ik::RobotModel> m;
+    try {
+        m = bio_ik::loadURDF(slurp(argv[1]), argc > 2 ? slurp(argv[2]) : std::string());
+    } catch (const std::exception& e) {
+        std::printf("exception: %s\n", e.what());
+        return 1;
+    }
+    const size_t L = m->link_names.size();
+    for (size_t i = 0; i < L; i++) {
+        std::printf("link %s joint %s parent %d type %d first_variable %d mimic %d %.17g %.17g origin", m->link_names[i].c_str(), m->joint_names[i].c_str(), m->link_parent[i],
+                    m->joint_type[i], m->joint_first_variable[i], m->joint_mimic[i], m->joint_mimic_factor[i], m->joint_mimic_offset[i]);
+        for (int c = 0; c < 7; c++) std::printf(" %.17g", m->link_origin[7 * i + c]);
+        std::printf(" axis");
+        for (int c = 0; c < 3; c++) std::printf(" %.17g", m->joint_axis[3 * i + c]);
+        std::printf(" mass %.17g", m->link_mass.size() == L ? m->link_mass[i] : 0.0);
+        for (int c = 0; c < 3; c++) std::printf(" %.17g", m->link_center.size() == 3 * L ? m->link_center[3 * i + c] : 0.0);
+        std::printf("\n");
+    }
+    for (size_t v = 0; v < m->variable_names.size(); v++)
+        std::printf("variable %s %.17g %.17g bounded %d velocity %.17g\n", m->variable_names[v].c_str(), m->var_min[v], m->var_max[v], (int)m->var_bounded[v], m->var_max_velocity[v]);
+    for (auto& g : m->groups) {
+        std::printf("group %s joints", g.first.c_str());
+        for (int j : g.second.active_joints) std::printf(" %s", m->joint_names[j].c_str());
+        std::printf(" tips");
+        for (int t : g.second.tips) std::printf(" %s", m->link_names[t].c_str());
+        std::printf("\n");
+    }
+    if (argc > 4) {  // one solve on the loaded model
+        using namespace bio_ik_kinematics_plugin;
+        BioIKKinematicsPlugin plugin;
+        BioIKParams params;
+        params.gpu_population = 32, params.gpu_max_steps = 64, params.random_seed = 2;
+        const std::string group = argv[3], tip = argv[4];
+        const bio_ik::JointModelGroup& g = m->groups.at(group);
+        const std::string base = m->link_names[0];
+        if (!plugin.initialize(*m, group, base, {tip}, 0.0, params)) {
+            std::printf("initialize failed\n");
+            return 1;
+        }
+        std::vector<double> target = m->defaultPositions();
+        for (size_t k = 0; k < g.active_joints.size(); k++) {
+            const int v = m->joint_first_variable[g.active_joints[k]];
+            target[v] = m->var_min[v] + (m->var_max[v] - m->var_min[v]) * (0.3 + 0.05 * (double)k);
+        }
+        for (size_t l = 0; l < L; l++)  // mimic joints follow
+            if (m->joint_mimic[l] >= 0 && m->joint_first_variable[l] >= 0)
+                target[m->joint_first_variable[l]] = target[m->joint_first_variable[m->joint_mimic[l]]] * m->joint_mimic_factor[l] + m->joint_mimic_offset[l];
+        double f[7];
+        m->linkTransform(m->linkIndex(tip), target, f);
+        geometry_msgs::Pose pose;
+        pose.position.x = f[0], pose.position.y = f[1], pose.position.z = f[2];
+        pose.orientation.x = f[3], pose.orientation.y = f[4], pose.orientation.z = f[5], pose.orientation.w = f[6];
+        std::vector<double> seed(plugin.getJointNames().size(), 0.0), solution;
+        for (size_t k = 0; k < seed.size(); k++) {
+            const int v = m->variableIndex(plugin.getJointNames()[k]);
+            seed[k] = m->defaultPositions()[v];
+        }
+        moveit_msgs::MoveItErrorCodes err;
+        const bool ok = plugin.searchPositionIK(pose, seed, TEST_TIMEOUT, solution, err);
+        if (!ok) {
+            std::printf("solve failed (%d)\n", err.val);
+            return 1;
+        }
+        std::vector<double> reached = m->defaultPositions();
+        for (size_t k = 0; k < solution.size(); k++) reached[m->variableIndex(plugin.getJointNames()[k])] = solution[k];
+        for (size_t l = 0; l < L; l++)
+            if (m->joint_mimic[l] >= 0 && m->joint_first_variable[l] >= 0)
+                reached[m->joint_first_variable[l]] = reached[m->joint_first_variable[m->joint_mimic[l]]] * m->joint_mimic_factor[l] + m->joint_mimic_offset[l];
+        double r[7];
+        m->linkTransform(m->linkIndex(tip), reached, r);
+        double dp = 0;
+        for (int c = 0; c < 3; c++) dp = std::max(dp, std::fabs(r[c] - f[c]));
+        std::printf("solve position error %.3g\n", dp);
+        if (!(dp < 1e-4)) return 1;
+    }
+    std::printf("ok\n");
+    return 0;
+}

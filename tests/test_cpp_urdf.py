@@ -1,0 +1,79 @@
+"""bio_ik/urdf.h (the C++ URDF / SRDF reader of the host-side mirror): the model it builds equals, field by field, the one the Python
+reader builds from the same text (link order, variables, mimic joints declared before the joint they follow, inertials, SRDF chains /
+joint lists / link lists / nested groups / end effectors, a fixed virtual joint), malformed descriptions raise, and a model loaded
+this way solves through the plugin mirror (host simulator in the CPU suite, the HIP library on a GPU box)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bio_ik_amd import abi
+from bio_ik_amd.urdf import load_urdf
+from test_urdf import SRDF, URDF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+URDF_MASS = URDF.replace('<link name="l1"/>', '<link name="l1"><inertial><origin xyz="0.01 0 0.1"/><mass value="2.5"/><inertia ixx="1"/></inertial></link>') \
+                .replace('<link name="tool"/>', '<!-- the tool --><link name="tool"><inertial><mass value="0.4"/></inertial><visual><geometry><box size="1 1 1"/></geometry></visual></link>')
+SRDF_FIXED_BASE = SRDF.replace('<group name="arm_chain">', "<virtual_joint name='world_joint' type='fixed' parent_frame='world' child_link='base'/><group name=\"arm_chain\">")
+
+
+def build(libdir, libname, tmp_path, timeout_s=None):
+    exe = str(tmp_path / "test_urdf")
+    cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s] if timeout_s else []) + [
+        "-I", os.path.join(ROOT, "bio_ik_amd", "cpp"), os.path.join(ROOT, "tests", "cpp", "test_urdf.cpp"),
+        "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread", "-o", exe]
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def dump(exe, tmp_path, urdf, srdf, *more):
+    (tmp_path / "robot.urdf").write_text(urdf)
+    (tmp_path / "robot.srdf").write_text(srdf)
+    r = subprocess.run([exe, str(tmp_path / "robot.urdf"), str(tmp_path / "robot.srdf"), *more], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    return r.stdout.strip().split("\n")
+
+
+def compare(lines, m):
+    links = [l.split() for l in lines if l.startswith("link ")]
+    variables = [l.split() for l in lines if l.startswith("variable ")]
+    groups = [l.split() for l in lines if l.startswith("group ")]
+    assert [l[1] for l in links] == m.link_names and [l[3] for l in links] == m.joint_names
+    assert [int(l[5]) for l in links] == list(m.link_parent) and [int(l[7]) for l in links] == list(m.joint_type)
+    assert [int(l[9]) for l in links] == list(m.joint_first_variable) and [int(l[11]) for l in links] == list(m.joint_mimic)
+    assert np.array_equal([float(l[12]) for l in links], m.joint_mimic_factor) and np.array_equal([float(l[13]) for l in links], m.joint_mimic_offset)
+    origin = np.array([[float(x) for x in l[15:22]] for l in links])
+    assert np.abs(origin - np.asarray(m.link_origin, dtype=float)).max() <= 1e-15  # (libm and numpy half-angle sines)
+    axis = np.array([[float(x) for x in l[23:26]] for l in links])
+    moving = np.asarray(m.joint_type) != abi.JOINT_FIXED
+    assert np.abs(axis[moving] - np.asarray(m.joint_axis, dtype=float)[moving]).max() <= 1e-16
+    assert np.array_equal([float(l[27]) for l in links], m.link_mass)
+    assert np.array_equal(np.array([[float(x) for x in l[28:31]] for l in links]), np.asarray(m.link_center, dtype=float))
+    assert [v[1] for v in variables] == m.variable_names
+    assert np.array_equal([float(v[2]) for v in variables], m.var_min) and np.array_equal([float(v[3]) for v in variables], m.var_max)
+    assert [int(v[5]) for v in variables] == [int(b) for b in m.var_bounded] and np.array_equal([float(v[7]) for v in variables], m.var_max_velocity)
+    assert sorted(g[1] for g in groups) == sorted(m.groups)
+    for g in groups:
+        j, t = g.index("joints"), g.index("tips")
+        assert g[j + 1:t] == [m.joint_names[i] for i in m.groups[g[1]].active_joints], g[1]
+        assert g[t + 1:] == [m.link_names[i] for i in m.groups[g[1]].tips], g[1]
+
+
+def run_suite(exe, tmp_path, solve):
+    compare(dump(exe, tmp_path, URDF, SRDF), load_urdf(URDF, SRDF))
+    compare(dump(exe, tmp_path, URDF_MASS, SRDF_FIXED_BASE), load_urdf(URDF_MASS, SRDF_FIXED_BASE))
+    r = subprocess.run([exe, "--errors"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    if solve:
+        out = dump(exe, tmp_path, URDF, SRDF, "arm_chain", "tool")
+        assert any(l.startswith("solve position error") for l in out)
+
+
+def test_cpp_urdf_reader_on_host_simulator(hostsim_lib, tmp_path):
+    run_suite(build(os.path.join(ROOT, "tests", "hostsim"), "bioik_hostsim", tmp_path, timeout_s=600.0), tmp_path, solve=True)
+
+
+@pytest.mark.gpu
+def test_cpp_urdf_reader_on_gpu(tmp_path):
+    run_suite(build(os.path.join(ROOT, "bio_ik_amd"), "bioik_hip", tmp_path), tmp_path, solve=True)
