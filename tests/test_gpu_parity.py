@@ -316,6 +316,35 @@ def test_full_size_mixed_batch_on_one_gpu(gpus, oracles, templates):
         assert perr[g[2] == 1].max() < POS_TOL and rerr[g[2] == 1].max() < ROT_TOL
 
 
+def test_c5_full_size_on_one_gpu(gpus, oracles, templates):
+    """BASELINE.json configs[4] at its full size on the one GPU of this box: 262 144 mixed queries (131 072 PR2 right-arm pop=128 +
+    131 072 31-DOF snake pop=512) through solve_mixed.  Too many for the oracle, so the checks are the size-independent ones: a window of
+    each block equals its own solve at the window's query offset (the sharding property, bit for bit), the success rates hold, and every
+    success of a 4096-query sample reproduces its goal pose under the reference-pinned FK."""
+    import torch
+    from bio_ik_amd.batch import solve_mixed
+    n, win, off = 131072, 2048, 77777
+    blocks = []
+    for cfg, pop, max_steps in (("c2", 128, 64), ("c4", 512, 32)):
+        h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
+        with pc.oracle_arithmetic(0):
+            seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=0xC5 + pop)
+        blocks.append((h, abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=11), seeds, params))
+    got = solve_mixed(blocks, device="cuda:0")
+    torch.cuda.synchronize()
+    for (h, p, seeds, params), g, cfg in zip(blocks, got, ("c2", "c4")):
+        assert g[0].shape[0] == n and g[2].mean() > 0.98
+        h.set_first_query(off)
+        w = h.solve_batch(p, seeds[off:off + win], params[off:off + win])
+        h.set_first_query(0)
+        assert all(np.array_equal(a[off:off + win], b) for a, b in zip(g, w)), cfg
+        idx = np.random.default_rng(5).choice(n, 4096, replace=False)
+        with pc.oracle_arithmetic(0):
+            perr, rerr = pc.pose_errors(oracles[cfg], g[0][idx], params[idx])
+        ok = g[2][idx] == 1
+        assert perr[ok].max() < POS_TOL and rerr[ok].max() < ROT_TOL
+
+
 def test_solve_batch_multi_two_handles_on_one_gpu(gpus, templates):
     """the C-ABI form of the multi-GPU split (bioik_solve_batch_multi): on this one-GPU box two handles on device 0 take the two shards
     on their own host threads and streams; the result equals the single-handle solve bit for bit, and the caller's device is untouched"""
