@@ -331,13 +331,15 @@ def main():
         "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic,
-                     "kernel": "k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": alg_flops,
+                     "kernel": "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
                      "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
                      "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
                      "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
-                             "formula x fitness evaluations counted on the device; kernel_ms is the event-bracketed duration of one launch while %d launches "
-                             "share the chip, so `frac` is per launch and `chip_level_frac` is all launches over the wall time; `traffic` = measured HBM "
+                             "formula x fitness evaluations counted on the device; a batch of this size is solved in two launches (k_solve_lean_cl: the first "
+                             "step of every query under the half-wavefront mapping, k_solve_lean: the unsolved queries to the end); kernel_ms is the "
+                             "event-bracketed duration of the two (= the sum of their rocprofv3 averages) while %d solves "
+                             "share the chip, so `frac` is per solve and `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
                              "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
                      "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                              "algorithmic_bytes_per_launch": alg_bytes, "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0,

@@ -409,12 +409,56 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         a.success = (int32_t*)w, w += units * 4;
         a.steps = (int32_t*)w;
     }
-    if (lean && sp.columnless)
-        LAUNCH(k_solve_lean_cl, (solve_body<true, true>(a, b_, l_)), units, nth, lds, stream, a);
-    else if (lean)
-        LAUNCH(k_solve_lean, solve_body<true>(a, b_, l_), units, nth, lds, stream, a);
-    else
-        LAUNCH(k_solve, solve_body<false>(a, b_, l_), units, nth, lds, stream, a);
+    auto launch = [&](const SolveArgs& args, int lanes, size_t lds_b) {
+        if (lean && args.sp.columnless)
+            LAUNCH(k_solve_lean_cl, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean)
+            LAUNCH(k_solve_lean, solve_body<true>(args, b_, l_), units, lanes, lds_b, stream, args);
+        else
+            LAUNCH(k_solve, solve_body<false>(args, b_, l_), units, lanes, lds_b, stream, args);
+    };
+    // One launch, or two (SolveArgs::step_begin ...).  Measured on the 4096-query PoseGoal batches of BASELINE.json (profiles/r02_two_launch_sweep.log):
+    // a stream of batches runs 9 % faster when every solve is split after its first step() -- same lane mapping in both launches, the state of
+    // the unsolved queries handed over through HBM -- and 11 % faster when the first launch uses the mapping with both species of a query on the
+    // halves of ONE wavefront and the children computed where they are read (no workgroup barriers, the sparse phases of both species in one
+    // instruction stream; a lone step takes 1.8x as long there, which is why it is not used to the end).  An isolated call neither gains nor loses.
+    // Later hand-overs give the same on uniformly seeded queries and cost up to 11 % on tracking seeds (most of those are solved within six steps).
+    // BIOIK_SOLVE_TWO_PHASE=K forces the hand-over after K steps for any problem (0: never) -- the parity suites run every mapping through it.
+    int first_steps = 0;
+    const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
+    if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE"))
+        first_steps = std::atoi(e);
+    else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24)
+        first_steps = 1;
+    if (first_steps < 0 || first_steps >= sp.max_steps) first_steps = 0;
+#if defined(BIOIK_PHASE_TIMING)
+    if (phase_path) first_steps = 0;
+#endif
+    if (first_steps == 0) {
+        launch(a, nth, lds);
+    } else {
+        const size_t carry_n = 17 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;
+        const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + (units * 4 + 63) / 64 * 64;
+        void* ws = be_alloc_async(count_off + 64, stream);
+        AsyncFree ws_guard{ws, stream};
+        be_zero_async((char*)ws + count_off, 64, stream);
+        SolveArgs a1 = a;
+        int nth1 = nth;
+        size_t lds1 = lds;
+        if (halves_ok && !manual) {
+            nth1 = 64;
+            a1.sp.species_parallel = 1, a1.sp.columnless = 1, a1.sp.child_cols = 1, a1.sp.child_pairs = 1;
+            lds1 = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact);
+            if (lds1 > 64 * 1024) be_allow_lds(lds1);
+        }
+        a1.step_end = first_steps;
+        a1.carry = (double*)ws, a1.carry_list = (int32_t*)((char*)ws + list_off), a1.carry_count = (unsigned int*)((char*)ws + count_off);
+        launch(a1, nth1, lds1);
+        SolveArgs a2 = a;
+        a2.step_begin = first_steps;
+        a2.carry = a1.carry, a2.unit_list = a1.carry_list, a2.unit_count = a1.carry_count;
+        launch(a2, nth, lds);  // (a grid of `units` workgroups: those beyond the count leave at once)
+    }
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
         std::vector<unsigned long long> h(units * PHASE_SLOTS);

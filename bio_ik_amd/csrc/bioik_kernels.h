@@ -185,6 +185,16 @@ struct SolveArgs {
     int32_t* steps;         // [n*islands]
     unsigned long long* phase_cycles;  // [n*islands][8] or null: per-phase shader cycles (builds with -DBIOIK_PHASE_TIMING)
     unsigned long long* launch_clock;  // one zeroed word per launch (timeout_ticks != 0): the first workgroup's start on the device clock
+    // A solve in two launches (the launcher's choice, bioik_hip.hip): the first runs the steps [0, step_end) of every unit under the lane
+    // mapping that fills the chip best and hands the units that are neither solved nor out of time to the second, which runs them to the
+    // end under the mapping with the fastest lone step.  What a unit is between two steps: the species' elites, the solution and
+    // 24 numbers of bookkeeping (three LDS arrays); the RNG is a function of the step index.
+    int32_t step_begin = 0, step_end = 0x7fffffff;  // this launch runs the steps [step_begin, min(step_end, sp.max_steps))
+    double* carry = nullptr;                  // [units][17 M + 24] state of the handed-over units (first launch writes, second reads)
+    int32_t* carry_list = nullptr;            // first launch: the units handed over, in the order they finish ...
+    unsigned int* carry_count = nullptr;      // ... and how many (zeroed by the host)
+    const int32_t* unit_list = nullptr;       // second launch: workgroup b continues unit_list[b] ...
+    const unsigned int* unit_count = nullptr; // ... for b < *unit_count (the grid is an upper bound)
 };
 
 struct SpeciesState {
@@ -202,8 +212,14 @@ struct SpeciesState {
 // copies of the chain walk do not weigh on the register allocation of the column kernels (with both in one kernel the lean flavour
 // spilled 74 instead of 32 VGPRs and lost 4 % on C2)
 template <bool LEAN, bool CL = false>
-BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
+BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
+    uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
+    const bool resume = a.unit_list != nullptr;
+    if (resume) {  // (uniform over the workgroup, before the first barrier)
+        if (unit >= (uint64_t)*a.unit_count) return;
+        unit = (uint64_t)a.unit_list[unit];
+    }
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
@@ -303,23 +319,35 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
 
     // ik_evolution_2.cpp:129-179: solution = seed, 2 species x 2 clones of the seed, zero momentum.
     // Inactive ops carry the seed's value in every vector, so the chain walk never distinguishes them.
-    for (int k = tid; k < n_ops; k += nth) {
-        double v = s_seed[pb->ops[k].var];
-        for (int s = 0; s < 2; s++)
-            for (int i = 0; i < 2; i++) {
-                double* d = s_pop + s * SP + i * 2 * M;
-                d[k] = v, d[M + k] = 0.0;
-            }
-        s_sol[k] = v;
-        s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
+    const int carry_n = 2 * SP + M + 24;  // doubles of a unit's state between two steps: s_pop, s_sol, s_state
+    if (!resume) {
+        for (int k = tid; k < n_ops; k += nth) {
+            double v = s_seed[pb->ops[k].var];
+            for (int s = 0; s < 2; s++)
+                for (int i = 0; i < 2; i++) {
+                    double* d = s_pop + s * SP + i * 2 * M;
+                    d[k] = v, d[M + k] = 0.0;
+                }
+            s_sol[k] = v;
+        }
+    } else {
+        const double* c = a.carry + unit * (uint64_t)carry_n;
+        for (int i = tid; i < carry_n; i += nth) {
+            const double v = c[i];
+            if (i < 2 * SP) s_pop[i] = v;
+            else if (i < 2 * SP + M) s_sol[i - 2 * SP] = v;
+            else s_state[i - 2 * SP - M] = v;
+        }
     }
+    for (int k = tid; k < n_ops; k += nth) s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
     p_barrier();
     if (pb->n_prefix > 0) {  // the joints in front of the first gene see the seed in every individual: walk them once per query
         if (tid == 0) f7_store(s_prefix, fk_prefix(pb, XV{s_sol, 1}));
         p_barrier();
     }
     // the seed is the first solution; whether it already satisfies the goals is what the first success test will find
-    const FitCheck fc0 = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
+    FitCheck fc0{0.0, 0};
+    if (!resume) fc0 = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
     double* s_solst = s_state + 20;  // [0] fitness, [1] success flag of the current solution
     const double sol_fit = fc0.fitness;
     // The bookkeeping of the two species lives in LDS between the phases of a step (s_state[rank][8], rank 0 = the leading species of
@@ -333,7 +361,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         double* d = s_state + r * 8;
         d[0] = S.fit, d[1] = S.pf0, d[2] = S.pf1, d[3] = (double)S.id, d[4] = (double)S.slot, d[5] = (double)S.cur, d[6] = (double)S.improved, d[7] = (double)S.ok;
     };
-    if (tid == 0) {
+    if (tid == 0 && !resume) {
         species_store(0, SpeciesState{P_INF, sol_fit, sol_fit, 0, 0, 0, 0, 0});
         species_store(1, SpeciesState{P_INF, sol_fit, sol_fit, 1, 1, 0, 0, 0});
         s_solst[0] = sol_fit, s_solst[1] = (double)fc0.ok;
@@ -355,10 +383,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         deadline = (((unsigned long long)s_wbc[2] << 32) | (unsigned long long)s_wbc[3]) + sp.timeout_ticks;
         p_barrier();
     }
-    int steps = 0;
-    bool success = false;
+    int steps = a.step_begin;
+    bool success = false, expired = false;
     double final_fit = BIOIK_DBL_MAX;
-    for (int step = 0; step < sp.max_steps; step++) {
+    const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
+    for (int step = a.step_begin; step < step_end; step++) {
         for (int rank = rank_begin; rank < rank_end; rank++) {
             SpeciesState S = species_load(rank);
             double* popS = s_pop + S.slot * SP;
@@ -763,12 +792,17 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit, double* lds) {
         if (sp.timeout_ticks != 0ull) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
             if (tid == 0) s_wbc[2] = p_wall_clock() >= deadline ? 1.0 : 0.0;
             p_barrier();
-            const bool expired = s_wbc[2] != 0.0;
+            expired = s_wbc[2] != 0.0;
             p_barrier();
             if (expired) break;
         }
     }
     PHASE_DUMP(a.phase_cycles, unit);
+    if (a.carry_list && !success && !expired && step_end < sp.max_steps) {  // neither solved nor out of time: the next launch goes on
+        double* c = a.carry + unit * (uint64_t)carry_n;
+        for (int i = tid; i < carry_n; i += nth) c[i] = i < 2 * SP ? s_pop[i] : (i < 2 * SP + M ? s_sol[i - 2 * SP] : s_state[i - 2 * SP - M]);
+        if (tid == 0) a.carry_list[p_atomic_inc(a.carry_count)] = (int32_t)unit;
+    }
 
     // result of this island; ranking fitness of ik_parallel.h:229-246
     double rank_fit = final_fit;

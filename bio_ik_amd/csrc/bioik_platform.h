@@ -66,6 +66,7 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     const unsigned long long old = atomicCAS(word, 0ull, value);
     return old ? old : value;
 }
+BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return atomicAdd(counter, 1u); }  // returns the value before
 #define P_INF (__builtin_inf())
 #define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
 #define BIOIK_HD __host__ __device__ inline

@@ -64,6 +64,7 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     unsigned long long expected = 0ull;
     return __atomic_compare_exchange_n(word, &expected, value, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? value : expected;
 }
+BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL); }
 #define P_INF (__builtin_inf())
 
 #define BIOIK_FP_STRICT

@@ -236,6 +236,10 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "2"},       # ... and scored two at a time
     {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_COLUMNLESS": "1"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "0", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
+    {"BIOIK_SOLVE_TWO_PHASE": "1"},                                      # two launches: hand-over after the first step (first launch: the species
+    {"BIOIK_SOLVE_TWO_PHASE": "2"},                                      # on the halves of a wavefront where the problem allows, else the usual mapping)
+    {"BIOIK_SOLVE_TWO_PHASE": "2", "BIOIK_SOLVE_THREADS": "256"},        # ... both launches under a forced mapping
+    {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},
 ])
 def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
     """the same solve under every lane <-> work mapping the launcher can choose"""
@@ -244,6 +248,27 @@ def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, e
     pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=16, pop=128, steps_list=(6,))
     pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=8, pop=100, steps_list=(3,))
     pc.trajectory(gpus["c4"], oracles["c4"], templates["c4"], n=4, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+
+
+def test_two_launch_solve_equals_single_launch(gpus, templates, monkeypatch):
+    """A batch that fills the chip several times over is solved in two launches (first steps under the half-wavefront mapping, the unsolved
+    queries handed to the mapping with the fastest lone step): bit for bit the result of one launch — full size, with islands, with a
+    step budget below the hand-over, and under a wall-clock timeout (which ends queries at launch-dependent steps: only its guarantees hold)."""
+    h, t = gpus["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 4096, seed=21)
+    for kw in ({"max_steps": 64}, {"max_steps": 24, "islands": 2}, {"max_steps": 6}, {"max_steps": 40, "mode": "bio2"}):
+        p = abi.default_solve_params(population=128, random_seed=4, **kw)
+        monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "0")
+        one = h.solve_batch(p, seeds, params)
+        monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE")
+        two = h.solve_batch(p, seeds, params)  # the launcher's own choice for 4096 queries
+        monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "13")
+        late = h.solve_batch(p, seeds, params)
+        monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE")
+        assert all(np.array_equal(a, b) for a, b in zip(one, two)) and all(np.array_equal(a, b) for a, b in zip(one, late)), kw
+    p = abi.default_solve_params(population=128, max_steps=4096, random_seed=4, timeout=0.004)
+    sol, fit, suc, steps = h.solve_batch(p, seeds, params)
+    assert steps.min() >= 1 and steps.max() < 4096 and suc.mean() > 0.5
 
 
 def test_full_batch_c2_result_level(gpus, oracles, templates):

@@ -7,16 +7,24 @@ shutil.copy(os.path.join(g, "bench_" + rnd + ".json"), os.path.join(p, rnd + "_b
 out = {}
 for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_collection.csv", "pmc_sq/sq_counter_collection.csv", "pmc_mem/mem_counter_collection.csv", "pmc_ic/ic_counter_collection.csv"):
     if not os.path.exists(os.path.join(g, f)): continue
-    rows = list(csv.DictReader(open(os.path.join(g, f)))); agg = collections.defaultdict(list)
+    # a bench step is one solve = one launch, or two (k_solve_lean_cl: the first steps of every query, k_solve_lean: the unsolved ones to the
+    # end): counters are summed per step = over the dispatches of both kernels / the dispatches of the kernel that ends a step
+    rows = list(csv.DictReader(open(os.path.join(g, f)))); agg = collections.defaultdict(float); per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = collections.Counter()
     for r in rows:
         if "k_solve" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            out["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            kn = r["Kernel_Name"].split("(")[0]
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            per_kernel[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            names[(kn, r["Counter_Name"])] += 1
+            out.setdefault("dispatch", {})[kn] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
-        out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "min": min(v), "max": max(v)}
+        closing = "k_solve_lean" if ("k_solve_lean", k) in names else max((kn for kn, c in names if c == k), key=lambda kn: names[(kn, k)])
+        steps = names[(closing, k)]
+        out[k] = {"steps": steps, "mean_per_launch": v / steps, "per_kernel_mean": {kn: sum(c[k]) / len(c[k]) for kn, c in per_kernel.items() if k in c}}
 fk, wk = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
 summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --timed-only --steps 5 --warmup 1 "
-                      "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)", "kernel": "k_solve_lean(SolveArgs)", "counters": out,
+                      "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)", "kernel": "k_solve_lean_cl(SolveArgs) + k_solve_lean(SolveArgs): the two launches of one solve, counters summed per solve (`mean_per_launch`)", "counters": out,
            "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
                                     "total_corrected": 2 * fk * 1024 + wk * 1024,
                                     "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "

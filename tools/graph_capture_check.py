@@ -6,7 +6,7 @@ from bio_ik_amd.workload import make_queries
 t = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
 h = HipSolver(t, device=0)
 dev = torch.device("cuda", 0)
-n = 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256  # (4096: the two-launch solve with its stream-ordered scratch inside the capture)
 seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=3)
 p = abi.default_solve_params(population=128, max_steps=64, random_seed=1)
 ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)

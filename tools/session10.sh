@@ -15,4 +15,5 @@ print('cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('query_parallel')
 BIOIK_BENCH_C5_BATCH=16384 python bench.py --config c5 --steps 3 --warmup 1 > $O/s10_c5.json 2> $O/s10_c5.err; head -c 600 $O/s10_c5.json; echo
 BIOIK_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > $O/s10_two_ranks.json 2> $O/s10_two_ranks.err; echo "two ranks rc=$?"; head -c 700 $O/s10_two_ranks.json; echo
 bash tools/step_rate.sh bio_ik_amd/libbioik_hip.so | tee $O/s10_step_rate.log
+python tools/graph_capture_check.py > $O/s10_graph.log 2>&1; python tools/graph_capture_check.py 4096 >> $O/s10_graph.log 2>&1; echo "graph capture rc=$?"; grep identical $O/s10_graph.log
 timeout 900 python tools/fuzz_parity.py 300 20260926 > $O/s10_fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 $O/s10_fuzz.log
