@@ -224,6 +224,12 @@ def main():
     if "BIOIK_BENCH_DTWIST" in os.environ:  # experiments only (e.g. 1e-300: no query ever succeeds, every workgroup runs max_steps)
         p.dtwist = float(os.environ["BIOIK_BENCH_DTWIST"])
 
+    if os.environ.get("BIOIK_BENCH_ORDER"):  # experiment: the queries of a batch sorted by the steps they will need (asc | desc), known from a first solve
+        first = h.solve_batch(p, seeds, params)
+        order = np.argsort(first[3], kind="stable")
+        if os.environ["BIOIK_BENCH_ORDER"] == "desc":
+            order = order[::-1]
+        seeds, params = np.ascontiguousarray(seeds[order]), np.ascontiguousarray(params[order])
     d_seeds = torch.from_numpy(seeds).to(dev)
     d_params = torch.from_numpy(params).to(dev)
     # Consecutive steps go round-robin to `in_flight` HIP streams with their own result buffers: a launch of 4096 queries
@@ -246,6 +252,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    stagger_ms = float(os.environ.get("BIOIK_BENCH_STAGGER_MS", "0"))
+
     def timed(n_steps, n_warm):
         for i in range(n_warm):
             step(i)
@@ -256,6 +264,8 @@ def main():
             a.record(streams[i % nfl])  # events on the stream the kernel is launched on
             step(i)
             b.record(streams[i % nfl])
+            if stagger_ms > 0.0 and i < nfl - 1:  # experiment (BIOIK_BENCH_STAGGER_MS): the first solves of the streams start this far apart
+                time.sleep(stagger_ms * 1e-3)
         barrier()
         el = time.perf_counter() - t0
         return el, (float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else 0.0)
