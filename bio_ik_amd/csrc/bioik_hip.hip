@@ -424,40 +424,55 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // instruction stream; a lone step takes 1.8x as long there, which is why it is not used to the end).  An isolated call neither gains nor loses.
     // Later hand-overs give the same on uniformly seeded queries and cost up to 11 % on tracking seeds (most of those are solved within six steps).
     // BIOIK_SOLVE_TWO_PHASE=K forces the hand-over after K steps for any problem (0: never) -- the parity suites run every mapping through it.
-    int first_steps = 0;
+    std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
     const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
-    if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE"))
-        first_steps = std::atoi(e);
-    else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24)
-        first_steps = 1;
-    if (first_steps < 0 || first_steps >= sp.max_steps) first_steps = 0;
+    if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
+        for (const char* c = e; *c;) {
+            char* end = nullptr;
+            const long k = std::strtol(c, &end, 10);
+            if (end == c) break;
+            if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
+            c = *end == ',' ? end + 1 : end;
+        }
+    } else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+        handovers.push_back(1);
+    }
 #if defined(BIOIK_PHASE_TIMING)
-    if (phase_path) first_steps = 0;
+    if (phase_path) handovers.clear();
 #endif
-    if (first_steps == 0) {
+    if (handovers.empty()) {
         launch(a, nth, lds);
     } else {
+        const size_t nh = handovers.size();
         const size_t carry_n = 17 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;
-        const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + (units * 4 + 63) / 64 * 64;
-        void* ws = be_alloc_async(count_off + 64, stream);
+        const size_t list_bytes = (units * 4 + 63) / 64 * 64;
+        const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + nh * list_bytes;
+        void* ws = be_alloc_async(count_off + nh * 64, stream);
         AsyncFree ws_guard{ws, stream};
-        be_zero_async((char*)ws + count_off, 64, stream);
-        SolveArgs a1 = a;
-        int nth1 = nth;
-        size_t lds1 = lds;
-        if (halves_ok && !manual) {
-            nth1 = 64;
-            a1.sp.species_parallel = 1, a1.sp.columnless = 1, a1.sp.child_cols = 1, a1.sp.child_pairs = 1;
-            lds1 = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact);
-            if (lds1 > 64 * 1024) be_allow_lds(lds1);
+        be_zero_async((char*)ws + count_off, nh * 64, stream);
+        for (size_t j = 0; j <= nh; j++) {  // launch j runs the steps [handovers[j-1], handovers[j])
+            SolveArgs aj = a;
+            int lanes = nth;
+            size_t lds_j = lds;
+            if (j == 0 && halves_ok && !manual) {
+                lanes = 64;
+                aj.sp.species_parallel = 1, aj.sp.columnless = 1, aj.sp.child_cols = 1, aj.sp.child_pairs = 1;
+                lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact);
+                if (lds_j > 64 * 1024) be_allow_lds(lds_j);
+            }
+            aj.carry = (double*)ws;
+            if (j > 0) {
+                aj.step_begin = handovers[j - 1];
+                aj.unit_list = (const int32_t*)((char*)ws + list_off + (j - 1) * list_bytes);
+                aj.unit_count = (const unsigned int*)((char*)ws + count_off + (j - 1) * 64);
+            }
+            if (j < nh) {
+                aj.step_end = handovers[j];
+                aj.carry_list = (int32_t*)((char*)ws + list_off + j * list_bytes);
+                aj.carry_count = (unsigned int*)((char*)ws + count_off + j * 64);
+            }
+            launch(aj, lanes, lds_j);  // (always a grid of `units` workgroups: those beyond the list's length leave at once)
         }
-        a1.step_end = first_steps;
-        a1.carry = (double*)ws, a1.carry_list = (int32_t*)((char*)ws + list_off), a1.carry_count = (unsigned int*)((char*)ws + count_off);
-        launch(a1, nth1, lds1);
-        SolveArgs a2 = a;
-        a2.step_begin = first_steps;
-        a2.carry = a1.carry, a2.unit_list = a1.carry_list, a2.unit_count = a1.carry_count;
-        launch(a2, nth, lds);  // (a grid of `units` workgroups: those beyond the count leave at once)
     }
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters

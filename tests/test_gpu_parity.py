@@ -240,6 +240,7 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_TWO_PHASE": "2"},                                      # on the halves of a wavefront where the problem allows, else the usual mapping)
     {"BIOIK_SOLVE_TWO_PHASE": "2", "BIOIK_SOLVE_THREADS": "256"},        # ... both launches under a forced mapping
     {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},
+    {"BIOIK_SOLVE_TWO_PHASE": "1,2,4"},                                  # a chain of hand-overs (four launches)
 ])
 def test_trajectory_independent_of_workgroup_mapping(gpus, oracles, templates, env, monkeypatch):
     """the same solve under every lane <-> work mapping the launcher can choose"""

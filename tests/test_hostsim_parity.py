@@ -91,6 +91,7 @@ def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, en
     {"BIOIK_SOLVE_TWO_PHASE": "1"},
     {"BIOIK_SOLVE_TWO_PHASE": "2", "BIOIK_SOLVE_THREADS": "128"},
     {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},
+    {"BIOIK_SOLVE_TWO_PHASE": "1,2"},  # a chain of hand-overs (three launches)
 ])
 def test_two_launch_solve(sims, oracles, templates, monkeypatch, env):
     """a solve split over two launches (SolveArgs::step_begin ...): the state handed over after K steps — elites, solution, bookkeeping —
