@@ -427,7 +427,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
     const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
-        for (const char* c = e; *c;) {
+        const bool init_only = std::strcmp(e, "init") == 0;  // (experiment: the first launch only initialises)
+        if (init_only) handovers.push_back(0);
+        for (const char* c = e; *c && !init_only;) {
             char* end = nullptr;
             const long k = std::strtol(c, &end, 10);
             if (end == c) break;
