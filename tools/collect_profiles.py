@@ -41,3 +41,22 @@ if isinstance(b.get("roofline"), dict):
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
     print(k, "%.4g" % out[k]["mean_per_launch"])
 print("hbm bytes/launch %.4g" % summary["hbm_bytes_per_launch"]["total_corrected"], out["dispatch"])
+
+# k_stream_fitness: measured HBM bytes per launch (same unit corrections) next to the algorithmic bytes of the bench line
+sf = {}
+for f, key in (("pmc_sfetch/sfetch_counter_collection.csv", "FETCH_SIZE"), ("pmc_swrite/swrite_counter_collection.csv", "WRITE_SIZE")):
+    path = os.path.join(g, f)
+    if os.path.exists(path):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "k_stream_fitness" in r["Kernel_Name"] and r["Counter_Name"] == key]
+        if v:
+            sf[key] = {"launches": len(v), "mean_per_launch_KiB": sum(v) / len(v)}
+if len(sf) == 2:
+    b = json.load(open(os.path.join(p, rnd + "_bench.json")))
+    alg = b.get("streamed_fitness", {}).get("algorithmic_bytes_per_launch")
+    meas = 2 * sf["FETCH_SIZE"]["mean_per_launch_KiB"] * 1024 + sf["WRITE_SIZE"]["mean_per_launch_KiB"] * 1024
+    json.dump({"kernel": "k_stream_fitness(StreamArgs)", "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python bench.py --no-cpu-baseline --steps 2 --warmup 1",
+               "counters": sf, "measured_hbm_bytes_per_launch": meas, "algorithmic_bytes_per_launch": alg, "measured_over_algorithmic": meas / alg if alg else None,
+               "note": "genes [unit][D][pop] f64 streamed once (FETCH_SIZE x 2: gfx950 tallies 128-B requests as 64 B), fitness written once; "
+                       "a ratio near 1 = every gene byte crosses the HBM interface once, in full 512-byte wavefront segments"},
+              open(os.path.join(p, rnd + "_pmc_k_stream_fitness.json"), "w"), indent=1)
+    print("k_stream_fitness measured / algorithmic bytes: %.3f" % (meas / alg if alg else float("nan")))
