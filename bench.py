@@ -8,11 +8,13 @@ GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-que
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
 Consecutive steps are issued round-robin on three HIP streams (`--in-flight`, config.batches_in_flight): the tail of one
 launch — a handful of queries that use the whole step budget, 64 sequential steps wherever they start — overlaps the bulk
-of the next ones; `one_batch_at_a_time` holds the same measurement with strictly one launch after the other
-(profiles/r01_inflight_sweep.log: 1 / 2 / 3 in flight).
+of the next ones; `one_batch_at_a_time` holds the same measurement with strictly one solve after the other
+(profiles/r01_inflight_sweep.log, r02_two_launch_sweep.log: 1 / 2 / 3 in flight).  For a batch of this size the library enqueues a solve as
+TWO kernels (k_solve_lean_cl: the first step of every query, k_solve_lean: the unsolved queries to the end, state handed over through HBM;
+DESIGN.md section 5): a step of this bench is still one call of `bioik_solve_batch_device`.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_solve_lean against the roof that binds it, FP64 vector arithmetic: ALGORITHMIC flops per launch
+  roofline     the solve's kernels (k_solve_lean dominant) against the roof that binds them, FP64 vector arithmetic: ALGORITHMIC flops per solve
                (130 L_m + 40 R + 25 G_pose per exact-FK evaluation of an individual, times the evaluations counted by
                the device step counters) / mean launch duration measured with HIP events on the launch stream, vs the 78.6 TFLOP/s
                FP64 vector peak of MI355X.  `roofline.hbm` holds the HBM figure the same way (§8d B_gen = 8*(pop*(3D+1) + 8D)
