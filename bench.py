@@ -154,7 +154,7 @@ def bench_c5(args, rank, world, gpu, dev):
         n_success = float(res[0][2].sum() + res[1][2].sum())
         out = {"metric": "IK solves/sec (mixed PR2 pop=128 / 31-DOF snake pop=512 batch, sharded end to end)", "value": n_success * args.steps / elapsed, "unit": "solves/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (one batch of queries per stream in flight, same recipe, different draws)",
                "config": {"workload": "BASELINE.json configs[4]: %d mixed queries (half PR2-like right arm 7-DOF PoseGoal pop=128, half 31-DOF snake PoseGoal + "
                                       "AvoidJointLimits pop=512), sorted by model, every block sharded over all ranks; host arrays on rank 0 in and out" % total,
                           "global_batch": total, "sharding": "scatter -> solve -> gather (torch.distributed; RCCL with N>1), no collective between shards"},
@@ -244,9 +244,20 @@ def main():
              torch.empty(BATCH, dtype=torch.int32, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev)) for _ in range(nfl)]
     torch.cuda.synchronize(dev)
 
+    # Every stream solves its OWN batch of synthetic queries (same recipe, different draws).  With one batch repeated on all streams the
+    # solves in flight have identical per-query durations and their long-running workgroups coincide: 6.5 instead of 6.0 ms per batch
+    # for one-launch solves (profiles/r02_two_launch_sweep.log, distinct-batch block).  BIOIK_BENCH_SAME_BATCH=1 restores the repetition.
+    inputs = [(d_seeds, d_params)] * nfl
+    if not os.environ.get("BIOIK_BENCH_SAME_BATCH"):
+        inputs = [(d_seeds, d_params)]
+        for k in range(1, nfl):
+            sk, pk, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank + 1000 * k)
+            inputs.append((torch.from_numpy(sk).to(dev), torch.from_numpy(pk).to(dev)))
+
     def step(i):
         o, st = bufs[i % nfl], streams[i % nfl]
-        h.solve_batch_device(p, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+        ds, dp = inputs[i % nfl]
+        h.solve_batch_device(p, BATCH, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
                              st.cuda_stream)
 
     def barrier():
@@ -274,7 +285,18 @@ def main():
 
     elapsed, kernel_ms = timed(args.steps, args.warmup)
     d_sol, d_fit, d_suc, d_steps = bufs[0]
-    identical = all(bool(torch.equal(o[0], d_sol)) and bool(torch.equal(o[2], d_suc)) and bool(torch.equal(o[3], d_steps)) for o in bufs[1:])
+    # what the timed steps produced, per stream: successes and step() calls of the batch that stream solves, times its share of the steps
+    share = [len(range(k, args.steps, nfl)) for k in range(nfl)]
+    succ_timed = float(sum(int(o[2].sum().item()) * share[k] for k, o in enumerate(bufs)))
+    steps_timed = float(sum(float(o[3].double().sum().item()) * share[k] for k, o in enumerate(bufs)))
+    # determinism across streams: batch 0 solved once more on another stream gives the same bits
+    identical = True
+    if nfl > 1:
+        chk = (torch.empty_like(d_sol), torch.empty_like(d_fit), torch.empty_like(d_suc), torch.empty_like(d_steps))
+        h.solve_batch_device(p, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), chk[0].data_ptr(), chk[1].data_ptr(), chk[2].data_ptr(), chk[3].data_ptr(),
+                             streams[1].cuda_stream)
+        torch.cuda.synchronize(dev)
+        identical = bool(torch.equal(chk[0], d_sol)) and bool(torch.equal(chk[2], d_suc)) and bool(torch.equal(chk[3], d_steps))
     sequential = None
     if nfl > 1 and not args.timed_only:  # the same steps strictly one after the other, for the record
         nfl_saved, nfl = nfl, 1
@@ -285,7 +307,7 @@ def main():
     suc = d_suc.cpu().numpy()
     steps_q = d_steps.cpu().numpy()
     n_success = int(suc.sum())
-    total_success = float(n_success * args.steps)
+    total_success = succ_timed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -304,13 +326,14 @@ def main():
     # algorithmic bytes of one launch
     gens_per_step = 2 * (8 if p.mode != abi.MODE_BIO2 else 16)
     b_gen = 8 * (POP * (3 * D + 1) + 8 * D)
-    generations = float(steps_q.astype(np.float64).sum()) * gens_per_step
+    steps_per_launch = steps_timed / max(args.steps, 1)  # step() calls of one batch: the mean over the timed launches (each stream has its own batch)
+    generations = steps_per_launch * gens_per_step
     alg_bytes = generations * b_gen + BATCH * (8 * (7 * T + V) + 8 * (V + 3))
     achieved = alg_bytes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
     # algorithmic flops of one launch: every child of every generation + the four exact evaluations of a step's species management
     n_moving, n_rev = 8, 7  # PR2-like right arm: torso (prismatic, inactive) + 7 revolute joints on the chain
     fpe = flops_per_evaluation(n_moving, n_rev, 1)
-    evaluations = generations * POP + 4.0 * float(steps_q.astype(np.float64).sum())
+    evaluations = generations * POP + 4.0 * steps_per_launch
     alg_flops = evaluations * fpe
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -336,8 +359,8 @@ def main():
         "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
                    "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective",
                    "batches_in_flight": nfl},
-        "success_rate": float(suc.mean()),
-        "mean_steps_per_solve": float(steps_q.mean()),
+        "success_rate": succ_timed / max(args.steps * BATCH, 1),
+        "mean_steps_per_solve": steps_per_launch / BATCH,
         "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
         "max_pos_err_m_of_successes": pos_err,
         "max_rot_err_rad_of_successes": rot_err,

@@ -417,13 +417,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         else
             LAUNCH(k_solve, solve_body<false>(args, b_, l_), units, lanes, lds_b, stream, args);
     };
-    // One launch, or two (SolveArgs::step_begin ...).  Measured on the 4096-query PoseGoal batches of BASELINE.json (profiles/r02_two_launch_sweep.log):
-    // a stream of batches runs 9 % faster when every solve is split after its first step() -- same lane mapping in both launches, the state of
-    // the unsolved queries handed over through HBM -- and 11 % faster when the first launch uses the mapping with both species of a query on the
-    // halves of ONE wavefront and the children computed where they are read (no workgroup barriers, the sparse phases of both species in one
-    // instruction stream; a lone step takes 1.8x as long there, which is why it is not used to the end).  An isolated call neither gains nor loses.
-    // Later hand-overs give the same on uniformly seeded queries and cost up to 11 % on tracking seeds (most of those are solved within six steps).
-    // BIOIK_SOLVE_TWO_PHASE=K forces the hand-over after K steps for any problem (0: never) -- the parity suites run every mapping through it.
+    // One launch, or two (SolveArgs::step_begin ...).  Measured on streams of distinct 4096-query PoseGoal batches (profiles/r02_two_launch_sweep.log):
+    // split after the first step(), the state of the unsolved queries handed over through HBM, the first launch with both species of a query on
+    // the halves of ONE wavefront and the children computed where they are read, a stream of batches runs 2.6 % faster and an isolated call 3.5 %
+    // (later hand-overs give the same on uniformly seeded queries and cost up to 11 % on tracking seeds, most of which are solved within six steps).
+    // The second launch takes the queries in the order the first finished them: solves in flight whose long-running queries would otherwise
+    // coincide (the same batch solved again on another stream) do not lose the 8 % such a coincidence costs.
+    // BIOIK_SOLVE_TWO_PHASE=K (or K1,K2,... / init) forces hand-overs after those steps for any problem (0: never) -- the parity suites run every
+    // mapping through it.
     std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
     const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
