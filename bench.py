@@ -154,7 +154,7 @@ def bench_c5(args, rank, world, gpu, dev):
         n_success = float(res[0][2].sum() + res[1][2].sum())
         out = {"metric": "IK solves/sec (mixed PR2 pop=128 / 31-DOF snake pop=512 batch, sharded end to end)", "value": n_success * args.steps / elapsed, "unit": "solves/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic (one batch of queries per stream in flight, same recipe, different draws)",
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[4]: %d mixed queries (half PR2-like right arm 7-DOF PoseGoal pop=128, half 31-DOF snake PoseGoal + "
                                       "AvoidJointLimits pop=512), sorted by model, every block sharded over all ranks; host arrays on rank 0 in and out" % total,
                           "global_batch": total, "sharding": "scatter -> solve -> gather (torch.distributed; RCCL with N>1), no collective between shards"},
@@ -355,7 +355,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic (one batch of queries per stream in flight: same recipe, different draws)",
         "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
                    "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective",
                    "batches_in_flight": nfl},
@@ -428,15 +428,16 @@ def main():
         # The same queries at the REFERENCE'S OWN parameters (2 species x (2 elites + 16 children), linearised phenotypes, budget
         # 512 steps as in the cpu_baseline leg): the like-for-like figure next to cpu_baseline.value; never `value`.
         pr = abi.default_solve_params(population=16, max_steps=512, random_seed=1, fk_mode=abi.FK_LINEAR)
-        for i in range(2):
-            o = bufs[i % nfl]
-            h.solve_batch_device(pr, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+        def rstep(i):
+            o, (ds, dp) = bufs[i % nfl], inputs[i % nfl]
+            h.solve_batch_device(pr, BATCH, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+        for i in range(nfl):
+            rstep(i)
         torch.cuda.synchronize(dev)
-        kr = 8
+        kr = 9
         t1 = time.perf_counter()
         for i in range(kr):
-            o = bufs[i % nfl]
-            h.solve_batch_device(pr, BATCH, d_seeds.data_ptr(), d_params.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
+            rstep(i)
         torch.cuda.synchronize(dev)
         dtr = (time.perf_counter() - t1) / kr
         rsuc = bufs[0][2].cpu().numpy()
@@ -447,11 +448,13 @@ def main():
     if rank == 0 and world == 1 and not args.timed_only:
         # The "tracking" workload of SURVEY.md section 8(d) (seed = target + N(0, 0.1 rad), as the reference's ik_test does): same
         # template, same parameters, same issue pattern; reported next to the global-seed figure, never `value`.
-        tseeds, tparams, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank, kind="tracking")
-        dts, dtp = torch.from_numpy(tseeds).to(dev), torch.from_numpy(tparams).to(dev)
+        tin = []
+        for k in range(nfl if not os.environ.get("BIOIK_BENCH_SAME_BATCH") else 1):  # one batch per stream, as above
+            tseeds, tparams, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank + 1000 * k, kind="tracking")
+            tin.append((torch.from_numpy(tseeds).to(dev), torch.from_numpy(tparams).to(dev)))
 
         def tstep(i):
-            o = bufs[i % nfl]
+            o, (dts, dtp) = bufs[i % nfl], tin[i % len(tin)]
             h.solve_batch_device(p, BATCH, dts.data_ptr(), dtp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), streams[i % nfl].cuda_stream)
         for i in range(nfl):
             tstep(i)
@@ -465,7 +468,7 @@ def main():
         tsuc = bufs[0][2].cpu().numpy()
         out["tracking_seeds"] = {"value": float(tsuc.sum()) / dtt, "unit": "solves/s", "ms_per_step": dtt * 1e3, "success_rate": float(tsuc.mean()),
                                  "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "batches_in_flight": nfl,
-                                 "sample": "4096 queries, seed = target configuration + N(0, 0.1 rad) clipped to the joint limits"}
+                                 "sample": "4096 queries per stream, seed = target configuration + N(0, 0.1 rad) clipped to the joint limits"}
 
     if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_CONFIGS", "1") != "0":
         out["configs"] = other_configs(dev, nfl, streams)
