@@ -89,7 +89,6 @@ def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, en
 
 @pytest.mark.parametrize("env", [
     {"BIOIK_SOLVE_TWO_PHASE": "1"},
-    {"BIOIK_SOLVE_TWO_PHASE": "2", "BIOIK_SOLVE_THREADS": "128"},
     {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},
     {"BIOIK_SOLVE_TWO_PHASE": "1,2"},  # a chain of hand-overs (three launches)
 ])
@@ -99,7 +98,7 @@ def test_two_launch_solve(sims, oracles, templates, monkeypatch, env):
     children, otherwise under the usual one; also with islands and with a secondary goal"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(3,))
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=128, steps_list=(3,))
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=40, steps_list=(3,), islands=2)
     pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=24, steps_list=(1, 4), fk_mode=abi.FK_LINEAR, mode="bio2_memetic_l")
 
