@@ -46,7 +46,8 @@ public:
             if (variable_names[i] == n) return (int)i;
         throw std::runtime_error("joint variable not found: " + n);  // reference problem.cpp:125
     }
-    // type: "fixed" | "revolute" | "continuous" | "prismatic" (URDF semantics)
+    // type: "fixed" | "revolute" | "continuous" | "prismatic" (URDF semantics) | "floating" | "planar" (MoveIt's multi-variable joints:
+    // variables <joint>/trans_x .. rot_w and <joint>/x, y, theta; the device takes one such joint, at the root of the model)
     int addLink(const std::string& link, const std::string& parent, const std::string& joint, const std::string& type, const double (&xyz)[3],
                 const double (&rpy)[3], const double (&axis)[3], double lower = 0, double upper = 0, double velocity = 0) {
         int idx = (int)link_names.size();
@@ -56,16 +57,29 @@ public:
         double q[4];
         quatFromRpy(rpy[0], rpy[1], rpy[2], q);
         for (double v : {xyz[0], xyz[1], xyz[2], q[0], q[1], q[2], q[3]}) link_origin.push_back(v);
-        int t = type == "fixed" ? BIOIK_JOINT_FIXED : (type == "prismatic" ? BIOIK_JOINT_PRISMATIC : BIOIK_JOINT_REVOLUTE);
-        if (type != "fixed" && type != "prismatic" && type != "revolute" && type != "continuous") throw std::runtime_error("unsupported joint type " + type);
+        int t = type == "fixed" ? BIOIK_JOINT_FIXED : (type == "prismatic" ? BIOIK_JOINT_PRISMATIC : (type == "floating" ? BIOIK_JOINT_FLOATING : (type == "planar" ? BIOIK_JOINT_PLANAR : BIOIK_JOINT_REVOLUTE)));
+        if (type != "fixed" && type != "prismatic" && type != "revolute" && type != "continuous" && type != "floating" && type != "planar")
+            throw std::runtime_error("unsupported joint type " + type);
         joint_type.push_back(t);
         double n = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-        for (int c = 0; c < 3; c++) joint_axis.push_back(t == BIOIK_JOINT_FIXED || n == 0 ? axis[c] : axis[c] / n);
+        const bool has_axis = t == BIOIK_JOINT_REVOLUTE || t == BIOIK_JOINT_PRISMATIC;
+        for (int c = 0; c < 3; c++) joint_axis.push_back(!has_axis || n == 0 ? axis[c] : axis[c] / n);
         joint_mimic.push_back(-1);
         joint_mimic_factor.push_back(1.0);
         joint_mimic_offset.push_back(0.0);
+        auto variable = [&](const std::string& name, double lo, double hi, bool bounded) {
+            variable_names.push_back(name), var_min.push_back(lo), var_max.push_back(hi), var_bounded.push_back(bounded ? 1 : 0), var_max_velocity.push_back(velocity);
+        };
         if (t == BIOIK_JOINT_FIXED) {
             joint_first_variable.push_back(-1);
+        } else if (t == BIOIK_JOINT_FLOATING) {  // MoveIt FloatingJointModel: position unbounded, quaternion components in [-1, 1]
+            joint_first_variable.push_back((int)variable_names.size());
+            for (const char* c : {"trans_x", "trans_y", "trans_z"}) variable(joint_names.back() + "/" + c, -1e300, 1e300, false);
+            for (const char* c : {"rot_x", "rot_y", "rot_z", "rot_w"}) variable(joint_names.back() + "/" + c, -1.0, 1.0, true);
+        } else if (t == BIOIK_JOINT_PLANAR) {  // PlanarJointModel: x, y unbounded, theta in [-pi, pi] and not position-bounded
+            joint_first_variable.push_back((int)variable_names.size());
+            variable(joint_names.back() + "/x", -1e300, 1e300, false), variable(joint_names.back() + "/y", -1e300, 1e300, false);
+            variable(joint_names.back() + "/theta", -M_PI, M_PI, false);
         } else {
             joint_first_variable.push_back((int)variable_names.size());
             variable_names.push_back(joint_names.back());
@@ -106,6 +120,8 @@ public:
         std::vector<double> out(variable_names.size(), 0.0);
         for (size_t v = 0; v < out.size(); v++)
             if (!(var_min[v] <= 0.0 && 0.0 <= var_max[v])) out[v] = 0.5 * (var_min[v] + var_max[v]);
+        for (size_t l = 0; l < joint_type.size(); l++)
+            if (joint_type[l] == BIOIK_JOINT_FLOATING) out[joint_first_variable[l] + 6] = 1.0;  // identity quaternion
         return out;
     }
     bioik_model_desc desc() const {
@@ -148,6 +164,15 @@ public:
             } else if (joint_type[l] == BIOIK_JOINT_PRISMATIC) {
                 double v = positions[joint_first_variable[l]];
                 double j[7] = {joint_axis[3 * l] * v, joint_axis[3 * l + 1] * v, joint_axis[3 * l + 2] * v, 0, 0, 0, 1};
+                concat(cur, j, cur);
+            } else if (joint_type[l] == BIOIK_JOINT_FLOATING) {
+                const double* v = &positions[joint_first_variable[l]];
+                const double n = std::sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5] + v[6] * v[6]);
+                double j[7] = {v[0], v[1], v[2], v[3] / n, v[4] / n, v[5] / n, v[6] / n};
+                concat(cur, j, cur);
+            } else if (joint_type[l] == BIOIK_JOINT_PLANAR) {
+                const double* v = &positions[joint_first_variable[l]];
+                double j[7] = {v[0], v[1], 0, 0, 0, std::sin(0.5 * v[2]), std::cos(0.5 * v[2])};
                 concat(cur, j, cur);
             }
         }

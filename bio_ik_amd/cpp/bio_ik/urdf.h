@@ -6,12 +6,12 @@
 // conventions as the Python reader (bio_ik_amd/urdf.py; tests/test_cpp_urdf.py holds the two against each other):
 //   * links in the order RobotModel::buildRecursive visits them (depth first from the root, children in file order), so link and
 //     variable indices match a MoveIt-loaded model of the same URDF;
-//   * joints: fixed | revolute | continuous | prismatic, <origin xyz rpy>, <axis> (URDF default 1 0 0), <limit lower upper velocity>,
+//   * joints: fixed | revolute | continuous | prismatic | floating | planar, <origin xyz rpy>, <axis> (URDF default 1 0 0), <limit lower upper velocity>,
 //     <mimic joint multiplier offset> (the followed joint may come later in the file); <inertial> mass and origin (BalanceGoal);
 //   * SRDF <group>: <chain base_link tip_link>, <joint name>, <link name> (= its parent joint), nested <group name>; <end_effector
-//     parent_link parent_group> names the tips of a group without a chain; a fixed <virtual_joint> puts `parent_frame` in front of the root.
-// Not read: collision / visual geometry, transmissions, xacro; floating / planar joints (URDF or virtual) are refused here — the C-ABI
-// takes them (include/bioik_hip.h), this flat C++ model does not describe multi-variable joints.
+//     parent_link parent_group> names the tips of a group without a chain; <virtual_joint type = fixed | floating | planar> puts
+//     `parent_frame` in front of the root (the mobile or free-flying base of MoveIt).
+// Not read: collision / visual geometry, transmissions, xacro.
 #pragma once
 #include <algorithm>
 #include <cctype>
@@ -261,8 +261,7 @@ inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const s
     for (const XmlNode* j : root.all("joint")) {
         UrdfJoint u;
         u.name = j->get("name"), u.type = j->get("type");
-        if (u.type == "floating" || u.type == "planar") throw std::runtime_error("joint " + u.name + ": " + u.type + " joints are not described by this C++ model (use the C-ABI arrays)");
-        if (u.type != "fixed" && u.type != "revolute" && u.type != "continuous" && u.type != "prismatic")
+        if (u.type != "fixed" && u.type != "revolute" && u.type != "continuous" && u.type != "prismatic" && u.type != "floating" && u.type != "planar")
             throw std::runtime_error("joint " + u.name + ": unsupported type " + u.type);
         if (!j->child("parent") || !j->child("child")) throw std::runtime_error("joint " + u.name + ": <parent> / <child> missing");
         u.parent = j->child("parent")->get("link"), u.child = j->child("child")->get("link");
@@ -296,12 +295,13 @@ inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const s
         if (!vj.empty()) {
             virt = vj[0];
             if (virt->get("child_link") != roots[0]) throw std::runtime_error("<virtual_joint> child_link " + virt->get("child_link") + " is not the root link " + roots[0]);
-            if (virt->get("type") != "fixed") throw std::runtime_error("<virtual_joint> type " + virt->get("type") + ": only fixed in this C++ model");
+            const std::string vt = virt->get("type");
+            if (vt != "fixed" && vt != "floating" && vt != "planar") throw std::runtime_error("<virtual_joint> type " + vt);
         }
     }
     if (virt) {
         m->addLink(virt->get("parent_frame"), "", "", "fixed", zero, zero, z_axis);
-        m->addLink(roots[0], virt->get("parent_frame"), virt->get("name"), "fixed", zero, zero, z_axis);
+        m->addLink(roots[0], virt->get("parent_frame"), virt->get("name"), virt->get("type"), zero, zero, z_axis);
     } else {
         m->addLink(roots[0], "", "", "fixed", zero, zero, z_axis);
     }

@@ -79,7 +79,8 @@ int main(int argc, char** argv) {
         std::vector<double> target = m->defaultPositions();
         for (size_t k = 0; k < g.active_joints.size(); k++) {
             const int v = m->joint_first_variable[g.active_joints[k]];
-            target[v] = m->var_min[v] + (m->var_max[v] - m->var_min[v]) * (0.3 + 0.05 * (double)k);
+            const bool unbounded = m->var_max[v] - m->var_min[v] > 1e6;  // (x / y of a planar base: a modest displacement; theta stays 0)
+            target[v] = unbounded ? 0.1 * (double)(k + 1) : m->var_min[v] + (m->var_max[v] - m->var_min[v]) * (0.3 + 0.05 * (double)k);
         }
         for (size_t l = 0; l < L; l++)  // mimic joints follow
             if (m->joint_mimic[l] >= 0 && m->joint_first_variable[l] >= 0)
@@ -89,11 +90,13 @@ int main(int argc, char** argv) {
         geometry_msgs::Pose pose;
         pose.position.x = f[0], pose.position.y = f[1], pose.position.z = f[2];
         pose.orientation.x = f[3], pose.orientation.y = f[4], pose.orientation.z = f[5], pose.orientation.w = f[6];
-        std::vector<double> seed(plugin.getJointNames().size(), 0.0), solution;
-        for (size_t k = 0; k < seed.size(); k++) {
-            const int v = m->variableIndex(plugin.getJointNames()[k]);
-            seed[k] = m->defaultPositions()[v];
+        std::vector<int> group_vars;  // the variables behind getJointNames(): 7 / 3 / 1 per floating / planar / other joint
+        for (const std::string& jn : plugin.getJointNames()) {
+            const int j = m->jointIndex(jn), count = m->joint_type[j] == BIOIK_JOINT_FLOATING ? 7 : (m->joint_type[j] == BIOIK_JOINT_PLANAR ? 3 : 1);
+            for (int c = 0; c < count; c++) group_vars.push_back(m->joint_first_variable[j] + c);
         }
+        std::vector<double> seed(group_vars.size(), 0.0), solution;
+        for (size_t k = 0; k < seed.size(); k++) seed[k] = m->defaultPositions()[group_vars[k]];
         moveit_msgs::MoveItErrorCodes err;
         const bool ok = plugin.searchPositionIK(pose, seed, TEST_TIMEOUT, solution, err);
         if (!ok) {
@@ -101,7 +104,11 @@ int main(int argc, char** argv) {
             return 1;
         }
         std::vector<double> reached = m->defaultPositions();
-        for (size_t k = 0; k < solution.size(); k++) reached[m->variableIndex(plugin.getJointNames()[k])] = solution[k];
+        if (solution.size() != group_vars.size()) {
+            std::printf("solution has %zu entries for %zu variables\n", solution.size(), group_vars.size());
+            return 1;
+        }
+        for (size_t k = 0; k < solution.size(); k++) reached[group_vars[k]] = solution[k];
         for (size_t l = 0; l < L; l++)
             if (m->joint_mimic[l] >= 0 && m->joint_first_variable[l] >= 0)
                 reached[m->joint_first_variable[l]] = reached[m->joint_first_variable[m->joint_mimic[l]]] * m->joint_mimic_factor[l] + m->joint_mimic_offset[l];

@@ -63,10 +63,18 @@ def compare(lines, m):
 def run_suite(exe, tmp_path, solve):
     compare(dump(exe, tmp_path, URDF, SRDF), load_urdf(URDF, SRDF))
     compare(dump(exe, tmp_path, URDF_MASS, SRDF_FIXED_BASE), load_urdf(URDF_MASS, SRDF_FIXED_BASE))
+    for vt in ("planar", "floating"):  # the mobile / free-flying base of MoveIt: a multi-variable virtual joint in front of the root
+        srdf = SRDF.replace('<group name="arm_chain">', '<virtual_joint name="world_joint" type="%s" parent_frame="odom" child_link="base"/>'
+                            '<group name="mobile"><joint name="world_joint"/><group name="arm_chain"/></group><group name="arm_chain">' % vt)
+        compare(dump(exe, tmp_path, URDF, srdf), load_urdf(URDF, srdf))
     r = subprocess.run([exe, "--errors"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
     if solve:
         out = dump(exe, tmp_path, URDF, SRDF, "arm_chain", "tool")
+        assert any(l.startswith("solve position error") for l in out)
+        planar = SRDF.replace('<group name="arm_chain">', '<virtual_joint name="world_joint" type="planar" parent_frame="odom" child_link="base"/>'
+                              '<group name="mobile"><joint name="world_joint"/><group name="arm_chain"/></group><group name="arm_chain">')
+        out = dump(exe, tmp_path, URDF, planar, "mobile", "tool")  # a mobile base: three more genes through the plugin mirror
         assert any(l.startswith("solve position error") for l in out)
 
 
