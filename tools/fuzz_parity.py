@@ -69,6 +69,8 @@ def main():
             env["BIOIK_SOLVE_STORE_CHILDREN"] = "0"
         elif rng.random() < 0.35 and "BIOIK_SOLVE_GENERAL" not in env:  # children computed where they are read (round 2), singly or in pairs
             env["BIOIK_SOLVE_COLUMNLESS"] = str(rng.choice(["1", "2"]))
+        if rng.random() < 0.3:  # the solve split over two or more launches (round 2), under whatever mapping was drawn above
+            env["BIOIK_SOLVE_TWO_PHASE"] = str(rng.choice(["1", "2", "3", "1,2", "2,4,6", "init"]))
         kw = {"no_wipeout": int(rng.random() < 0.2)}
         seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=int(rng.integers(1 << 30)), kind=str(rng.choice(["global", "tracking"])))
         p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=int(rng.integers(1 << 30)), mode=mode, fk_mode=fk, islands=islands, **kw)
