@@ -62,6 +62,7 @@ class BioIKKinematicsPlugin {
         if (name == "bio2_memetic") return BIOIK_MODE_BIO2_MEMETIC;
         if (name == "bio2_memetic_l") return BIOIK_MODE_BIO2_MEMETIC_L;
         if (name == "gd_c") return BIOIK_MODE_GD_C;  // src/ik_gradient.cpp:263
+        if (name == "gd") return BIOIK_MODE_GD;      // :253
         if (name == "jac") return BIOIK_MODE_JAC;    // src/ik_gradient.cpp:289
         throw std::runtime_error("unknown solver mode " + name);  // IKFactory::create -> ERROR, src/utils.h:436
     }

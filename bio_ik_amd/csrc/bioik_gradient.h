@@ -153,8 +153,8 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
     bool success = false;
     double final_fit = BIOIK_DBL_MAX;
     for (int step = 0; step < sp.max_steps; step++) {
-        if (sp.solver == 1) {
-            // ---- IKGradientDescent<'c'>::step, ik_gradient.cpp:162-247
+        if (sp.solver != 2) {
+            // ---- IKGradientDescent<'c'>::step (solver 1) / IKGradientDescent<' '>::step (solver 3), ik_gradient.cpp:162-247
             BIOIK_FP_STRICT
             const double jd = 0.0001;
             double g = 0.0;
@@ -193,8 +193,20 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
             double joint_diff = p2 / cost_diff;
             if (!__builtin_isfinite(joint_diff)) joint_diff = 0.0;
             p_wave_sync();
-            for (int k = tid; k < n_ops; k += nth)
-                if ((active_mask >> k) & 1ull) s_sol[k] = clip_op(s_sol[k] - s_grad[k] * joint_diff, k);  // 'c': always accept and continue
+            bool accept = true;  // 'c': always accept and continue (:220-223)
+            if (sp.solver == 3) {  // ' ': has the solution improved? (:225-232) even lanes score the candidate, odd lanes the configuration
+                const bool odd = tid & 1;
+                for (int k = 0; k < n_ops; k++)
+                    xcol[(size_t)k * nth] = (!odd && ((active_mask >> k) & 1ull)) ? clip_op(s_sol[k] - s_grad[k] * joint_diff, k) : s_sol[k];
+                const double fl = fitness_of(xl);
+                if (tid < 2) s_ex[tid] = fl;
+                p_wave_sync();
+                accept = s_ex[0] < s_ex[1];
+                p_wave_sync();
+            }
+            if (accept)
+                for (int k = tid; k < n_ops; k += nth)
+                    if ((active_mask >> k) & 1ull) s_sol[k] = clip_op(s_sol[k] - s_grad[k] * joint_diff, k);
             p_wave_sync();
             {   // update best solution (:246): lane 0 scores the configuration, lane 1 the best one so far
                 const double fv = fitness_of(XV{(tid & 1) ? s_best : s_sol, 1});

@@ -94,6 +94,7 @@ enum {
     /* IKFactory names of reference src/ik_gradient.cpp:254-292 (one island, started at the seed; population / fk_mode are not used) */
     BIOIK_MODE_GD_C = 3,            /* "gd_c": gradient descent by central differences of the exact fitness, linear step estimate,
                                        always continue (ik_gradient.cpp:136-251, if_stuck = 'c')                                   */
+    BIOIK_MODE_GD = 5,              /* "gd":   as gd_c, but a step is kept only if it lowers the fitness (src/ik_gradient.cpp:225-232) */
     BIOIK_MODE_JAC = 4              /* "jac":  pseudo-inverse-Jacobian steps on the twists between the tips and their pose goals
                                        (ik_gradient.cpp:42-133, 269-292)                                                          */
 };

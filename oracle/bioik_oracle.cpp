@@ -402,7 +402,7 @@ struct OrcSolver {
     int rng_mode;
     std::unique_ptr<Evolution2<ReferenceRandom>> ref;
     std::unique_ptr<Evolution2<CounterRandom>> ctr;
-    std::unique_ptr<GradientDescent> gd;   // BIOIK_MODE_GD_C
+    std::unique_ptr<GradientDescent> gd;   // BIOIK_MODE_GD_C, BIOIK_MODE_GD
     std::unique_ptr<JacobianSolver> jac;   // BIOIK_MODE_JAC
     std::vector<double> seed, params;
 };
@@ -417,8 +417,8 @@ void* orc_solver_create(void* problem, const bioik_solve_params* params, int rng
         s->params.assign(goal_params, goal_params + p.param_count);
         s->params.push_back(0.0);
         Query q{s->seed.data(), s->params.data()};
-        if (params->mode == BIOIK_MODE_GD_C) {
-            s->gd.reset(new GradientDescent(&p, *params, 'c'));
+        if (params->mode == BIOIK_MODE_GD_C || params->mode == BIOIK_MODE_GD) {
+            s->gd.reset(new GradientDescent(&p, *params, params->mode == BIOIK_MODE_GD ? ' ' : 'c'));
             s->gd->initialize(q);
         } else if (params->mode == BIOIK_MODE_JAC) {
             s->jac.reset(new JacobianSolver(&p, *params));

@@ -427,8 +427,8 @@ IslandResult run_island_loop(Solver& ik, size_t n_vars, const bioik_solve_params
 template <class Rng>
 IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_params& sp, const Query& q, double timeout_s) {
     const size_t nv = problem->model->vars.size();
-    if (sp.mode == BIOIK_MODE_GD_C) {
-        GradientDescent ik(problem, sp, 'c');
+    if (sp.mode == BIOIK_MODE_GD_C || sp.mode == BIOIK_MODE_GD) {
+        GradientDescent ik(problem, sp, sp.mode == BIOIK_MODE_GD ? ' ' : 'c');
         return run_island_loop(ik, nv, sp, q, timeout_s);
     }
     if (sp.mode == BIOIK_MODE_JAC) {

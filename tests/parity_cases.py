@@ -155,12 +155,12 @@ def point_solvers(h, o, template, n=8, exact_jac=True):
     shared exact-FK arithmetic: identical bits.  jac goes through acos (twist of the pose error), which the device math library and libm
     may round differently: identical where both sides run on the host, to 1e-9 on the device."""
     seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=41, kind="tracking")
-    for mode, budgets in (("gd_c", (1, 6, 20)), ("jac", (1, 3, 10))):
+    for mode, budgets in (("gd_c", (1, 6, 20)), ("gd", (1, 6, 20)), ("jac", (1, 3, 10))):
         for st in budgets:
             p = abi.default_solve_params(mode=mode, max_steps=st)
             a = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
             b = h.solve_batch(p, seeds, params)
-            if mode == "gd_c" or exact_jac:
+            if mode in ("gd_c", "gd") or exact_jac:
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), (mode, st, np.abs(a[0] - b[0]).max())
             else:
                 assert np.abs(a[0] - b[0]).max() < 1e-9 and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), (mode, st)
