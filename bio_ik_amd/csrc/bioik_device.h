@@ -255,6 +255,77 @@ BIOIK_DEV double goal_eval_joint_set_x(ProbPtr pb, int type, int var_op, int var
     return 0.0;
 }
 
+// the same goals for N individuals at once (N independent dependency chains; per individual the operations and their order are those of
+// goal_eval_joint_set_x): the pre-selection scores every child of a generation on its secondary goals, and with the children computed
+// where they are read a gene is a hash, a Gaussian and a clip -- a long chain per gene that one individual at a time leaves exposed
+template <int N, class XA>
+BIOIK_DEV void goal_eval_joint_set_xn(ProbPtr pb, int type, int var_op, int var_seed, double p0, const XA (&x)[N], const lds_f64* seed, double (&out)[N]) {
+    const int n_ops = pb->n_ops;
+    double sum[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) sum[j] = 0.0;
+    switch (type) {
+        case G_AVOID_JOINT_LIMITS:
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
+                    const double mid = (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5, half_span = pb->ops[k].span * 0.5, vw = pb->ops[k].vw;
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        double d = x[j](k) - mid;
+                        d = fmax(0.0, fabs(d) * 2.0 - half_span);
+                        d *= vw;
+                        sum[j] += d * d;
+                    }
+                }
+            break;
+        case G_CENTER_JOINTS:
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
+                    const double mid = (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5, vw = pb->ops[k].vw;
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        double d = x[j](k) - mid;
+                        d *= vw;
+                        sum[j] += d * d;
+                    }
+                }
+            break;
+        case G_REGULARIZATION:
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0) {
+                    const double sv = seed[pb->ops[k].var];
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        double d = x[j](k) - sv;
+                        sum[j] += d * d;
+                    }
+                }
+            break;
+        case G_MINIMAL_DISPLACEMENT:
+            for (int k = 0; k < n_ops; k++)
+                if (pb->ops[k].gene >= 0) {
+                    const double sv = seed[pb->ops[k].var], vw = pb->ops[k].vw;
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        double d = x[j](k) - sv;
+                        d *= vw;
+                        sum[j] += d * d;
+                    }
+                }
+            break;
+        case G_JOINT_VARIABLE:
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const double v = var_op >= 0 ? x[j](var_op) : seed[var_seed];
+                const double d = p0 - v;
+                sum[j] = d * d;
+            }
+            break;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = sum[j];
+}
+
 struct LdsX {  // an op-indexed vector in LDS with its address space spelled out (crosses a call boundary)
     const lds_f64* p;
     int s;
@@ -363,6 +434,28 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XA& x, const QueryCtx& qc) 
         sum += goal_eval<JS_INLINE, XA>(pb, pb->secondary[g].type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x, qc) *
                pb->secondary[g].weight_sq;
     return sum;
+}
+// the same for N individuals at once (see goal_eval_joint_set_xn); per individual: the goals in their order, each weighted as above
+template <int N, class XA>
+BIOIK_DEV void secondary_fitness_n(ProbPtr pb, const XA (&x)[N], const QueryCtx& qc, double (&out)[N]) {
+    const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = 0.0;
+    for (int g = 0; g < pb->n_secondary; g++) {
+        const int type = pb->secondary[g].type;
+        const double w = pb->secondary[g].weight_sq;
+        double e[N];
+        if (type == G_AVOID_JOINT_LIMITS || type == G_CENTER_JOINTS || type == G_REGULARIZATION || type == G_MINIMAL_DISPLACEMENT || type == G_JOINT_VARIABLE) {
+            const double* P = qc.par + pb->secondary[g].param_off;
+            goal_eval_joint_set_xn<N>(pb, type, pb->secondary[g].var_op, pb->secondary[g].var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, x, (const lds_f64*)qc.seed, e);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; j++)
+                e[j] = goal_eval<true, XA>(pb, type, pb->secondary[g].var_op, pb->secondary[g].var_seed, qc.par + pb->secondary[g].param_off, zero, x[j], qc);
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) out[j] += e[j] * w;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -410,12 +410,36 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 int n_eval = lambda;
                 if (has_sec) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
-                    for (int c = gtid; c < lambda; c += G) {
-                        if (columnless) {
-                            s_sec[c] = secondary_fitness<true>(pb, make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d), qc);
-                        } else {
-                            reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
-                            s_sec[c] = secondary_fitness<true>(pb, xl, qc);
+                    if (columnless && lambda >= 4 * G) {  // four children per lane and trip: four independent hash -> Gaussian -> clip -> cost chains
+                        for (int c = gtid; c < lambda; c += 4 * G) {
+                            int cj[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) cj[j] = c + j * G < lambda ? c + j * G : c;  // (a tail repeats the first child and drops it)
+                            const ChildX<PB> cx[4] = {make_child_x(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, p0d, p1d),
+                                                      make_child_x(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, p0d, p1d)};
+                            double e[4];
+                            secondary_fitness_n<4>(pb, cx, qc, e);
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (c + j * G < lambda) s_sec[c + j * G] = e[j];
+                        }
+                    } else if (columnless && lambda >= 2 * G) {
+                        for (int c = gtid; c < lambda; c += 2 * G) {
+                            const int c1 = c + G < lambda ? c + G : c;
+                            const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
+                            double e[2];
+                            secondary_fitness_n<2>(pb, cx, qc, e);
+                            s_sec[c] = e[0];
+                            if (c + G < lambda) s_sec[c + G] = e[1];
+                        }
+                    } else {
+                        for (int c = gtid; c < lambda; c += G) {
+                            if (columnless) {
+                                s_sec[c] = secondary_fitness<true>(pb, make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d), qc);
+                            } else {
+                                reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, xcol, nth, nullptr, 0);
+                                s_sec[c] = secondary_fitness<true>(pb, xl, qc);
+                            }
                         }
                     }
                     // ascending by (secondary fitness, child index) -- the order of a stable sort -- with a bitonic network over the next power

@@ -87,6 +87,16 @@ def test_trajectory_workgroup_mappings(sims, oracles, templates, monkeypatch, en
     pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
+@pytest.mark.parametrize("pop", [70, 130])
+def test_preselection_with_computed_children_several_per_lane(sims, oracles, templates, monkeypatch, pop):
+    """pre-selection on the secondary goals with the children computed where they are read, two (pop=70 on 32-lane groups) and four (pop=130)
+    children per lane and trip, each with a ragged last trip; the bitonic order of a non-power-of-two population"""
+    for k, v in {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "1"}.items():
+        monkeypatch.setenv(k, v)
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=pop, steps_list=(2,))
+    pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=pop, steps_list=(1,))
+
+
 @pytest.mark.parametrize("env", [
     {"BIOIK_SOLVE_TWO_PHASE": "1"},
     {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},
