@@ -573,7 +573,24 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         };
                         if (k0 < n_ops) take(k0);
                         if (n_ops > 32 && k0 + 32 < n_ops) take(k0 + 32);  // (at most 64 ops)
-                    } else if (k0 == 0) {  // not stored: re-derive the child from the counter RNG
+                    } else if (LEAN) {
+                        // not stored: the winner is re-derived from the counter RNG, lane k its op k (the operations of reproduce_children per gene;
+                        // one lane doing all of them was 7 % of a C3 step)
+                        BIOIK_FP_STRICT
+                        const int c = has_sec ? s_order[id - 2] : id - 2;
+                        const ChildX<PB> cx = make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d);
+                        auto derive = [&](int k) {
+                            const double gene = cx(k);
+                            double mom = 0.0;
+                            if ((active_mask >> k) & 1ull) {
+                                const double parent_gradient = p0d[k] * (1.0 - cx.fmix) + p1d[k] * cx.fmix;
+                                mom = parent_gradient * (1.0 - 0.3) + (gene - p0g[k]) * 0.3;
+                            }
+                            dst[k] = gene, dst[M + k] = mom;
+                        };
+                        if (k0 < n_ops) derive(k0);
+                        if (n_ops > 32 && k0 + 32 < n_ops) derive(k0 + 32);  // (at most 64 ops)
+                    } else if (k0 == 0) {  // general flavour: quaternion genes are renormalised over the whole vector (reproduce_children)
                         int c = has_sec ? s_order[id - 2] : id - 2;
                         reproduce_child(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d, dst, 1, dst + M, 1);
                     }
