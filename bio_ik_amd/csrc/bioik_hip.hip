@@ -333,6 +333,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
         sp.child_pairs = cands[best].pairs;
         sp.columnless = cands[best].columnless;
+        // Problems with secondary goals score only a random prefix of the pre-selected children, so the phases besides the chain walk (the
+        // pre-selection itself, selection, the memetic phase) weigh more; with both species of a query on the halves of ONE wavefront those
+        // run once for the two.  Measured: C3 (128 children per species) +14 %, C4 (512: sixteen children per lane) -22 % (tools/c34_mapping_probe.sh).
+        if (sp.columnless && dp.n_secondary > 0 && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
+            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact) * kCuWaves <= 160 * 1024) {
+            nth = 64, sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1;
+        }
     } else {
         while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2, 1, exact) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
         // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
