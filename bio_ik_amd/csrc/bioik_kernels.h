@@ -561,7 +561,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         const int r = id - 2;
                         const int c = has_sec ? s_order[r] : r;
                         const double fmix = (((uint32_t)c + 2u) % 2u == 0u) ? 0.2 : 0.0;
-                        const double* src = (lds + L.xcol) + (size_t)(r / G) * M * nth + (grp * G + r % G);
+                        // (column r / G, lane r % G of the group; the group sizes the launcher produces are powers of two: no integer division)
+                        const int r_col = (G & (G - 1)) == 0 ? r >> (31 - __builtin_clz((unsigned)G)) : r / G, r_lane = r - r_col * G;
+                        const double* src = (lds + L.xcol) + (size_t)r_col * M * nth + (grp * G + r_lane);
                         auto take = [&](int k) {
                             double gene = src[(size_t)k * nth];
                             double mom = 0.0;

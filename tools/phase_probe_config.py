@@ -1,5 +1,5 @@
 """Per-phase shader cycles of a solve of C3 / C4 (profiling build: hipcc ... -DBIOIK_PHASE_TIMING -o build/libphase.so).
-usage: BIOIK_HIP_LIBRARY=build/libphase.so python tools/phase_probe_config.py [c2|c3|c4] [queries]"""
+usage: BIOIK_HIP_LIBRARY=build/libphase.so python tools/phase_probe_config.py [c2|ref|c3|c4] [queries]"""
 import os
 import sys
 
@@ -20,13 +20,15 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 3072
     if cfg == "c2":
         t, pop, steps = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")]), 128, 32
+    elif cfg == "ref":  # C2 at the reference's own parameters: 16 children per species, linearised phenotypes
+        t, pop, steps = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")]), 16, 32
     elif cfg == "c3":
         t, pop, steps = ProblemTemplate(pr2_like(), "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]), 128, 16
     else:
         t, pop, steps = ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]), 512, 8
     h = HipSolver(t, device=0)
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=5)
-    p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=1)
+    p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=1, fk_mode=abi.FK_LINEAR if cfg == "ref" else abi.FK_EXACT)
     p.dtwist = 1e-300  # no query may succeed: every workgroup runs the whole budget
     path = "/tmp/phase_%s.bin" % cfg
     os.environ["BIOIK_PHASE_DUMP"] = path
