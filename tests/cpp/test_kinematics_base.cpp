@@ -21,6 +21,8 @@
 #ifndef TEST_TIMEOUT
 #define TEST_TIMEOUT 0.25
 #endif
+// budget of the solves that cannot succeed (an unreachable pose): a fifth of it on a GPU, two seconds of wall clock on the host simulator
+#define TEST_FAR_TIMEOUT (TEST_TIMEOUT > 10.0 ? 2.0 : TEST_TIMEOUT * 0.2)
 
 #define CHECK(c)                                                        \
     do {                                                                \
@@ -158,12 +160,12 @@ int main(int argc, char** argv) {
     far.position.x = far.position.y = far.position.z = 5.0;
     {
         const auto t0 = std::chrono::steady_clock::now();
-        CHECK(!solver->searchPositionIK(far, seeds[0], TEST_TIMEOUT * 0.2, solution, code) && code.val == code.NO_IK_SOLUTION);
+        CHECK(!solver->searchPositionIK(far, seeds[0], TEST_FAR_TIMEOUT, solution, code) && code.val == code.NO_IK_SOLUTION);
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::printf("unreachable goal, timeout %.3f s: returned after %.3f s\n", TEST_TIMEOUT * 0.2, dt);
+        std::printf("unreachable goal, timeout %.3f s: returned after %.3f s\n", TEST_FAR_TIMEOUT, dt);
         kinematics::KinematicsQueryOptions approx;
         approx.return_approximate_solution = true;
-        CHECK(solver->searchPositionIK(far, seeds[0], TEST_TIMEOUT * 0.2, solution, code, approx) && code.val == code.SUCCESS && solution.size() == 7);
+        CHECK(solver->searchPositionIK(far, seeds[0], TEST_FAR_TIMEOUT, solution, code, approx) && code.val == code.SUCCESS && solution.size() == 7);
     }
     // the goal (cost) plugin interface: caller-supplied goals, replacing the default pose goal (:540-556); fixed joints (:104-114)
     {
