@@ -764,8 +764,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             } else {
                                 const bool accept = vprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
                                 // (a half-wave group shares its wavefront with the other species: it stays in step with it and merely
-                                // repeats the rejected iteration, which changes nothing)
-                                if (G >= 64 && !accept) descending = false;
+                                // repeats the rejected iteration, which changes nothing -- until the other species has stopped as well)
+                                if (G >= 64 ? !accept : p_ballot(accept) == 0ull) descending = false;
                                 if (accept)
                                     for (int k = gtid; k < n_ops; k += Gw) el[k] = s_x4[k];
                                 p_wave_sync();

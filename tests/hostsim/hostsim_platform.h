@@ -57,6 +57,16 @@ BIOIK_DEV T p_row_mirror(T v) {
     return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))));
 }
 BIOIK_DEV int p_uniform(int v) { return v; }
+BIOIK_DEV unsigned long long p_ballot(bool pred) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)
+    const int w = sim::tid >> 6, l = sim::tid & 63;
+    uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
+    x[l] = pred ? 1u : 0u;
+    sim::blk->wave_bar[w]->arrive_and_wait();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) m |= (unsigned long long)x[i] << i;
+    sim::blk->wave_bar[w]->arrive_and_wait();
+    return m;
+}
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
 unsigned long long sim_wall_clock();  // 100 MHz ticks of a steady host clock (defined with the simulator's back end)
 BIOIK_DEV unsigned long long p_wall_clock() { return sim_wall_clock(); }
