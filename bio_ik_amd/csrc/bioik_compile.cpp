@@ -519,6 +519,26 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     dev.genes_follow_ops = 1;
     for (int i = 1; i < D; i++)
         if (dev.op_of_gene[i] <= dev.op_of_gene[i - 1]) dev.genes_follow_ops = 0;
+    // sparsity classes of the revolute ops' constants (bioik_types.h: BIOIK_POS_*, BIOIK_ROT_*): exact zeros only, so the terms the
+    // walk drops are exact no-ops of the general transform
+    for (size_t k = 0; k < ops.size(); k++) {
+        DevOp& op = ops[k];
+        op.pos_kind = BIOIK_POS_GENERAL, op.rot_kind = BIOIK_ROT_GENERAL;
+#ifndef BIOIK_NO_SPARSE_OPS
+        if (op.type != BIOIK_OP_REVOLUTE) continue;
+        const bool zx = op.cpos[0] == 0.0, zy = op.cpos[1] == 0.0, zz = op.cpos[2] == 0.0;
+        if (zx && zy && zz) op.pos_kind = BIOIK_POS_ZERO;
+        else if (zy && zz) op.pos_kind = BIOIK_POS_X;
+        else if (zx && zz) op.pos_kind = BIOIK_POS_Y;
+        else if (zx && zy) op.pos_kind = BIOIK_POS_Z;
+        if (op.ca[0] == 0.0 && op.ca[1] == 0.0 && op.ca[2] == 0.0 && op.ca[3] == 1.0 && op.cb[3] == 0.0) {
+            const bool bx = op.cb[0] == 0.0, by = op.cb[1] == 0.0, bz = op.cb[2] == 0.0;
+            if (by && bz && !bx) op.rot_kind = BIOIK_ROT_X;
+            else if (bx && bz && !by) op.rot_kind = BIOIK_ROT_Y;
+            else if (bx && by && !bz) op.rot_kind = BIOIK_ROT_Z;
+        }
+#endif
+    }
     for (size_t k = 0; k < ops.size(); k++) {
         dev.ops[k] = ops[k];
         if (ops[k].gene >= 0) dev.active_mask |= 1ull << k;

@@ -68,6 +68,80 @@ BIOIK_DEV Q4 qmul(Q4 p, Q4 q) {
 BIOIK_DEV F7 f7_concat(const F7& a, const F7& b) { return F7{a.p + qrot(a.q, b.p), qmul(a.q, b.q)}; }
 
 // ---------------------------------------------------------------------------------------------------------
+// A revolute joint applied to the running frame f:  f.p += f.q * cpos,  f.q = f.q (x) (cs * ca + sn * cb)
+// (forward_kinematics.h:89-112, :331-354 with the fixed links folded into (cpos, ca), bioik_types.h).  The general form costs
+// 21 + 8 + 16 FP64 instructions.  pos_kind / rot_kind (wavefront-uniform, from the problem compiler) name the constants that
+// are exact zeros; a dropped term is `x * 0 + y`, which IS y, so every branch below returns the numbers of the general form
+// (up to the sign of an exact zero).  Derivation: bk_qrot / bk_qmul of bioik_fused.h with the zero operands struck out, and
+// `p + (2 r + 0)` written as the single rounding fma(2, r, p) (doubling is exact).
+// ---------------------------------------------------------------------------------------------------------
+template <int AXIS>  // v = cpos[AXIS] on axis AXIS, the other two components are zero
+BIOIK_DEV void revolute_pos_axis(F7& f, double v) {
+    const Q4 q = f.q;
+    if constexpr (AXIS == 0) {
+        const double ty = q.z * v, tz = -(q.y * v);
+        const double rx = BK_FMA(q.y, tz, -(q.z * ty)), ry = BK_FMA(q.w, ty, -(q.x * tz)), rz = BK_FMA(q.w, tz, q.x * ty);
+        f.p = V3{f.p.x + BK_FMA(2.0, rx, v), BK_FMA(2.0, ry, f.p.y), BK_FMA(2.0, rz, f.p.z)};
+    } else if constexpr (AXIS == 1) {
+        const double tx = -(q.z * v), tz = q.x * v;
+        const double rx = BK_FMA(q.w, tx, q.y * tz), ry = BK_FMA(q.z, tx, -(q.x * tz)), rz = BK_FMA(q.w, tz, -(q.y * tx));
+        f.p = V3{BK_FMA(2.0, rx, f.p.x), f.p.y + BK_FMA(2.0, ry, v), BK_FMA(2.0, rz, f.p.z)};
+    } else {
+        const double tx = q.y * v, ty = -(q.x * v);
+        const double rx = BK_FMA(q.w, tx, -(q.z * ty)), ry = BK_FMA(q.w, ty, q.z * tx), rz = BK_FMA(q.x, ty, -(q.y * tx));
+        f.p = V3{BK_FMA(2.0, rx, f.p.x), BK_FMA(2.0, ry, f.p.y), f.p.z + BK_FMA(2.0, rz, v)};
+    }
+}
+template <int AXIS>  // local rotation (a e_AXIS, c): unrotated constant frame, joint axis on a coordinate axis; a = sn * cb[AXIS], c = cs
+BIOIK_DEV void revolute_rot_axis(F7& f, double a, double c) {
+    const Q4 p = f.q;
+    if constexpr (AXIS == 0)
+        f.q = Q4{BK_FMA(p.w, a, p.x * c), BK_FMA(p.y, c, p.z * a), BK_FMA(p.z, c, -(p.y * a)), BK_FMA(p.w, c, -(p.x * a))};
+    else if constexpr (AXIS == 1)
+        f.q = Q4{BK_FMA(p.x, c, -(p.z * a)), BK_FMA(p.w, a, p.y * c), BK_FMA(p.z, c, p.x * a), BK_FMA(p.w, c, -(p.y * a))};
+    else
+        f.q = Q4{BK_FMA(p.x, c, p.y * a), BK_FMA(p.y, c, -(p.x * a)), BK_FMA(p.w, a, p.z * c), BK_FMA(p.w, c, -(p.z * a))};
+}
+struct RevConst {  // the constants of one revolute op as the walk holds them (scalar registers)
+    double cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3;
+    int pos_kind, rot_kind;
+};
+// N individuals through the same joint: the branches are wavefront-uniform, the constants stay scalar operands
+template <int N>
+BIOIK_DEV void revolute_apply(F7 (&f)[N], const double (&sn)[N], const double (&cs)[N], const RevConst& k) {
+    // position first: it reads the frame's rotation in front of the joint
+    if (k.pos_kind == BIOIK_POS_GENERAL) {
+#pragma unroll
+        for (int j = 0; j < N; j++) f[j].p = f[j].p + qrot(f[j].q, v3(k.cp0, k.cp1, k.cp2));
+    } else if (k.pos_kind == BIOIK_POS_X) {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_pos_axis<0>(f[j], k.cp0);
+    } else if (k.pos_kind == BIOIK_POS_Y) {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_pos_axis<1>(f[j], k.cp1);
+    } else if (k.pos_kind == BIOIK_POS_Z) {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_pos_axis<2>(f[j], k.cp2);
+    }  // BIOIK_POS_ZERO: the joint sits at its parent's origin
+    if (k.rot_kind == BIOIK_ROT_GENERAL) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const Q4 lq = Q4{BK_FMA(cs[j], k.ca0, sn[j] * k.cb0), BK_FMA(cs[j], k.ca1, sn[j] * k.cb1), BK_FMA(cs[j], k.ca2, sn[j] * k.cb2), BK_FMA(cs[j], k.ca3, sn[j] * k.cb3)};
+            f[j].q = qmul(f[j].q, lq);
+        }
+    } else if (k.rot_kind == BIOIK_ROT_X) {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_rot_axis<0>(f[j], sn[j] * k.cb0, cs[j]);
+    } else if (k.rot_kind == BIOIK_ROT_Y) {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_rot_axis<1>(f[j], sn[j] * k.cb1, cs[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; j++) revolute_rot_axis<2>(f[j], sn[j] * k.cb2, cs[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Counter-based RNG: Philox2x32-10 (Salmon et al., SC'11; Random123 constants) with integer-only
 // post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
@@ -481,8 +555,9 @@ BIOIK_DEV F7 multi_joint_values(int type, const XV& x, int val_first) {
     return v;
 }
 BIOIK_DEV void multi_joint_bump(F7& v, int i, double step) {  // variable i += step (forward difference of the Jacobian, :695-726)
-    double* p = i < 3 ? (i == 0 ? &v.p.x : i == 1 ? &v.p.y : &v.p.z) : (i == 3 ? &v.q.x : i == 4 ? &v.q.y : i == 5 ? &v.q.z : &v.q.w);
-    *p = *p + step;
+    // (selects, not a pointer into the frame: an address-taken F7 lives in scratch memory)
+    v.p.x = i == 0 ? v.p.x + step : v.p.x, v.p.y = i == 1 ? v.p.y + step : v.p.y, v.p.z = i == 2 ? v.p.z + step : v.p.z;
+    v.q.x = i == 3 ? v.q.x + step : v.q.x, v.q.y = i == 4 ? v.q.y + step : v.q.y, v.q.z = i == 5 ? v.q.z + step : v.q.z, v.q.w = i >= 6 ? v.q.w + step : v.q.w;
 }
 BIOIK_DEV F7 multi_joint_frame(int type, const F7& v) {
     if (type == BIOIK_OP_FLOATING) {
@@ -571,15 +646,15 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
             } else if (k > 0 && src < 0) {
                 f = f7_identity();
             }
-            {
-                // (selects, not a branch: this single-genotype walk is unrolled over BIOIK_FK_BLOCK joints, and a branch per joint
-                // with its own copy of the transform measured 5-9 % slower on the LDS-heavy problems that use it; fk_walk_n branches)
-                const bool rev = type == BIOIK_OP_REVOLUTE;
-                const double s = rev ? sn[j] : 0.0, c = rev ? cs[j] : 1.0, xp = rev ? 0.0 : xv[j];
-                const Q4 lq = Q4{BK_FMA(c, ca0, s * cb0), BK_FMA(c, ca1, s * cb1), BK_FMA(c, ca2, s * cb2), BK_FMA(c, ca3, s * cb3)};
-                const V3 lp = v3(BK_FMA(xp, cb0, cp0), BK_FMA(xp, cb1, cp1), BK_FMA(xp, cb2, cp2));
+            if (type == BIOIK_OP_REVOLUTE) {  // (wavefront-uniform: a scalar branch)
+                F7 fj[1] = {f};
+                const double s1[1] = {sn[j]}, c1[1] = {cs[j]};
+                revolute_apply<1>(fj, s1, c1, RevConst{cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3, pb->ops[k].pos_kind, pb->ops[k].rot_kind});
+                f = fj[0];
+            } else {
+                const V3 lp = v3(BK_FMA(xv[j], cb0, cp0), BK_FMA(xv[j], cb1, cp1), BK_FMA(xv[j], cb2, cp2));
                 f.p = f.p + qrot(f.q, lp);
-                f.q = qmul(f.q, lq);
+                f.q = qmul(f.q, Q4{ca0, ca1, ca2, ca3});
             }
             if (ss >= 0) {
                 double* sl = slots + (size_t)ss * 7 * nth + tid;
@@ -679,6 +754,7 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
         const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
+        const int pk = pb->ops[k].pos_kind, rk = pb->ops[k].rot_kind;
         const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
         const int msrc = pb->ops[k].mimic_src;
         const double mf = pb->ops[k].mimic_factor, mo = pb->ops[k].mimic_offset;
@@ -706,12 +782,7 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
             double sn[N], cs[N];
 #pragma unroll
             for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const Q4 lq = Q4{BK_FMA(cs[j], ca0, sn[j] * cb0), BK_FMA(cs[j], ca1, sn[j] * cb1), BK_FMA(cs[j], ca2, sn[j] * cb2), BK_FMA(cs[j], ca3, sn[j] * cb3)};
-                f[j].p = f[j].p + qrot(f[j].q, v3(cp0, cp1, cp2));
-                f[j].q = qmul(f[j].q, lq);
-            }
+            revolute_apply<N>(f, sn, cs, RevConst{cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3, pk, rk});
         } else {
 #pragma unroll
             for (int j = 0; j < N; j++) {

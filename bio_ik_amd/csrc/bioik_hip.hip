@@ -373,6 +373,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (std::getenv("BIOIK_SOLVE_REPORT")) {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
                                         groups, sp.child_pairs ? 2 : 1);
+        int n_rev = 0, n_pos = 0, n_rot = 0;  // revolute ops and how many of them the walk takes through a sparse form
+        for (int k = 0; k < dp.n_chain_ops; k++)
+            if (dp.ops[k].type == BIOIK_OP_REVOLUTE) n_rev++, n_pos += dp.ops[k].pos_kind != BIOIK_POS_GENERAL, n_rot += dp.ops[k].rot_kind != BIOIK_ROT_GENERAL;
+        std::fprintf(stderr, "[bioik] joint program: %d revolute ops, sparse position %d, sparse rotation %d\n", n_rev, n_pos, n_rot);
         std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d columnless %d | LDS %zu B "
                      "(genotype columns %d, parked frames %d, per-group %d x %d) -> %d workgroups = %d wavefronts per CU\n",
                      dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, sp.columnless, lds, (L.slots - L.xcol) * 8,

@@ -209,6 +209,35 @@ struct SpeciesState {
     int ok;           // success test of the first elite (it is what becomes the solution when the species leads)
 };
 
+// The lane numbers of one phase of solve_body and everything derived from them -- the species group's scratch pointers, the lane's
+// genotype column -- declared from FRESH copies of the lane numbers (p_fresh, bioik_platform.h): a phase that opens a scope with this
+// computes its LDS addresses where it uses them instead of inheriting them from in front of the step loop, where the compiler had
+// parked them in scratch memory (r02: 36 spilled VGPRs, every one of them an address of this kind).
+#define BIOIK_LANE_SCOPE                                                                                                            \
+    const int tid = p_fresh(tid0), grp = p_fresh(grp0), gtid = p_fresh(gtid0);                                                       \
+    double* const gbase = lds + L.g_first + grp * L.g_stride; /* this group's scratch */                                            \
+    double* const s_xn = gbase + L.xn;                                                                                              \
+    double* const s_gv = gbase + L.gv;                                                                                              \
+    double* const s_frames = gbase + L.frames;                                                                                      \
+    double* const s_tips = gbase + L.tips;                                                                                          \
+    double* const s_delta = gbase + L.delta;                                                                                        \
+    double* const s_base = gbase + L.base;                                                                                          \
+    double* const s_grad = gbase + L.grad;                                                                                          \
+    double* const s_xm = gbase + L.xm;                                                                                              \
+    double* const s_xp = gbase + L.xp;                                                                                              \
+    double* const s_dv = gbase + L.dv;                                                                                              \
+    double* const s_fc = gbase + L.fc;                                                                                              \
+    double* const s_red = gbase + L.red;                                                                                            \
+    double* const s_sec = gbase + L.sec;                                                                                            \
+    int32_t* const s_order = (int32_t*)(gbase + L.order);                                                                           \
+    double* const s_bc = gbase + L.bc; /* values broadcast from the group's leading wavefront */                                    \
+    double* const xcol = lds + L.xcol + tid; /* this lane's genotype column(s): [col][op][lane], stride nth */                      \
+    const XV xl{xcol, nth};                                                                                                         \
+    const LinModel lm{s_tips, s_delta, s_base};                                                                                     \
+    const bool glead = gtid < 64, wlead = tid < 64
+#define BIOIK_EPILOGUE_SCOPE_BEGIN { BIOIK_LANE_SCOPE;
+#define BIOIK_EPILOGUE_SCOPE_END }
+
 // LEAN: the flavour without floating / planar joints (see pb_flavour); the launcher picks it whenever the problem allows.
 // CL: children computed where they are read (no genotype columns, sp.columnless) — a kernel of its own, so that the accessor-templated
 // copies of the chain walk do not weigh on the register allocation of the column kernels (with both in one kernel the lean flavour
@@ -225,7 +254,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
-    const int tid = p_tid(), nth = p_nthreads(), lane = tid & 63;
+    const int tid0 = p_tid(), nth = p_nthreads();
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
@@ -239,7 +268,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
     const int groups = sp.species_parallel ? 2 : 1;
     const int G = nth / groups;        // lanes per species group (a multiple of 64)
-    const int grp = tid / G, gtid = tid - grp * G;
+    const int grp0 = tid0 / G, gtid0 = tid0 - grp0 * G;
     const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, sp.child_pairs ? 2 : 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
@@ -248,25 +277,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double* s_prefix = lds + L.prefix;
     double* s_state = lds + L.state;
     double* s_slots = lds + L.slots;
-    double* gbase = lds + L.g_first + grp * L.g_stride;  // this group's scratch
-    double* s_xn = gbase + L.xn;
-    double* s_gv = gbase + L.gv;
-    double* s_frames = gbase + L.frames;
-    double* s_tips = gbase + L.tips;
-    double* s_delta = gbase + L.delta;
-    double* s_base = gbase + L.base;
-    double* s_grad = gbase + L.grad;
-    double* s_xm = gbase + L.xm;
-    double* s_xp = gbase + L.xp;
-    double* s_dv = gbase + L.dv;
-    double* s_fc = gbase + L.fc;
     double* s_clip = lds + L.clip;
-    double* s_red = gbase + L.red;
-    double* s_sec = gbase + L.sec;
-    int32_t* s_order = (int32_t*)(gbase + L.order);
     const int M = n_ops > 0 ? n_ops : 1;
-    double* xcol = lds + L.xcol + tid;  // this lane's genotype column(s): [col][op][lane], stride nth
-    const XV xl{xcol, nth};
+    BIOIK_LANE_SCOPE;  // (the initialisation's own; every phase of the step loop opens a new one)
     const int SP = 2 * 2 * 2 * M;  // doubles per species in s_pop
     const int BF = 4 * M;          // doubles per buffer: [ind0 genes][ind0 momentum][ind1 genes][ind1 momentum]
 
@@ -277,15 +290,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     for (int i = tid; i < P; i += nth) s_par[i] = a.params[q * P + i];
     p_barrier();
     const QueryCtx qc{s_seed, s_par};
-    const LinModel lm{s_tips, s_delta, s_base};
     const uint32_t key = rng_query_key(sp.random_seed, sp.first_query + q, island);
     // Values every lane needs but one wavefront can compute (fitness of an elite, of the solution ...): the leading
     // wavefront of the species group / of the workgroup evaluates and publishes through LDS; the other wavefronts sleep
     // at the barrier instead of spending issue slots of their SIMDs on identical copies.
-    double* s_bc = gbase + L.bc;
     double* s_wbc = s_state + 16;
-    const bool glead = gtid < 64, wlead = tid < 64;
-    auto group_value = [&](auto&& fn) -> double {
+    // (the lane numbers and the group's broadcast slot are arguments: the caller's phase passes its own, see BIOIK_LANE_SCOPE)
+    auto group_value = [&](bool glead, int gtid, double* s_bc, auto&& fn) -> double {
         double v = 0.0;
         if (glead) v = fn();
         if (G > 64) {
@@ -296,7 +307,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
         return v;
     };
-    auto group_check = [&](const XV& x) -> FitCheck {  // exact fitness + success test of a group's vector, known to the whole group
+    auto group_check = [&](bool glead, int gtid, double* s_bc, const XV& x) -> FitCheck {  // exact fitness + success test of a group's vector, known to the whole group
         FitCheck fc{0.0, 0};
         if (glead) fc = exact_fitness_check(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
         if (G > 64) {
@@ -308,7 +319,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
         return fc;
     };
-    auto wg_check = [&](const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
+    auto wg_check = [&](bool wlead, int tid, const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
         FitCheck fc{0.0, 0};
         if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);
         if (nth > 64) {
@@ -351,7 +362,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     }
     // the seed is the first solution; whether it already satisfies the goals is what the first success test will find
     FitCheck fc0{0.0, 0};
-    if (!resume) fc0 = wg_check(XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
+    if (!resume) fc0 = wg_check(wlead, tid, XV{s_sol, 1}, sp.dpos, sp.drot, sp.dtwist, 1);
     double* s_solst = s_state + 20;  // [0] fitness, [1] success flag of the current solution
     const double sol_fit = fc0.fitness;
     // The bookkeeping of the two species lives in LDS between the phases of a step (s_state[rank][8], rank 0 = the leading species of
@@ -371,21 +382,18 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         s_solst[0] = sol_fit, s_solst[1] = (double)fc0.ok;
     }
     p_barrier();
-    const int rank_begin = groups == 2 ? grp : 0, rank_end = groups == 2 ? grp + 1 : 2;
+    const int rank_begin = groups == 2 ? grp0 : 0, rank_end = groups == 2 ? grp0 + 1 : 2;
     PHASE_MARK(PH_INIT);
 
     // ik_parallel.h:160: the caller's timeout bounds the call, not the query.  The launch's clock starts when its first workgroup
     // does (one compare-and-swap per workgroup on a word the host zeroed); lane 0 reads the clock once per step and the verdict
     // crosses LDS, so that every wavefront of the workgroup leaves the loop in the same step.
-    unsigned long long deadline = 0ull;
+    double* s_deadline = s_state + 22;  // the deadline on the device clock as two exact halves (the slots are doubles); only lane 0 reads it
     if (sp.timeout_ticks != 0ull) {
         if (tid == 0) {
-            const unsigned long long t0 = p_stamp_once(a.launch_clock, p_wall_clock());
-            s_wbc[2] = (double)(t0 >> 32), s_wbc[3] = (double)(t0 & 0xffffffffull);  // (two exact halves: the slots are doubles)
+            const unsigned long long t1 = p_stamp_once(a.launch_clock, p_wall_clock()) + sp.timeout_ticks;
+            s_deadline[0] = (double)(t1 >> 32), s_deadline[1] = (double)(t1 & 0xffffffffull);
         }
-        p_barrier();
-        deadline = (((unsigned long long)s_wbc[2] << 32) | (unsigned long long)s_wbc[3]) + sp.timeout_ticks;
-        p_barrier();
     }
     int steps = a.step_begin;
     bool success = false, expired = false;
@@ -397,12 +405,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             double* popS = s_pop + S.slot * SP;
             if (!exact) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
+                BIOIK_LANE_SCOPE;
                 const double* cb = popS + S.cur * BF;
                 build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);
-                S.pf0 = group_value([&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
-                S.pf1 = group_value([&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
+                S.pf0 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
+                S.pf1 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
             }
             for (int gen = 0; gen < sp.generations; gen++) {
+                BIOIK_LANE_SCOPE;
                 const double* cb = popS + S.cur * BF;
                 const double *p0g = cb, *p0d = cb + M, *p1d = cb + 3 * M;
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
@@ -546,6 +556,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its ops k, k + 32
                 double* nb = popS + (S.cur ^ 1) * BF;
                 for (int pass = 0; pass < (G >= 64 ? 1 : 2); pass++) {  // a half-wave group has 32 lanes: one winner per pass
+                    BIOIK_LANE_SCOPE;
                     if (gtid >= 64) break;
                     const int i = G >= 64 ? gtid >> 5 : pass, k0 = gtid & 31;
                     const int id = i == 0 ? first.id : second.id;
@@ -619,6 +630,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             // Hand-overs are LDS writes and reads of one wavefront in program order (p_wave_sync): no s_barrier inside the phase, so a
             // species stops as soon as a candidate is rejected, whatever the other species' wavefront is doing.
             if (sp.memetic) {
+                BIOIK_LANE_SCOPE;
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
                 if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);  // fresh linearisation at the elite
@@ -781,17 +793,19 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             // (problem.cpp:259-341): if the species leads and improves on the solution, this elite IS the new solution, so the
             // island loop's success test (ik_parallel.h:173-181) needs no walk of its own.
             {
+                BIOIK_LANE_SCOPE;
                 const double* cb = popS + S.cur * BF;
-                const FitCheck fc = group_check(XV{cb, 1});
+                const FitCheck fc = group_check(glead, gtid, s_bc, XV{cb, 1});
                 S.improved = (fc.fitness != S.fit) ? 1 : 0;
                 S.fit = fc.fitness;
                 S.pf0 = fc.fitness;
                 S.ok = fc.ok;
                 PHASE_MARK(PH_RANK);
             }
-            if (gtid == 0) species_store(rank, S);
+            if (p_fresh(gtid0) == 0) species_store(rank, S);
         }
         p_barrier();  // both species are ranked and their bookkeeping is in LDS
+        BIOIK_LANE_SCOPE;  // species management and the checks at the end of the step
 
         // species management (:617-645)
         SpeciesState A = species_load(0), B = species_load(1);
@@ -821,7 +835,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     cb[2 * M + k] = v, cb[3 * M + k] = 0.0;
                 }
                 p_barrier();
-                if (exact) B.pf0 = B.pf1 = wg_check(XV{cb, 1}, 0.0, 0.0, 0.0, 0).fitness;
+                if (exact) B.pf0 = B.pf1 = wg_check(wlead, tid, XV{cb, 1}, 0.0, 0.0, 0.0, 0).fitness;
             }
         }
         steps++;
@@ -845,7 +859,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         PHASE_MARK(PH_CHECK);
         if (success) break;
         if (sp.timeout_ticks != 0ull) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
-            if (tid == 0) s_wbc[2] = p_wall_clock() >= deadline ? 1.0 : 0.0;
+            if (tid == 0) {
+                const unsigned long long deadline = ((unsigned long long)s_deadline[0] << 32) | (unsigned long long)s_deadline[1];
+                s_wbc[2] = p_wall_clock() >= deadline ? 1.0 : 0.0;
+            }
             p_barrier();
             expired = s_wbc[2] != 0.0;
             p_barrier();
@@ -853,6 +870,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
     }
     PHASE_DUMP(a.phase_cycles, unit);
+    BIOIK_EPILOGUE_SCOPE_BEGIN
     if (a.carry_list && !success && !expired && step_end < sp.max_steps) {  // neither solved nor out of time: the next launch goes on
         double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < carry_n; i += nth) c[i] = i < 2 * SP ? s_pop[i] : (i < 2 * SP + M ? s_sol[i - 2 * SP] : s_state[i - 2 * SP - M]);
@@ -873,6 +891,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         a.success[unit] = success ? 1 : 0;
         a.steps[unit] = steps;
     }
+    BIOIK_EPILOGUE_SCOPE_END
 }
 
 // best island per query (ik_parallel.h:220-269); one lane per query

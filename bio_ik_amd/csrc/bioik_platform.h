@@ -60,6 +60,14 @@ BIOIK_DEV double p_quad_xor(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The same value as a NEW value the optimiser cannot see through (no instruction is emitted).  The solver's body is one long
+// function whose loops all index LDS by a few lane numbers; the compiler hoists every address it derives from them in front of the
+// outermost loop, where they are live across everything and end up in scratch memory.  A phase that starts from a fresh copy of
+// the lane numbers computes its addresses where it uses them (one or two integer instructions each) and lets them die with it.
+BIOIK_DEV int p_fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock
