@@ -180,10 +180,17 @@ BIOIK_DEV uint32_t rng_ctr1(uint32_t generation, uint32_t species, uint32_t purp
 // ~N(0,1) from ONE 32-bit word: Binomial(16,1/2) lattice (popcount of the low half) + triangular jitter (sum of the two
 // high bytes) -> continuous piecewise-linear density, integer-only up to one exact conversion and one rounding
 BIOIK_DEV double rng_gauss32(uint32_t x) {
+#if defined(BIOIK_GAUSS_TWO_CONVERSIONS)  // the definition, term by term (what the CPU restatements of the tests evaluate)
     int k = p_popc(x & 0xffffu) - 8;
     uint32_t s = ((x >> 16) & 0xffu) + (x >> 24);
     double t = (double)s * (1.0 / 256.0) - 1.0;
     return ((double)k + t) * 0.4898979485566356;  // 1 / sqrt(4 + 1/6)
+#else
+    // the same number from ONE integer and ONE conversion: (k - 8) + s / 256 - 1 = (256 k + s - 2304) / 256 is exact in either form,
+    // and scaling the constant by 2^-8 is exact too, so the single rounding of the product is the same rounding
+    const int v = (p_popc(x & 0xffffu) << 8) + (int)(((x >> 16) & 0xffu) + (x >> 24)) - 2304;
+    return (double)v * (0.4898979485566356 / 256.0);
+#endif
 }
 BIOIK_DEV double rng_uniform(uint32_t x0, uint32_t x1) {
     uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;

@@ -169,16 +169,26 @@ struct bioik_problem {
     bioik_model* model;
     bioik::HostProblem host;
     DevProblem* d_pb = nullptr;
-    // grow-only device arena + page-locked host mirror for the host-pointer entry point (bioik_solve_batch): one allocation
-    // for the life of the handle, one DMA in and one DMA out per call
-    void* io_dev = nullptr;
-    void* io_host = nullptr;
-    size_t io_bytes = 0;
-    // the handle's own stream: host-pointer solves of different handles overlap, also on one device.  Created at the first host-pointer
-    // solve, not with the handle: HIP multiplexes streams onto four hardware queues per device, and a stream that a device-pointer
-    // caller never uses would push one of the caller's own streams onto a shared queue (launches "in flight" would then serialise)
-    stream_t io_stream = nullptr;
-    bool io_stream_made = false;
+    // Host-pointer solves (bioik_solve_batch, bioik_solve_batch_submit / _wait) go through one of kIoSlots slots, each with a grow-only
+    // device arena, its page-locked host mirror (one DMA in, one DMA out per solve) and its own stream: up to kIoSlots batches of one
+    // handle are in flight together, the tail of one solve behind the bulk of the next.  Streams are created at a
+    // slot's first use, not with the handle: HIP multiplexes streams onto four hardware queues per device, and a stream that a
+    // device-pointer caller never uses would push one of the caller's own streams onto a shared queue.
+    static constexpr int kIoSlots = 3;
+    struct IoSlot {
+        void* dev = nullptr;
+        void* host = nullptr;
+        size_t bytes = 0;
+        stream_t stream = nullptr;
+        bool stream_made = false;
+        // the solve in flight on this slot, if any: where its results go when it completes
+        bool pending = false;
+        uint64_t ticket = 0;
+        size_t n = 0, o_sol = 0, o_fit = 0, o_suc = 0, o_steps = 0;
+        double *solutions = nullptr, *fitness = nullptr;
+        int32_t *success = nullptr, *steps = nullptr;
+    } io[kIoSlots];
+    uint64_t next_ticket = 1;  // ticket t runs on slot t % kIoSlots
     uint64_t first_query = 0;
     // launch clocks of solves with a wall-clock timeout: a ring of words, one per launch in flight, zeroed in stream order
     unsigned long long* d_clocks = nullptr;
@@ -567,9 +577,17 @@ void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
     be_free(p->d_clocks);
-    be_stream_destroy(p->io_stream);
-    be_free(p->io_dev);
-    be_free_pinned(p->io_host);
+    for (auto& sl : p->io) {
+        if (sl.pending) {  // (a submitted solve nobody waited for: let it finish before its buffers go)
+            try {
+                be_sync(sl.stream);
+            } catch (...) {
+            }
+        }
+        be_stream_destroy(sl.stream);
+        be_free(sl.dev);
+        be_free_pinned(sl.host);
+    }
     delete p;
 }
 
@@ -606,30 +624,44 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
     API_END
 }
 
-// host arrays in, host arrays out: staged through the handle's page-locked arena, one DMA each way, on the handle's own stream
-static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint64_t first_query, size_t n, const double* seeds, const double* goal_params,
-                       double* solutions, double* fitness, int32_t* success, int32_t* steps) {
-    if (n == 0) return;
-    std::lock_guard<std::mutex> lock(p->mtx);
+// host arrays in, host arrays out: staged through a slot's page-locked arena, one DMA each way, on the slot's own stream.
+// io_finish: the slot's solve is complete and its results are in the caller's arrays (no-op for an idle slot).  Called with p->mtx held.
+static void io_finish(bioik_problem* p, bioik_problem::IoSlot& sl) {
+    if (!sl.pending) return;
+    sl.pending = false;  // (whatever happens below, the slot is free again)
+    DeviceGuard on_device(p->model->device);
+    be_sync(sl.stream);
+    const size_t V = p->host.dev.V;
+    const char* hd = (const char*)sl.host;
+    std::memcpy(sl.solutions, hd + sl.o_sol, sl.n * V * 8);
+    std::memcpy(sl.fitness, hd + sl.o_fit, sl.n * 8);
+    std::memcpy(sl.success, hd + sl.o_suc, sl.n * 4);
+    std::memcpy(sl.steps, hd + sl.o_steps, sl.n * 4);
+}
+// io_begin: copy in, enqueue the transfer in, the solve and the transfer out on the slot's stream; returns without waiting.
+// A solve still pending on the slot is completed first (its results reach its caller's arrays).  Called with p->mtx held.
+static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticket, const bioik_solve_params& params, uint64_t first_query, size_t n,
+                     const double* seeds, const double* goal_params, double* solutions, double* fitness, int32_t* success, int32_t* steps) {
+    io_finish(p, sl);
     DeviceGuard on_device(p->model->device);
     const size_t V = p->host.dev.V, P = p->host.dev.P;
     // arena layout: [seeds | goal_params] in, [solutions | fitness | success | steps] out, every block 64-byte aligned
     auto up = [](size_t b) { return (b + 63) / 64 * 64; };
     const size_t o_seeds = 0, o_par = o_seeds + up(n * V * 8), in_bytes = o_par + up(n * P * 8);
     const size_t o_sol = in_bytes, o_fit = o_sol + up(n * V * 8), o_suc = o_fit + up(n * 8), o_steps = o_suc + up(n * 4), total = o_steps + up(n * 4);
-    if (p->io_bytes < total) {
-        be_free(p->io_dev);
-        be_free_pinned(p->io_host);
-        p->io_dev = p->io_host = nullptr, p->io_bytes = 0;
+    if (sl.bytes < total) {
+        be_free(sl.dev);
+        be_free_pinned(sl.host);
+        sl.dev = sl.host = nullptr, sl.bytes = 0;
         const size_t cap = total + total / 4;
-        p->io_dev = be_alloc(cap);
-        p->io_host = be_alloc_pinned(cap);
-        p->io_bytes = cap;
+        sl.dev = be_alloc(cap);
+        sl.host = be_alloc_pinned(cap);
+        sl.bytes = cap;
     }
-    char* hd = (char*)p->io_host;
-    char* dd = (char*)p->io_dev;
-    if (!p->io_stream_made) p->io_stream = be_stream_create(), p->io_stream_made = true;
-    const stream_t st = p->io_stream;
+    char* hd = (char*)sl.host;
+    char* dd = (char*)sl.dev;
+    if (!sl.stream_made) sl.stream = be_stream_create(), sl.stream_made = true;
+    const stream_t st = sl.stream;
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
     be_h2d(dd, hd, in_bytes, st);
@@ -637,11 +669,18 @@ static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint6
     launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(dd + o_sol), (double*)(dd + o_fit), (int32_t*)(dd + o_suc),
                  (int32_t*)(dd + o_steps), st);
     be_d2h(hd + o_sol, dd + o_sol, total - in_bytes, st);
-    be_sync(st);
-    std::memcpy(solutions, hd + o_sol, n * V * 8);
-    std::memcpy(fitness, hd + o_fit, n * 8);
-    std::memcpy(success, hd + o_suc, n * 4);
-    std::memcpy(steps, hd + o_steps, n * 4);
+    sl.pending = true, sl.ticket = ticket, sl.n = n;
+    sl.o_sol = o_sol, sl.o_fit = o_fit, sl.o_suc = o_suc, sl.o_steps = o_steps;
+    sl.solutions = solutions, sl.fitness = fitness, sl.success = success, sl.steps = steps;
+}
+static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint64_t first_query, size_t n, const double* seeds, const double* goal_params,
+                       double* solutions, double* fitness, int32_t* success, int32_t* steps) {
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(p->mtx);
+    const uint64_t ticket = p->next_ticket++;
+    bioik_problem::IoSlot& sl = p->io[ticket % bioik_problem::kIoSlots];
+    io_begin(p, sl, ticket, params, first_query, n, seeds, goal_params, solutions, fitness, success, steps);
+    io_finish(p, sl);
 }
 
 int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
@@ -651,6 +690,40 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
     if (n && (!seeds || !solutions || !fitness || !success || !steps || (p->host.dev.P > 0 && !goal_params)))
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     solve_host(p, *params, p->first_query, n, seeds, goal_params, solutions, fitness, success, steps);
+    API_END
+}
+
+// Asynchronous host-pointer solve: a caller with a stream of batches keeps up to three of them in flight on ONE handle.
+int bioik_solve_batch_submit(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
+                             double* fitness, int32_t* success, int32_t* steps, uint64_t* ticket) {
+    API_BEGIN
+    if (!p || !params || !ticket) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n && (!seeds || !solutions || !fitness || !success || !steps || (p->host.dev.P > 0 && !goal_params)))
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    std::lock_guard<std::mutex> lock(p->mtx);
+    const uint64_t t = p->next_ticket++;
+    *ticket = t;
+    if (n == 0) return BIOIK_OK;  // (nothing to do: waiting for this ticket returns at once)
+    io_begin(p, p->io[t % bioik_problem::kIoSlots], t, *params, p->first_query, n, seeds, goal_params, solutions, fitness, success, steps);
+    API_END
+}
+int bioik_solve_batch_wait(bioik_problem* p, uint64_t ticket) {
+    API_BEGIN
+    if (!p) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    bioik_problem::IoSlot& sl = p->io[ticket % bioik_problem::kIoSlots];
+    stream_t st = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(p->mtx);
+        if (ticket == 0 || ticket >= p->next_ticket) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_batch_wait: unknown ticket");
+        if (!sl.pending || sl.ticket != ticket) return BIOIK_OK;  // completed when its slot was taken again, or an empty batch
+        st = sl.stream;
+    }
+    {  // the wait itself happens outside the handle's lock: another thread may submit the next batch meanwhile
+        DeviceGuard on_device(p->model->device);
+        be_sync(st);
+    }
+    std::lock_guard<std::mutex> lock(p->mtx);
+    if (sl.pending && sl.ticket == ticket) io_finish(p, sl);
     API_END
 }
 

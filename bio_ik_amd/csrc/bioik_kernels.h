@@ -104,7 +104,56 @@ BIOIK_DEV void top2_merge(double& b1f, int& b1p, double& b2f, int& b2p, double o
 // wave64 xor-butterfly: afterwards every lane holds the two best of the wavefront.  (A DPP reduction with row broadcasts and
 // scalar read-back was measured 30 % slower than ds_bpermute rounds on gfx950; the two steps inside a quad are DPP moves.)
 // G: lanes of the group that is reduced (>= 64: the whole wavefront; 32: one half of it, the other half is the other species)
+// The same result for a whole wavefront (G >= 64) from two wavefront minima.  Every lane's pair is sorted, so the best candidate of
+// the wavefront is the least of the lanes' FIRST entries: a minimum over 64 doubles (four DPP steps inside the rows of 16, then the
+// four row results through scalar registers), one ballot for the lane that holds it, one v_readlane for its position.  The
+// runner-up is the least of what is left: the winner's lane offers its second entry, every other lane its first.  Equal fitness in
+// several lanes (clipped clones; +inf when fewer children than lanes were scored) is decided by position, as cand_better does --
+// the rare path, one more minimum over the tied lanes' positions.  About a third of the instructions of the merging butterfly.
+BIOIK_DEV double wave_min_f64(double v) {
+    v = fmin(v, p_quad_xor<1>(v));
+    v = fmin(v, p_quad_xor<2>(v));
+    v = fmin(v, p_row_mirror<1>(v));
+    v = fmin(v, p_row_mirror<0>(v));  // every lane: the minimum of its row of 16
+    return fmin(fmin(p_read_lane(v, 0), p_read_lane(v, 16)), fmin(p_read_lane(v, 32), p_read_lane(v, 48)));
+}
+BIOIK_DEV int imin(int a, int b) { return a < b ? a : b; }
+BIOIK_DEV int wave_min_i32(int v) {
+    v = imin(v, p_quad_xor<1>(v));
+    v = imin(v, p_quad_xor<2>(v));
+    v = imin(v, p_row_mirror<1>(v));
+    v = imin(v, p_row_mirror<0>(v));
+    return imin(imin(p_read_lane(v, 0), p_read_lane(v, 16)), imin(p_read_lane(v, 32), p_read_lane(v, 48)));
+}
+// lane (wavefront-uniform) of the least (f, pos) among the lanes' candidates, and that candidate
+BIOIK_DEV int wave_argmin(double f, int pos, double& mf, int& mp) {
+    mf = wave_min_f64(f);
+    const unsigned long long tied = p_ballot(f == mf);  // (never empty: the candidates are never NaN, top2_insert)
+    int lane;
+    if ((tied & (tied - 1ull)) == 0ull) {
+        lane = __builtin_ctzll(tied);
+    } else {
+        const int pm = wave_min_i32(f == mf ? pos : 0x7fffffff);
+        lane = __builtin_ctzll(p_ballot(f == mf && pos == pm));
+    }
+    mp = p_read_lane(pos, lane);
+    return lane;
+}
+BIOIK_DEV void top2_wave64_minima(double& b1f, int& b1p, double& b2f, int& b2p) {
+    double w1f, w2f;
+    int w1p, w2p;
+    const int l1 = wave_argmin(b1f, b1p, w1f, w1p);
+    const bool mine = (p_tid() & 63) == l1;
+    wave_argmin(mine ? b2f : b1f, mine ? b2p : b1p, w2f, w2p);
+    b1f = w1f, b1p = w1p, b2f = w2f, b2p = w2p;
+}
 BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p, int G) {
+#if !defined(BIOIK_TOP2_BUTTERFLY)
+    if (G >= 64) {
+        top2_wave64_minima(b1f, b1p, b2f, b2p);
+        return;
+    }
+#endif
 #pragma unroll
     for (int m = 32; m >= 16; m >>= 1) {  // across the rows of 16 lanes: LDS-crossbar permutes
         if (m >= G) continue;

@@ -60,6 +60,13 @@ BIOIK_DEV double p_quad_xor(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the value lane `lane` of the wavefront holds (lane: wavefront-uniform), in every lane: v_readlane_b32, a scalar register as the carrier
+BIOIK_DEV int p_read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+BIOIK_DEV double p_read_lane(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 // The same value as a NEW value the optimiser cannot see through (no instruction is emitted).  The solver's body is one long
 // function whose loops all index LDS by a few lane numbers; the compiler hoists every address it derives from them in front of the
 // outermost loop, where they are live across everything and end up in scratch memory.  A phase that starts from a fresh copy of

@@ -36,10 +36,20 @@ BIOIK_SINCOS_FN void bioik_sincos(double x, double* sn, double* cs) {
     const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
     const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     const int q = ((int)fn) & 3;
-    double so = (q & 1) ? c : s;
-    double co = (q & 1) ? s : c;
-    if (q == 1 || q == 2) co = -co;
-    if (q >= 2) so = -so;
-    *sn = so;
-    *cs = co;
+    const double so = (q & 1) ? c : s;
+    const double co = (q & 1) ? s : c;
+#if defined(BIOIK_SINCOS_SIGN_BRANCHES)
+    *sn = q >= 2 ? -so : so;
+    *cs = (q == 1 || q == 2) ? -co : co;
+#else
+    // quadrants 2, 3 negate the sine, quadrants 1, 2 the cosine: bit 1 of q (of q + 1) moved onto the sign bit -- a shift, an and, an
+    // exclusive or on the high word instead of a comparison and a select per value (negation IS the sign flip, for every double)
+    unsigned long long sb, cb;
+    __builtin_memcpy(&sb, &so, 8);
+    __builtin_memcpy(&cb, &co, 8);
+    sb ^= (unsigned long long)(((unsigned)q << 30) & 0x80000000u) << 32;
+    cb ^= (unsigned long long)((((unsigned)q + 1u) << 30) & 0x80000000u) << 32;
+    __builtin_memcpy(sn, &sb, 8);
+    __builtin_memcpy(cs, &cb, 8);
+#endif
 }

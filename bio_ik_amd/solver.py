@@ -27,7 +27,7 @@ EXPORTS = [
     "bioik_problem_active_variable_count", "bioik_problem_active_variables", "bioik_problem_tip_count", "bioik_problem_tip_links",
     "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch", "bioik_solve_batch_multi",
     "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
-    "bioik_eval_check", "bioik_stream_fitness_device",
+    "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait",
 ]
 
 
@@ -53,6 +53,8 @@ def _declare(L):
     L.bioik_default_solve_params.argtypes = [C.POINTER(abi.SolveParams)]
     L.bioik_default_solve_params.restype = None
     L.bioik_solve_batch.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi]
+    L.bioik_solve_batch_submit.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi, C.POINTER(C.c_uint64)]
+    L.bioik_solve_batch_wait.argtypes = [C.c_void_p, C.c_uint64]
     L.bioik_solve_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pd, _pi, _pi]
     L.bioik_solve_batch_device.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]
@@ -190,6 +192,21 @@ class HipSolver:
         steps = np.zeros(n, dtype=np.int32)
         self._chk(self.L.bioik_solve_batch(self.problem, C.byref(params), n, _d(s), _d(gp), _d(sol), _d(fit), _i(suc), _i(steps)))
         return sol, fit, suc, steps
+
+    def submit_batch(self, params, seeds, goal_params):
+        """bioik_solve_batch_submit: the same solve without waiting.  Returns a ticket object; `wait_batch(ticket)` returns what solve_batch
+        returns.  Up to three batches of this handle are in flight together (the library rotates over three internal streams)."""
+        s = _f64(seeds).reshape(-1, self.V)
+        n = s.shape[0]
+        gp = self._gp(goal_params, n)
+        out = (np.zeros((n, self.V)), np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32))
+        t = C.c_uint64(0)
+        self._chk(self.L.bioik_solve_batch_submit(self.problem, C.byref(params), n, _d(s), _d(gp), _d(out[0]), _d(out[1]), _i(out[2]), _i(out[3]), C.byref(t)))
+        return (t.value, out, (s, gp))  # (the arrays stay alive with the ticket)
+
+    def wait_batch(self, ticket):
+        self._chk(self.L.bioik_solve_batch_wait(self.problem, C.c_uint64(ticket[0])))
+        return ticket[1]
 
     def solve_batch_multi(self, others, params, seeds, goal_params):
         """One batch over this handle and `others` (HipSolver objects of the same template, e.g. one per GPU): contiguous shards, one host

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BIOIK_ABI_VERSION 2
+#define BIOIK_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -228,6 +228,20 @@ int bioik_problem_set_first_query(bioik_problem* p, uint64_t first_query);
 int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds,
                       const double* goal_params, double* solutions, double* fitness, int32_t* success,
                       int32_t* steps);
+
+/* The same solve without waiting for it — for a caller with a STREAM of batches, the batched counterpart of calling
+ * IKParallel::solve() from several threads (reference src/ik_parallel.h:193-218 keeps its own worker threads busy the same way).
+ * `submit` copies the inputs into a page-locked arena of the handle, enqueues transfer in / solve / transfer out on one of the
+ * handle's THREE internal streams (tickets rotate over them) and returns a ticket; `wait` blocks until that solve is complete and
+ * its results are in the arrays given to `submit`, which must stay valid until then.  Up to three solves of a handle are in flight
+ * together: the slow tail of one (a few queries that use the whole step budget) runs behind the bulk of the next, which is worth
+ * about a factor of two in solves per second on 4096-query batches.  Submitting a fourth solve first
+ * completes the oldest one (its results are delivered; its `wait` then returns at once).  Tickets may be waited for in any
+ * order, from any thread; a ticket that is never waited for is completed by a later submit or by bioik_problem_destroy. */
+int bioik_solve_batch_submit(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds,
+                             const double* goal_params, double* solutions, double* fitness, int32_t* success,
+                             int32_t* steps, uint64_t* ticket);
+int bioik_solve_batch_wait(bioik_problem* p, uint64_t ticket);
 
 /* The same batch over several problem handles of ONE template — one handle per GPU of the node (the "device list" of the batched
  * searchPositionIK()), or several handles on one device.  Shard r = queries [r n / W, (r + 1) n / W) goes

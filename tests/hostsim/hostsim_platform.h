@@ -57,6 +57,8 @@ BIOIK_DEV T p_row_mirror(T v) {
     return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))));
 }
 BIOIK_DEV int p_uniform(int v) { return v; }
+template <class T>
+BIOIK_DEV T p_read_lane(T v, int lane) { return p_shfl(v, lane); }
 BIOIK_DEV int p_fresh(int v) { return v; }
 BIOIK_DEV unsigned long long p_ballot(bool pred) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)
     const int w = sim::tid >> 6, l = sim::tid & 63;

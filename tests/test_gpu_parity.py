@@ -389,6 +389,63 @@ def test_solve_batch_multi_two_handles_on_one_gpu(gpus, templates):
     assert torch.cuda.current_device() == 0
 
 
+def test_solve_batch_multi_on_distinct_devices(gpus, templates):
+    """bioik_solve_batch_multi with one handle per GPU of the node (every visible device): the shards run on different devices and the
+    result equals the single-device solve bit for bit.  Skipped on a one-GPU box (the two-handle test above covers the control flow)."""
+    import torch
+    from bio_ik_amd.solver import HipSolver, device_count
+    nd = device_count()
+    if nd < 2:
+        pytest.skip("needs at least two HIP devices")
+    h, t = gpus["c2"], templates["c2"]
+    others = [HipSolver(t, device=d) for d in range(1, nd)]
+    n = 4096 * nd
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=78)
+    p = abi.default_solve_params(population=128, max_steps=48, random_seed=6)
+    h.set_first_query(777)
+    want = h.solve_batch(p, seeds, params)
+    got = h.solve_batch_multi(others, p, seeds, params)
+    h.set_first_query(0)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    assert torch.cuda.current_device() == 0
+
+
+def test_submit_wait_pipelining_full_size(gpus, templates):
+    """bioik_solve_batch_submit / _wait: five 4096-query batches through the handle's three slots equal the synchronous solves bit for bit,
+    whatever the order of waiting; the pipelined sequence is not slower than the one-at-a-time sequence"""
+    import time
+    h, t = gpus["c2"], templates["c2"]
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=3)
+    batches = [make_queries(t, h.active_variables, h.fk_genes, 4096, seed=900 + k)[:2] for k in range(5)]
+    h.solve_batch(p, *batches[0])  # (warm-up: code object, arenas)
+    t0 = time.perf_counter()
+    want = [h.solve_batch(p, s, g) for s, g in batches]
+    t_sync = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tickets = [h.submit_batch(p, s, g) for s, g in batches]
+    got = {k: h.wait_batch(tickets[k]) for k in (4, 0, 2, 1, 3)}
+    t_pipe = time.perf_counter() - t0
+    for k in range(5):
+        assert all(np.array_equal(a, b) for a, b in zip(want[k], got[k]))
+    assert t_pipe < 1.05 * t_sync, (t_pipe, t_sync)
+    print("five 4096-query batches: one at a time %.1f ms, pipelined %.1f ms" % (t_sync * 1e3, t_pipe * 1e3))
+
+
+def test_selection_ties_are_decided_by_position(monkeypatch):
+    """joints without any range: every child of a generation has the same fitness, the elitist selection is decided by position alone
+    (ik_evolution_2.cpp:410-431) -- the tie path of the wavefront-minimum top-2 and of the merging butterfly, bit for bit against the oracle"""
+    from bio_ik_amd import PoseGoal, snake
+    from bio_ik_amd.solver import HipSolver
+    t = ProblemTemplate(snake(4, limit=0.0), "snake", [PoseGoal("tip")])
+    o = orc.Oracle(t)
+    for env in ({"BIOIK_SOLVE_THREADS": "128"}, {"BIOIK_SOLVE_THREADS": "256"}, {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1"}, {}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pc.trajectory(HipSolver(t, device=0), o, t, n=3, pop=128 if env else 16, steps_list=(3,))
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_sharded_batch_equals_whole_batch(gpus, templates):
     """the multi-GPU split: shards solved separately with their query offsets reproduce the unsharded batch"""
     h, t = gpus["c2"], templates["c2"]

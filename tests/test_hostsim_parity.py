@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import parity_cases as pc
-from bio_ik_amd import ProblemTemplate, abi
+from bio_ik_amd import PoseGoal, ProblemTemplate, abi
 from bio_ik_amd.solver import HipSolver
 from conftest import gnarly_goals
 from oracle import orc
@@ -292,3 +292,40 @@ def test_gradient_descent_and_jacobian_solvers(sims, oracles, templates, cfg):
     out = pc.point_solvers(sims[cfg], oracles[cfg], templates[cfg], n=3)
     if cfg == "c2":
         assert out[2].all()  # jac reaches a pose goal near its seed within ten steps
+
+
+def test_submit_wait_pipelining(sims, templates):
+    """bioik_solve_batch_submit / _wait (host-simulated kernels): batches kept in flight on the handle's three slots return what the
+    synchronous call returns, in any order of waiting, and a fourth submit completes the oldest ticket by itself"""
+    from bio_ik_amd.workload import make_queries
+    h, t = sims["c2"], templates["c2"]
+    p = abi.default_solve_params(population=16, max_steps=3, random_seed=5)
+    batches = []
+    for k in range(5):
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=100 + k)
+        batches.append((seeds, params, h.solve_batch(p, seeds, params)))
+    tickets = [h.submit_batch(p, b[0], b[1]) for b in batches]   # five submits on three slots: the first two complete on the way
+    for k in (4, 0, 2, 1, 3):
+        sol, fit, suc, steps = h.wait_batch(tickets[k])
+        ref = batches[k][2]
+        assert np.array_equal(sol, ref[0]) and np.array_equal(fit, ref[1]) and np.array_equal(suc, ref[2]) and np.array_equal(steps, ref[3])
+    h.wait_batch(tickets[0])  # waiting twice is harmless
+    with pytest.raises(Exception):
+        h.wait_batch((10 ** 6, None, None))
+
+
+def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):
+    """joints without any range: every child of a generation is the same genotype, so every fitness of a generation is the same number and
+    the elitist selection is decided by position alone (ik_evolution_2.cpp:410-431) -- the tie path of the wavefront-minimum top-2
+    (whole wavefronts) and of the merging butterfly (half-wavefront groups) against the oracle"""
+    from bio_ik_amd import snake
+    m = snake(4, limit=0.0)
+    t = ProblemTemplate(m, "snake", [PoseGoal("tip")])
+    o = orc.Oracle(t)
+    for env in ({"BIOIK_SOLVE_THREADS": "128"}, {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1"}, {}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = HipSolver(t, lib=hostsim_lib)
+        pc.trajectory(h, o, t, n=2, pop=128 if env else 16, steps_list=(2,))
+        for k in env:
+            monkeypatch.delenv(k)
