@@ -1,13 +1,17 @@
-// bio_ik/goal.h — C++ host-side mirror of the reference's goal (cost) plugin interface
-// (reference include/bio_ik/goal.h:49-129) for the MI355X build.
+// bio_ik/goal.h — the goal (cost) plugin interface of the MI355X build: source compatible with the reference's
+// include/bio_ik/goal.h:46-129.
 //
-// Same class and member names as the reference.  Instead of a virtual `evaluate(const GoalContext&)` that the CPU
-// solver calls per individual, a built-in goal serialises itself for the device: `gpuOpcode()` (BIOIK_GOAL_* of
-// include/bioik_hip.h), `gpuLinkName()` / `gpuVariableName()` (what `describe()` puts into the GoalContext,
-// goal.h:87-90) and `gpuParams()` (the per-query numbers).  Goals that need host callbacks return opcode -1 and make the
-// plugin report BIOIK_ERR_UNSUPPORTED.
-// tf2 / MoveIt are not required: positions and orientations are the small PODs below (x y z / x y z w).
+// `GoalContext`, `Goal::describe(GoalContext&)` and `Goal::evaluate(const GoalContext&)` have the reference's names, signatures and
+// meaning, so goal classes written against the reference — its built-in ones and a user's own subclasses — compile unchanged.
+// What is new is the second face of a goal: a built-in goal also SERIALISES itself for the device — `gpuOpcode()` (BIOIK_GOAL_* of
+// include/bioik_hip.h), `gpuLinkName()` / `gpuVariableName()` (what `describe()` adds to the context, goal.h:87-90) and `gpuParams()`
+// (its per-query numbers) — because on the MI355X the costs of a whole population are evaluated inside the solver kernels, not by a
+// virtual call per individual.  `evaluate()` remains the definition of the cost (the parity tests hold the kernels against it) and is
+// what runs for goals on the host (bio_ik/goal_eval.h).  A goal without a device opcode (a user subclass, JointFunctionGoal,
+// LinkFunctionGoal) cannot steer the device search: the plugin refuses it with a message.
 #pragma once
+#include <sys/types.h>
+
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -15,43 +19,84 @@
 #include <unordered_set>
 #include <vector>
 
-#include "../../../include/bioik_hip.h"
+#include <bioik_hip.h>
 #if defined(BIOIK_WITH_KINEMATICS_BASE)  // built inside the MoveIt plugin (src/kinematics_plugin_hip.cpp): MoveIt's own option struct
 #include <moveit/kinematics_base/kinematics_base.h>
+#include <moveit/robot_model/joint_model_group.h>
+#include <moveit/robot_model/robot_model.h>
 #endif
+
+#include "frame.h"
+#include "robot_info.h"
 
 namespace bio_ik {
 
-struct Vector3 {
-    double x = 0, y = 0, z = 0;
-    Vector3() {}
-    Vector3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {}
-    Vector3 normalized() const {
-        double l = std::sqrt(x * x + y * y + z * z);
-        return Vector3(x / l, y / l, z / l);
+class HostGoalProblem;
+
+class GoalContext {  // reference goal.h:49-95
+protected:
+    const double* active_variable_positions_ = nullptr;
+    const Frame* tip_link_frames_ = nullptr;
+    std::vector<ssize_t> goal_variable_indices_;
+    std::vector<size_t> goal_link_indices_;
+    bool goal_secondary_ = false;
+    std::vector<std::string> goal_link_names_, goal_variable_names_;
+    double goal_weight_ = 1;
+#if defined(BIOIK_WITH_KINEMATICS_BASE)
+    const moveit::core::JointModelGroup* joint_model_group_ = nullptr;
+#endif
+    std::vector<size_t> problem_active_variables_;
+    std::vector<size_t> problem_tip_link_indices_;
+    std::vector<double> initial_guess_;
+    std::vector<double> velocity_weights_;
+    const RobotInfo* robot_info_ = nullptr;
+    mutable std::vector<double> temp_vector_;
+
+public:
+    GoalContext() {}
+    const Frame& getLinkFrame(size_t i = 0) const { return tip_link_frames_[goal_link_indices_[i]]; }
+    double getVariablePosition(size_t i = 0) const {
+        const ssize_t j = goal_variable_indices_[i];
+        return j >= 0 ? active_variable_positions_[j] : initial_guess_[-1 - j];  // a fixed variable keeps the seed's value (goal.h:70-77)
     }
-};
-struct Quaternion {
-    double x = 0, y = 0, z = 0, w = 1;
-    Quaternion() {}
-    Quaternion(double x_, double y_, double z_, double w_) : x(x_), y(y_), z(z_), w(w_) {}
-    Quaternion normalized() const {
-        double l = std::sqrt(x * x + y * y + z * z + w * w);
-        return Quaternion(x / l, y / l, z / l, w / l);
-    }
+    const Frame& getProblemLinkFrame(size_t i) const { return tip_link_frames_[i]; }
+    size_t getProblemLinkCount() const { return problem_tip_link_indices_.size(); }
+    size_t getProblemLinkIndex(size_t i) const { return problem_tip_link_indices_[i]; }
+    double getProblemVariablePosition(size_t i) const { return active_variable_positions_[i]; }
+    size_t getProblemVariableCount() const { return problem_active_variables_.size(); }
+    size_t getProblemVariableIndex(size_t i) const { return problem_active_variables_[i]; }
+    double getProblemVariableInitialGuess(size_t i) const { return initial_guess_[problem_active_variables_[i]]; }
+    double getProblemVariableWeight(size_t i) const { return velocity_weights_[i]; }
+    const RobotInfo& getRobotInfo() const { return *robot_info_; }
+    void addLink(const std::string& name) { goal_link_names_.push_back(name); }
+    void addVariable(const std::string& name) { goal_variable_names_.push_back(name); }
+    void setSecondary(bool secondary) { goal_secondary_ = secondary; }
+    void setWeight(double weight) { goal_weight_ = weight; }
+#if defined(BIOIK_WITH_KINEMATICS_BASE)
+    const moveit::core::JointModelGroup& getJointModelGroup() const { return *joint_model_group_; }
+    const moveit::core::RobotModel& getRobotModel() const { return joint_model_group_->getParentModel(); }
+#endif
+    std::vector<double>& getTempVector() const { return temp_vector_; }
+    friend class HostGoalProblem;  // bio_ik/goal_eval.h: the host-side counterpart of the reference's `Problem`
 };
 
 class Goal {  // reference goal.h:97-119
 protected:
-    bool secondary_ = false;
-    double weight_ = 1.0;
+    bool secondary_;
+    double weight_;
 
 public:
+    Goal() : secondary_(false), weight_(1) {}
     virtual ~Goal() {}
     bool isSecondary() const { return secondary_; }
     double getWeight() const { return weight_; }
     void setWeight(double w) { weight_ = w; }
-    // ---- device serialisation (replaces describe()/evaluate() on the GPU path) ----
+    virtual void describe(GoalContext& context) const {
+        context.setSecondary(secondary_);
+        context.setWeight(weight_);
+    }
+    virtual double evaluate(const GoalContext&) const { return 0; }
+    // ---- device serialisation (what the solver kernels evaluate; -1: the goal exists on the host only) ----
     virtual int gpuOpcode() const { return -1; }
     virtual std::string gpuLinkName() const { return std::string(); }
     virtual std::string gpuVariableName() const { return std::string(); }

@@ -1,6 +1,7 @@
 // bio_ik/kinematics_plugin_hip.h — what libbio_ik (MI355X build) exports next to the pluginlib class `bio_ik/BioIKKinematicsPlugin`:
 // the additive batched form of searchPositionIK (the reference's interface, src/kinematics_plugin.cpp:437-446, solves one query per call).
 #pragma once
+#include <memory>
 #include <vector>
 
 #include <geometry_msgs/Pose.h>
@@ -19,5 +20,25 @@ bool searchPositionIKBatch(const kinematics::KinematicsBase& solver, const std::
                            std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
                            const kinematics::KinematicsQueryOptions& options = kinematics::KinematicsQueryOptions(),
                            const moveit::core::RobotState* context_state = nullptr);
+
+// The same without waiting: the batch is marshalled and enqueued (transfers and kernels on one of the plugin's three streams per
+// device), and the call returns a ticket; searchPositionIKBatchWait blocks until that batch is complete and post-processed.  A caller
+// with a stream of batches keeps up to three in flight and gets the throughput the device reaches on a stream of batches -- the slow
+// tail of one batch runs behind the bulk of the next.  `ik_seed_states` must stay alive until the wait; the
+// timeout is counted from the submitting call.
+struct BatchTicket {
+    struct Impl;
+    std::unique_ptr<Impl> impl;
+    BatchTicket();
+    ~BatchTicket();
+    BatchTicket(BatchTicket&&);
+    BatchTicket& operator=(BatchTicket&&);
+};
+BatchTicket searchPositionIKBatchAsync(const kinematics::KinematicsBase& solver, const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses,
+                                       const std::vector<std::vector<double>>& ik_seed_states, double timeout,
+                                       const kinematics::KinematicsQueryOptions& options = kinematics::KinematicsQueryOptions(),
+                                       const moveit::core::RobotState* context_state = nullptr);
+bool searchPositionIKBatchWait(const kinematics::KinematicsBase& solver, BatchTicket& ticket, std::vector<std::vector<double>>& solutions,
+                               std::vector<moveit_msgs::MoveItErrorCodes>& error_codes);
 
 }  // namespace bio_ik_kinematics_plugin

@@ -1,0 +1,329 @@
+// bio_ik/plugin_core.h — the ONE implementation of what `BioIKKinematicsPlugin::searchPositionIK` does around the solver call
+// (reference src/kinematics_plugin.cpp:437-655), shared by every face of the plugin: the MoveIt translation unit
+// (src/kinematics_plugin_hip.cpp, `kinematics::KinematicsBase`), the header-only class for programs without MoveIt
+// (bio_ik/kinematics_plugin.h) and, through the C shim of src/plugin_shim.cpp, the Python package.
+//
+//   seed state over the context / default state (:465-485)            -> Engine::submit
+//   default goals first, then the caller's; `replace` (:550-556)      -> the caller builds the goal list, Engine compiles / caches it
+//   tip poses into the model frame, per-query goal numbers (:487-546)  -> Engine::submit
+//   problem.initialize / ik->initialize / ik->solve (:560-578)         -> bioik_solve_batch_submit (include/bioik_hip.h), n queries at once
+//   angle wrap towards the seed, at the limits, clamp (:580-613)       -> Engine::wait
+//   enforcePositionBounds, result -> group variables (:616-629)        -> Engine::wait
+//   solution_fitness, approximate solutions (:632-641)                 -> Engine::wait
+//
+// A batch is SUBMITTED (inputs marshalled, transfers and kernels enqueued, nothing waited for) and later WAITED for: a caller with a
+// stream of batches keeps up to three in flight per device and reaches the throughput of DESIGN.md section 6 through this boundary;
+// the synchronous calls are submit + wait.  Robot-model access goes through `ModelView`, a handful of arrays and name look-ups that
+// each face fills from its own model type.  Header-only; link with libbioik_hip.so.
+#pragma once
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <functional>
+#include <list>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+
+#include "goal.h"
+#include "goal_types.h"
+
+namespace bio_ik {
+namespace core {
+
+struct ModelView {
+    size_t n_variables = 0;
+    std::vector<uint8_t> var_revolute;  // the variable of a revolute joint (what the angle wrap applies to, :584-586)
+    std::vector<uint8_t> var_bounded;   // VariableBounds::position_bounded_
+    std::vector<double> var_min, var_max;
+    bool has_mimic = false;             // the reference skips the angle wrap for models with mimic joints (:585)
+    std::vector<int> group_vars;        // robot variable behind every entry of an ik_seed_state / solution vector (:473-484, :619-629)
+    std::vector<int32_t> group_joints;  // link index (= its parent joint) per JointModelGroup::getActiveJointModels()
+    std::function<int(const std::string&)> link_index, variable_index, joint_link_index;  // by name; negative: unknown
+    std::function<void(double*)> enforce_bounds;  // RobotModel::enforcePositionBounds where the face has MoveIt's; else the generic form below
+};
+
+struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path reads them, + the additive gpu_* keys
+    std::string mode = "bio2_memetic";
+    int random_seed = 0;
+    double dpos = DBL_MAX, drot = DBL_MAX, dtwist = 1e-5;
+    bool no_wipeout = false;
+    int gpu_population = 128, gpu_islands = 1, gpu_max_steps = 4096;
+    std::string gpu_fk = "exact";
+    bool gpu_reproducible_calls = false;  // true: every call draws from the same random streams (query k of a call = stream k), so a repeated
+                                          // call returns the same answer; false (default): the streams advance from call to call like the
+                                          // reference's generator state, and a retry of a failed query explores differently
+    std::vector<int> devices = {0};  // a batch is sharded over them (contiguous shards, no exchange)
+};
+
+// IKFactory names with a device implementation (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292).  Not available: bio1,
+// gd_r (random restarts) and the `_2 / _4 / _8` forms of gd / gd_c / jac (further solver threads started at random configurations,
+// ik_parallel.h:141-145), the cppoptlib and FANN families -- an unknown name is a configuration error, as in IKFactory::create.
+inline int solverMode(const std::string& name) {
+    if (name == "bio2") return BIOIK_MODE_BIO2;
+    if (name == "bio2_memetic") return BIOIK_MODE_BIO2_MEMETIC;
+    if (name == "bio2_memetic_l") return BIOIK_MODE_BIO2_MEMETIC_L;
+    if (name == "gd_c") return BIOIK_MODE_GD_C;
+    if (name == "gd") return BIOIK_MODE_GD;
+    if (name == "jac") return BIOIK_MODE_JAC;
+    throw std::runtime_error("bio_ik (MI355X): solver mode '" + name + "' has no device implementation (available: bio2, bio2_memetic, bio2_memetic_l, gd, gd_c, jac)");
+}
+
+inline void concat7(const double* a, const double* b, double* r) {  // a o b for frames px py pz qx qy qz qw (include/bio_ik/frame.h:174-187)
+    const double *q = a + 3, *v = b;
+    const double tx = 2 * (q[1] * v[2] - q[2] * v[1]), ty = 2 * (q[2] * v[0] - q[0] * v[2]), tz = 2 * (q[0] * v[1] - q[1] * v[0]);
+    double o[7];
+    o[0] = a[0] + v[0] + q[3] * tx + q[1] * tz - q[2] * ty;
+    o[1] = a[1] + v[1] + q[3] * ty + q[2] * tx - q[0] * tz;
+    o[2] = a[2] + v[2] + q[3] * tz + q[0] * ty - q[1] * tx;
+    const double* p = b + 3;
+    o[3] = q[3] * p[0] + q[0] * p[3] + q[1] * p[2] - q[2] * p[1];
+    o[4] = q[3] * p[1] - q[0] * p[2] + q[1] * p[3] + q[2] * p[0];
+    o[5] = q[3] * p[2] + q[0] * p[1] - q[1] * p[0] + q[2] * p[3];
+    o[6] = q[3] * p[3] - q[0] * p[0] - q[1] * p[1] - q[2] * p[2];
+    for (int i = 0; i < 7; i++) r[i] = o[i];
+}
+
+// One batch of queries that share a goal structure, as every face hands it over.
+struct Request {
+    std::vector<const Goal*> goals;         // all goals: the plugin's defaults first (unless `replace`), then the caller's (:550-556)
+    size_t n_pose_goals = 0;                // the leading goals are PoseGoals that take the per-query tip poses (the default goals of the tips)
+    std::vector<std::string> fixed_joints;  // BioIKKinematicsQueryOptions::fixed_joints
+    const std::vector<std::vector<double>>* seed_states = nullptr;  // [n][group variables]
+    std::vector<double> tip_poses;          // [n][n_pose_goals][7], in the frame `base_frame` is given in
+    double base_frame[7] = {0, 0, 0, 0, 0, 0, 1};  // global transform of the plugin's base frame (:487-502)
+    std::vector<double> context;            // the full variable vector the seeds are laid over: context state or default positions (:465-472)
+    double timeout = 0.0;                   // the caller's timeout [s], counted from the moment submit() is entered (:504)
+    bool return_approximate_solution = false;
+    const BioIKKinematicsQueryOptions* bio = nullptr;  // receives solution_fitness (:632-634)
+};
+
+class Engine {
+    struct ProblemSet {  // one compiled problem per device for ONE goal structure
+        std::vector<bioik_problem*> per_device;
+        ~ProblemSet() {
+            for (auto* p : per_device) bioik_problem_destroy(p);
+        }
+    };
+    ModelView mv_;
+    Settings settings_;
+    std::vector<bioik_model*> models_;
+    // compiled problems, least recently used first; bounded, so a caller that varies its goal weights from call to call does not grow
+    // device and host memory without limit (a batch in flight keeps its set alive through its ticket)
+    std::list<std::pair<std::string, std::shared_ptr<ProblemSet>>> cache_;
+    static constexpr size_t kCacheCapacity = 32;
+    uint64_t next_query_ = 0;  // global index of the next query: the random streams advance from call to call, as the reference's generator does
+
+    std::shared_ptr<ProblemSet> problemFor(const std::vector<const Goal*>& goals, const std::vector<std::string>& fixed) {
+        std::ostringstream key;
+        key << std::hexfloat;  // exact weight bits: goals whose weights differ in any digit get their own compiled problem
+        for (auto* g : goals) key << g->gpuOpcode() << ':' << g->gpuLinkName() << ':' << g->gpuVariableName() << ':' << g->getWeight() << ':' << g->isSecondary() << ';';
+        for (auto& f : fixed) key << '#' << f;
+        const std::string k = key.str();
+        for (auto it = cache_.begin(); it != cache_.end(); ++it)
+            if (it->first == k) {
+                cache_.splice(cache_.end(), cache_, it);  // most recently used last
+                return cache_.back().second;
+            }
+        std::vector<bioik_goal_desc> gd;
+        for (auto* g : goals) {
+            if (g->gpuOpcode() < 0)
+                throw std::runtime_error("bio_ik (MI355X): a goal without a device implementation (JointFunctionGoal, LinkFunctionGoal or a user-defined Goal) cannot be part "
+                                         "of a device solve; evaluate it on the host (bio_ik/goal_eval.h) on the returned solutions instead");
+            bioik_goal_desc d{g->gpuOpcode(), -1, -1, g->isSecondary() ? 1 : 0, g->getWeight()};
+            if (!g->gpuLinkName().empty()) {
+                d.link = mv_.link_index(g->gpuLinkName());
+                if (d.link < 0) throw std::runtime_error("link not found: " + g->gpuLinkName());  // problem.cpp:141
+            }
+            if (!g->gpuVariableName().empty()) {
+                d.variable = mv_.variable_index(g->gpuVariableName());
+                if (d.variable < 0) throw std::runtime_error("joint variable not found: " + g->gpuVariableName());  // problem.cpp:125
+            }
+            gd.push_back(d);
+        }
+        std::vector<int32_t> fixed_idx;
+        for (auto& f : fixed) {
+            const int l = mv_.joint_link_index(f);
+            if (l < 0) throw std::runtime_error("joint not found: " + f);
+            fixed_idx.push_back(l);
+        }
+        bioik_problem_desc pd{};
+        pd.struct_size = sizeof(pd);
+        pd.n_group_joints = (uint32_t)mv_.group_joints.size(), pd.group_joints = mv_.group_joints.data();
+        pd.n_goals = (uint32_t)gd.size(), pd.goals = gd.data();
+        pd.n_fixed_joints = (uint32_t)fixed_idx.size(), pd.fixed_joints = fixed_idx.data();
+        auto set = std::make_shared<ProblemSet>();
+        for (auto* m : models_) {
+            bioik_problem* p = nullptr;
+            if (bioik_problem_create(m, &pd, &p) != BIOIK_OK) throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
+            set->per_device.push_back(p);
+        }
+        cache_.emplace_back(k, set);
+        if (cache_.size() > kCacheCapacity) cache_.pop_front();
+        return set;
+    }
+
+public:
+    // A submitted batch.  Holds everything the post-processing needs; the arrays the device writes into live here until wait().
+    struct Ticket {
+        size_t n = 0;
+        std::shared_ptr<void> problems;  // keeps the compiled problems alive
+        std::vector<bioik_problem*> handles;
+        std::vector<uint64_t> tickets;   // one per device shard (0: an empty shard)
+        std::vector<double> seeds, params, sol, fit;
+        std::vector<int32_t> suc, steps, active;
+        bool approximate = false, failed = false;
+        const BioIKKinematicsQueryOptions* bio = nullptr;
+    };
+
+    Engine() {}
+    Engine(const Engine&) = delete;
+    ~Engine() { release(); }
+    void release() {
+        cache_.clear();
+        for (auto* m : models_) bioik_model_destroy(m);
+        models_.clear();
+    }
+    bool ready() const { return !models_.empty(); }
+    const Settings& settings() const { return settings_; }
+
+    // `md` describes the model for the device (bioik_model_desc, include/bioik_hip.h), `mv` for the host-side logic of this file
+    void initialize(const bioik_model_desc& md, const ModelView& mv, const Settings& s) {
+        release();
+        mv_ = mv, settings_ = s;
+        solverMode(s.mode);  // (an unknown mode is a configuration error: throw here, as IKFactory::create does at load time)
+        if (settings_.devices.empty()) settings_.devices.push_back(0);
+        for (int dev : settings_.devices) {
+            bioik_model* m = nullptr;
+            if (bioik_model_create(&md, dev, &m) != BIOIK_OK) {
+                const std::string msg = bioik_last_error();
+                release();
+                throw std::runtime_error("bio_ik (MI355X): " + msg);
+            }
+            models_.push_back(m);
+        }
+        next_query_ = 0;
+    }
+
+    std::shared_ptr<Ticket> submit(const Request& rq) {
+        const auto t_entry = std::chrono::steady_clock::now();
+        if (models_.empty()) throw std::runtime_error("bio_ik (MI355X): plugin not initialised");
+        auto tk = std::make_shared<Ticket>();
+        const size_t n = rq.seed_states ? rq.seed_states->size() : 0, V = mv_.n_variables;
+        tk->n = n, tk->approximate = rq.return_approximate_solution, tk->bio = rq.bio;
+        std::shared_ptr<ProblemSet> set = problemFor(rq.goals, rq.fixed_joints);
+        tk->problems = set, tk->handles = set->per_device;
+        bioik_problem* problem = tk->handles.front();
+        const size_t P = (size_t)bioik_problem_param_count(problem);
+        tk->active.resize((size_t)bioik_problem_active_variable_count(problem));
+        bioik_problem_active_variables(problem, tk->active.data());
+        // the seed states over the context / default state (:465-485)
+        tk->seeds.resize(n * V);
+        for (size_t k = 0; k < n; k++) {
+            double* row = &tk->seeds[k * V];
+            for (size_t v = 0; v < V; v++) row[v] = rq.context[v];
+            const std::vector<double>& seed = (*rq.seed_states)[k];
+            for (size_t i = 0; i < mv_.group_vars.size(); i++) row[mv_.group_vars[i]] = seed.at(i);
+        }
+        // per-query goal numbers: the default pose goals move into the model frame (:487-502, :540-546), then every goal writes its own
+        tk->params.resize(n * P);
+        std::vector<double> row;
+        for (size_t k = 0; k < n; k++) {
+            row.clear();
+            for (size_t gi = 0; gi < rq.goals.size(); gi++) {
+                const Goal* g = rq.goals[gi];
+                if (gi < rq.n_pose_goals) {
+                    double m[7];
+                    concat7(rq.base_frame, &rq.tip_poses.at((k * rq.n_pose_goals + gi) * 7), m);
+                    auto* goal = static_cast<PoseGoal*>(const_cast<Goal*>(g));
+                    goal->setPosition(Vector3(m[0], m[1], m[2]));
+                    goal->setOrientation(Quaternion(m[3], m[4], m[5], m[6]));  // normalises (goal_types.h:146)
+                }
+                g->gpuParams(row);
+            }
+            for (size_t i = 0; i < P; i++) tk->params[k * P + i] = row.at(i);
+        }
+        bioik_solve_params sp;
+        bioik_default_solve_params(&sp);
+        sp.mode = solverMode(settings_.mode);
+        sp.fk_mode = settings_.gpu_fk == "linear" ? BIOIK_FK_LINEAR : BIOIK_FK_EXACT;
+        sp.population = settings_.gpu_population, sp.islands = settings_.gpu_islands, sp.max_steps = settings_.gpu_max_steps;
+        sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
+        sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;
+        sp.no_wipeout = settings_.no_wipeout ? 1 : 0;
+        tk->sol.resize(n * V), tk->fit.resize(n), tk->suc.resize(n), tk->steps.resize(n);
+        // problem.timeout = t0 + timeout with t0 taken at entry (:448, :504): what the marshalling above has used is off the budget (one
+        // step always runs, ik_parallel.h:160)
+        if (rq.timeout > 0.0) {
+            const double used = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count();
+            sp.timeout = std::max(rq.timeout - used, 1e-6);
+        }
+        // contiguous shards over the devices, each submitted to its own handle (its own streams): no exchange between shards, and the
+        // query-indexed random streams make the result independent of the split
+        const size_t W = tk->handles.size();
+        tk->tickets.assign(W, 0);
+        const uint64_t first = settings_.gpu_reproducible_calls ? 0 : next_query_;
+        next_query_ += n;
+        for (size_t r = 0; r < W; r++) {
+            const size_t a = r * n / W, b = (r + 1) * n / W;
+            if (a == b) continue;
+            bioik_problem_set_first_query(tk->handles[r], first + a);
+            if (bioik_solve_batch_submit(tk->handles[r], &sp, b - a, &tk->seeds[a * V], P ? &tk->params[a * P] : nullptr, &tk->sol[a * V], &tk->fit[a], &tk->suc[a],
+                                         &tk->steps[a], &tk->tickets[r]) != BIOIK_OK)
+                tk->failed = true;  // device errors never abort the caller: every query of the batch reports NO_IK_SOLUTION
+        }
+        return tk;
+    }
+
+    // Waits for the batch; solutions [n][group variables], ok[k] = accurate solution or an approximate one was asked for (:638-641).
+    // Returns true iff every query is ok.
+    bool wait(Ticket& tk, std::vector<std::vector<double>>& solutions, std::vector<uint8_t>& ok) {
+        const size_t n = tk.n, V = mv_.n_variables;
+        for (size_t r = 0; r < tk.handles.size(); r++)
+            if (tk.tickets[r] && bioik_solve_batch_wait(tk.handles[r], tk.tickets[r]) != BIOIK_OK) tk.failed = true;
+        solutions.assign(n, std::vector<double>());
+        ok.assign(n, 0);
+        if (tk.failed) return false;
+        bool all_ok = true;
+        for (size_t k = 0; k < n; k++) {
+            double* st = &tk.sol[k * V];
+            const double* seed = &tk.seeds[k * V];
+            if (!mv_.has_mimic)
+                for (int ivar : tk.active) {  // wrap angles (:580-613)
+                    if (!mv_.var_revolute[ivar]) continue;
+                    double v = st[ivar];
+                    const double r = seed[ivar], lo = mv_.var_min[ivar], hi = mv_.var_max[ivar];
+                    if (r < v - M_PI || r > v + M_PI) {  // move close to the initial guess
+                        v -= r, v /= (2 * M_PI), v += 0.5, v -= std::floor(v), v -= 0.5, v *= (2 * M_PI), v += r;
+                    }
+                    if (v > hi) v -= std::ceil(std::max(0.0, v - hi) / (2 * M_PI)) * (2 * M_PI);  // wrap at the joint limits
+                    if (v < lo) v += std::ceil(std::max(0.0, lo - v) / (2 * M_PI)) * (2 * M_PI);
+                    if (v < lo) v = lo;  // clamp at the edges
+                    if (v > hi) v = hi;
+                    st[ivar] = v;
+                }
+            if (mv_.enforce_bounds) {
+                mv_.enforce_bounds(st);  // RobotModel::enforcePositionBounds (:616)
+            } else {
+                for (size_t v = 0; v < V; v++) {  // its effect on one-variable joints: clamp bounded variables, wrap continuous revolute ones to (-pi, pi]
+                    if (mv_.var_bounded[v]) {
+                        st[v] = std::min(std::max(st[v], mv_.var_min[v]), mv_.var_max[v]);
+                    } else if (mv_.var_revolute[v] && (st[v] <= -M_PI || st[v] > M_PI)) {
+                        st[v] = std::fmod(st[v], 2 * M_PI);
+                        if (st[v] <= -M_PI) st[v] += 2 * M_PI;
+                        else if (st[v] > M_PI) st[v] -= 2 * M_PI;
+                    }
+                }
+            }
+            for (int gv : mv_.group_vars) solutions[k].push_back(st[gv]);  // map the result to the group's variables (:619-629)
+            ok[k] = (tk.suc[k] || tk.approximate) ? 1 : 0;
+            all_ok = all_ok && ok[k];
+        }
+        if (tk.bio && n) tk.bio->solution_fitness = tk.fit[n - 1];  // :632-634
+        return all_ok;
+    }
+};
+
+}  // namespace core
+}  // namespace bio_ik

@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../../include/bioik_hip.h"
+#include <bioik_hip.h>
 
 namespace bio_ik {
 

@@ -31,6 +31,7 @@
 #define BIOIK_WITH_KINEMATICS_BASE 1
 #include <bio_ik/bio_ik.h>
 #include <bio_ik/kinematics_plugin_hip.h>
+#include <bio_ik/plugin_core.h>
 
 namespace bio_ik_kinematics_plugin {
 
@@ -57,29 +58,6 @@ Frame7 toFrame(const geometry_msgs::Pose& p) {
     f.v[0] = p.position.x, f.v[1] = p.position.y, f.v[2] = p.position.z;
     f.v[3] = p.orientation.x, f.v[4] = p.orientation.y, f.v[5] = p.orientation.z, f.v[6] = p.orientation.w;
     return f;
-}
-Frame7 concat(const Frame7& a, const Frame7& b) {  // a o b (include/bio_ik/frame.h:174-187 semantics)
-    const double *q = a.v + 3, *v = b.v;
-    const double tx = 2 * (q[1] * v[2] - q[2] * v[1]), ty = 2 * (q[2] * v[0] - q[0] * v[2]), tz = 2 * (q[0] * v[1] - q[1] * v[0]);
-    Frame7 r;
-    r.v[0] = a.v[0] + v[0] + q[3] * tx + q[1] * tz - q[2] * ty;
-    r.v[1] = a.v[1] + v[1] + q[3] * ty + q[2] * tx - q[0] * tz;
-    r.v[2] = a.v[2] + v[2] + q[3] * tz + q[0] * ty - q[1] * tx;
-    const double *p = a.v + 3, *o = b.v + 3;
-    r.v[3] = p[3] * o[0] + p[0] * o[3] + p[1] * o[2] - p[2] * o[1];
-    r.v[4] = p[3] * o[1] - p[0] * o[2] + p[1] * o[3] + p[2] * o[0];
-    r.v[5] = p[3] * o[2] + p[0] * o[1] - p[1] * o[0] + p[2] * o[3];
-    r.v[6] = p[3] * o[3] - p[0] * o[0] - p[1] * o[1] - p[2] * o[2];
-    return r;
-}
-int solverMode(const std::string& name) {  // IKFactory names (src/ik_evolution_2.cpp:652-654); unknown -> ERROR (src/utils.h:436)
-    if (name == "bio2") return BIOIK_MODE_BIO2;
-    if (name == "bio2_memetic") return BIOIK_MODE_BIO2_MEMETIC;
-    if (name == "bio2_memetic_l") return BIOIK_MODE_BIO2_MEMETIC_L;
-    if (name == "gd_c") return BIOIK_MODE_GD_C;  // src/ik_gradient.cpp:263
-    if (name == "gd") return BIOIK_MODE_GD;      // :253
-    if (name == "jac") return BIOIK_MODE_JAC;    // src/ik_gradient.cpp:289
-    throw std::runtime_error("bio_ik (MI355X): solver mode '" + name + "' has no device implementation");
 }
 }  // namespace
 
@@ -162,28 +140,14 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
     mutable std::vector<std::unique_ptr<bio_ik::Goal>> default_goals;
     mutable std::mutex mutex;  // the reference's instance is not re-entrant either (mutable members, :121-124); here calls serialise
 
-    // IKParams (src/utils.h:64-85) restricted to what the device path reads, + the additive gpu_* keys
-    std::string mode = "bio2_memetic";
-    int random_seed = 0;
-    double dpos = DBL_MAX, drot = DBL_MAX, dtwist = 1e-5;
-    bool no_wipeout = false;
-    int gpu_population = 128, gpu_islands = 1, gpu_max_steps = 4096, gpu_device = 0;
-    std::string gpu_fk = "exact";
-
+    // IKParams (src/utils.h:64-85) restricted to what the device path reads, + the additive gpu_* keys (bio_ik/plugin_core.h)
+    bio_ik::core::Settings settings;
     std::unique_ptr<FlatModel> flat;
-    std::vector<int> devices;            // kinematics.yaml `gpu_devices: "0,1,2,3"` (default: the single `gpu_device`): a batch is sharded over them
-    std::vector<bioik_model*> models;    // one per device
-    mutable std::map<std::string, std::vector<bioik_problem*>> problems;  // per goal structure: one compiled problem per device
+    // everything between the arguments of searchPositionIK and the C-ABI: the implementation shared with the other faces of the plugin
+    mutable bio_ik::core::Engine engine;
 
     BioIKKinematicsPlugin() {}
-    ~BioIKKinematicsPlugin() override { release(); }
-    void release() {
-        for (auto& kv : problems)
-            for (auto* p : kv.second) bioik_problem_destroy(p);
-        problems.clear();
-        for (auto* m : models) bioik_model_destroy(m);
-        models.clear();
-    }
+    ~BioIKKinematicsPlugin() override {}
 
     const std::vector<std::string>& getJointNames() const override { return joint_names; }  // :130-133
     const std::vector<std::string>& getLinkNames() const override { return link_names; }    // :135-138
@@ -200,9 +164,14 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
             // targets hand over the RobotModel (initialize(const RobotModel&, ...)), and that is the overload this build supports
             throw std::runtime_error("bio_ik (MI355X): initialize needs the moveit::core::RobotModel overload");
         }
+        engine.release();  // (a re-initialisation starts from nothing, also when it fails below)
+        default_goals.clear();
         robot_model = model_ptr;
         joint_model_group = robot_model->getJointModelGroup(group_name);
-        if (!joint_model_group) return false;  // "failed to get joint model group" (:215-218)
+        if (!joint_model_group) {  // "failed to get joint model group" (:215-218)
+            robot_model.reset();
+            return false;
+        }
         joint_names.clear();
         for (auto* joint_model : joint_model_group->getJointModels())
             if (joint_model->getName() != base_frame_ && joint_model->getType() != moveit::core::JointModel::UNKNOWN &&
@@ -213,37 +182,63 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         if (!tips2.empty()) tip_frames_ = tips2;
         link_names = tip_frames_;
 
-        lookupParam("mode", mode, std::string("bio2_memetic"));
-        lookupParam("random_seed", random_seed, static_cast<int>(std::random_device()()));
-        lookupParam("dpos", dpos, DBL_MAX);
-        lookupParam("drot", drot, DBL_MAX);
-        lookupParam("dtwist", dtwist, 1e-5);
-        lookupParam("no_wipeout", no_wipeout, false);
-        lookupParam("gpu_population", gpu_population, 128);   // children per species and generation (reference: 16, ik_evolution_2.cpp:138)
-        lookupParam("gpu_islands", gpu_islands, 1);
-        lookupParam("gpu_max_steps", gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query
-        lookupParam("gpu_fk", gpu_fk, std::string("exact"));  // "exact" | "linear" (the reference's linearised phenotypes)
+        bio_ik::core::Settings& p = settings;
+        p = bio_ik::core::Settings();
+        lookupParam("mode", p.mode, std::string("bio2_memetic"));
+        lookupParam("random_seed", p.random_seed, static_cast<int>(std::random_device()()));
+        lookupParam("dpos", p.dpos, DBL_MAX);
+        lookupParam("drot", p.drot, DBL_MAX);
+        lookupParam("dtwist", p.dtwist, 1e-5);
+        lookupParam("no_wipeout", p.no_wipeout, false);
+        lookupParam("gpu_population", p.gpu_population, 128);   // children per species and generation (reference: 16, ik_evolution_2.cpp:138)
+        lookupParam("gpu_islands", p.gpu_islands, 1);
+        lookupParam("gpu_max_steps", p.gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query
+        lookupParam("gpu_fk", p.gpu_fk, std::string("exact"));  // "exact" | "linear" (the reference's linearised phenotypes)
+        lookupParam("gpu_reproducible_calls", p.gpu_reproducible_calls, false);  // true: a repeated call replays the same random streams
+        int gpu_device = 0;
         lookupParam("gpu_device", gpu_device, 0);
-        std::string gpu_devices;
+        std::string gpu_devices;  // kinematics.yaml `gpu_devices: "0,1,2,3"` (default: the single `gpu_device`): a batch is sharded over them
         lookupParam("gpu_devices", gpu_devices, std::string());
-        devices.clear();
+        p.devices.clear();
         {
             std::stringstream ss(gpu_devices);
             for (std::string item; std::getline(ss, item, ',');)
-                if (!item.empty()) devices.push_back(std::stoi(item));
+                if (!item.empty()) p.devices.push_back(std::stoi(item));
         }
-        if (devices.empty()) devices.push_back(gpu_device);
-        solverMode(mode);
+        if (p.devices.empty()) p.devices.push_back(gpu_device);
 
         temp_state.reset(new moveit::core::RobotState(robot_model));
         flat.reset(new FlatModel(*robot_model));
-        bioik_model_desc md = flat->desc();
-        release();
-        for (int dev : devices) {
-            bioik_model* m = nullptr;
-            if (bioik_model_create(&md, dev, &m) != BIOIK_OK) throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
-            models.push_back(m);
+        // what the shared implementation needs to know about the model (bio_ik/plugin_core.h: ModelView)
+        bio_ik::core::ModelView mv;
+        const moveit::core::RobotModel* rm = robot_model.get();
+        mv.n_variables = rm->getVariableCount();
+        mv.var_revolute.assign(mv.n_variables, 0);
+        for (size_t v = 0; v < mv.n_variables; v++) {
+            const moveit::core::JointModel* jm = rm->getJointOfVariable((int)v);
+            mv.var_revolute[v] = jm->getType() == moveit::core::JointModel::REVOLUTE ? 1 : 0;
+            const moveit::core::VariableBounds& b = jm->getVariableBounds()[v - (size_t)jm->getFirstVariableIndex()];
+            mv.var_bounded.push_back(b.position_bounded_ ? 1 : 0);
+            mv.var_min.push_back(b.min_position_), mv.var_max.push_back(b.max_position_);
         }
+        mv.has_mimic = !rm->getMimicJointModels().empty();
+        for (auto& joint_name : joint_names) {  // seed / solution vectors: the variables of the group's joints in this order (:473-484, :619-629)
+            auto* joint_model = rm->getJointModel(joint_name);
+            if (!joint_model) continue;
+            for (size_t vi = 0; vi < joint_model->getVariableCount(); vi++) mv.group_vars.push_back((int)(joint_model->getFirstVariableIndex() + vi));
+        }
+        for (auto* j : joint_model_group->getActiveJointModels()) mv.group_joints.push_back((int32_t)j->getChildLinkModel()->getLinkIndex());
+        mv.link_index = [rm](const std::string& n) {
+            auto* l = rm->getLinkModel(n);
+            return l ? (int)l->getLinkIndex() : -1;
+        };
+        mv.variable_index = [rm](const std::string& n) { return (int)rm->getVariableIndex(n); };
+        mv.joint_link_index = [rm](const std::string& n) {
+            auto* j = rm->getJointModel(n);
+            return j ? (int)j->getChildLinkModel()->getLinkIndex() : -1;
+        };
+        mv.enforce_bounds = [rm](double* st) { rm->enforcePositionBounds(st); };
+        engine.initialize(flat->desc(), mv, p);  // (throws on an unknown solver mode or a missing HIP device: configuration errors)
 
         default_goals.clear();  // :279-329
         for (size_t i = 0; i < tip_frames_.size(); i++) {
@@ -313,86 +308,32 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
                                 options);
     }
 
-    // one compiled problem (Problem::initialize + RobotFK::initialize on the device side) per goal STRUCTURE; the numbers travel per query
-    const std::vector<bioik_problem*>& problemFor(const std::vector<const bio_ik::Goal*>& goals, const std::vector<std::string>& fixed) const {
-        std::ostringstream key;
-        key << std::hexfloat;
-        for (auto* g : goals) key << g->gpuOpcode() << ':' << g->gpuLinkName() << ':' << g->gpuVariableName() << ':' << g->getWeight() << ':' << g->isSecondary() << ';';
-        for (auto& f : fixed) key << '#' << f;
-        auto it = problems.find(key.str());
-        if (it != problems.end()) return it->second;
-        std::vector<bioik_goal_desc> gd;
-        for (auto* g : goals) {
-            if (g->gpuOpcode() < 0) throw std::runtime_error("bio_ik (MI355X): goal type without a device implementation (host-callback goal)");
-            bioik_goal_desc d{g->gpuOpcode(), -1, -1, g->isSecondary() ? 1 : 0, g->getWeight()};
-            if (!g->gpuLinkName().empty()) {
-                auto* l = robot_model->getLinkModel(g->gpuLinkName());
-                if (!l) throw std::runtime_error("link not found: " + g->gpuLinkName());  // problem.cpp:141
-                d.link = (int32_t)l->getLinkIndex();
-            }
-            if (!g->gpuVariableName().empty()) d.variable = robot_model->getVariableIndex(g->gpuVariableName());
-            gd.push_back(d);
-        }
-        std::vector<int32_t> group_joints, fixed_idx;
-        for (auto* j : joint_model_group->getActiveJointModels()) group_joints.push_back((int32_t)j->getChildLinkModel()->getLinkIndex());
-        for (auto& f : fixed) {
-            auto* j = robot_model->getJointModel(f);
-            if (!j) throw std::runtime_error("joint not found: " + f);
-            fixed_idx.push_back((int32_t)j->getChildLinkModel()->getLinkIndex());
-        }
-        bioik_problem_desc pd{};
-        pd.struct_size = sizeof(pd);
-        pd.n_group_joints = (uint32_t)group_joints.size(), pd.group_joints = group_joints.data();
-        pd.n_goals = (uint32_t)gd.size(), pd.goals = gd.data();
-        pd.n_fixed_joints = (uint32_t)fixed_idx.size(), pd.fixed_joints = fixed_idx.data();
-        std::vector<bioik_problem*> per_device;
-        for (auto* m : models) {
-            bioik_problem* p = nullptr;
-            if (bioik_problem_create(m, &pd, &p) != BIOIK_OK) {
-                for (auto* q : per_device) bioik_problem_destroy(q);
-                throw std::runtime_error(std::string("bio_ik (MI355X): ") + bioik_last_error());
-            }
-            per_device.push_back(p);
-        }
-        return problems[key.str()] = per_device;
-    }
-
-    // The batched core: n queries of one goal structure, ONE bioik_solve_batch call.  poses[k] (tips of query k; ignored with
-    // options.replace), seeds[k] (group variables); `timeout` bounds the whole call (ik_parallel.h:160, honoured on the device).
-    bool solveBatch(const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses, const std::vector<std::vector<double>>& ik_seed_states, double timeout,
-                    std::vector<std::vector<double>>& solutions, std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
-                    const kinematics::KinematicsQueryOptions& options, const moveit::core::RobotState* context_state) const {
+    // The batched core: n queries of one goal structure, marshalled and enqueued here, finished by finishBatch.  poses[k] (tips of query k;
+    // ignored with options.replace), seeds[k] (group variables); `timeout` bounds the whole call (ik_parallel.h:160, honoured on the device).
+    std::shared_ptr<bio_ik::core::Engine::Ticket> submitBatch(const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses,
+                                                              const std::vector<std::vector<double>>& ik_seed_states, double timeout,
+                                                              const kinematics::KinematicsQueryOptions& options, const moveit::core::RobotState* context_state) const {
         std::lock_guard<std::mutex> lock(mutex);
-        if (!robot_model || models.empty()) throw std::runtime_error("bio_ik (MI355X): plugin not initialised");
+        if (!robot_model || !joint_model_group || !engine.ready()) throw std::runtime_error("bio_ik (MI355X): plugin not initialised");
         auto* bio_ik_options = bio_ik::toBioIKKinematicsQueryOptions(&options);
-        const size_t n = ik_seed_states.size(), V = robot_model->getVariableCount();
-        // get variable default positions / context state, overwrite used variables with seed state (:465-485)
-        state.resize(V);
+        const size_t V = robot_model->getVariableCount();
+        bio_ik::core::Request rq;
+        // variable default positions / context state: what the seed states are laid over (:465-472)
+        rq.context.resize(V);
         if (context_state)
-            for (size_t i = 0; i < V; i++) state[i] = context_state->getVariablePositions()[i];
+            for (size_t i = 0; i < V; i++) rq.context[i] = context_state->getVariablePositions()[i];
         else
-            robot_model->getVariableDefaultPositions(state);
-        std::vector<double> seeds(n * V);
-        for (size_t k = 0; k < n; k++) {
-            for (size_t v = 0; v < V; v++) seeds[k * V + v] = state[v];
-            size_t i = 0;
-            for (auto& joint_name : getJointNames()) {
-                auto* joint_model = robot_model->getJointModel(joint_name);
-                if (!joint_model) continue;
-                for (size_t vi = 0; vi < joint_model->getVariableCount(); vi++) seeds[k * V + joint_model->getFirstVariableIndex() + vi] = ik_seed_states[k].at(i++);
-            }
-        }
+            robot_model->getVariableDefaultPositions(rq.context);
         const bool replace = bio_ik_options && bio_ik_options->replace;
-        // all goals: defaults first, then the caller's (:550-556)
-        std::vector<const bio_ik::Goal*> all_goals;
-        if (!replace)
-            for (auto& goal : default_goals) all_goals.push_back(goal.get());
-        if (bio_ik_options)
-            for (auto& goal : bio_ik_options->goals) all_goals.push_back(goal.get());
-        const std::vector<bioik_problem*>& shards = problemFor(all_goals, bio_ik_options ? bio_ik_options->fixed_joints : std::vector<std::string>());
-        bioik_problem* problem = shards.front();
-        const size_t P = (size_t)bioik_problem_param_count(problem);
-        // transform tips to the model frame (:487-502) and let every goal write its numbers
+        if (!replace)  // all goals: defaults first, then the caller's (:550-556)
+            for (auto& goal : default_goals) rq.goals.push_back(goal.get());
+        if (bio_ik_options) {
+            for (auto& goal : bio_ik_options->goals) rq.goals.push_back(goal.get());
+            rq.fixed_joints = bio_ik_options->fixed_joints;
+        }
+        rq.n_pose_goals = replace ? 0 : tip_frames_.size();
+        rq.seed_states = &ik_seed_states;
+        // the tips are given in the base frame: its global transform takes them to the model frame (:487-502)
         Frame7 r;
         if (context_state) {
             r = toFrame(context_state->getGlobalLinkTransform(getBaseFrame()));
@@ -400,77 +341,28 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
             temp_state->setToDefaultValues();
             r = toFrame(temp_state->getGlobalLinkTransform(getBaseFrame()));
         }
-        std::vector<double> params(n * P), row;
-        for (size_t k = 0; k < n; k++) {
-            row.clear();
-            size_t gi = 0;
-            for (auto* g : all_goals) {
-                if (!replace && gi < tip_frames_.size()) {
-                    const Frame7 m = concat(r, toFrame(ik_poses.at(k).at(gi)));
-                    auto* goal = static_cast<bio_ik::PoseGoal*>(const_cast<bio_ik::Goal*>(g));
-                    goal->setPosition(bio_ik::Vector3(m.v[0], m.v[1], m.v[2]));
-                    goal->setOrientation(bio_ik::Quaternion(m.v[3], m.v[4], m.v[5], m.v[6]));  // normalises (goal_types.h:146)
+        for (int c = 0; c < 7; c++) rq.base_frame[c] = r.v[c];
+        if (rq.n_pose_goals)
+            for (size_t k = 0; k < ik_seed_states.size(); k++)
+                for (size_t t = 0; t < rq.n_pose_goals; t++) {
+                    const Frame7 f = toFrame(ik_poses.at(k).at(t));
+                    rq.tip_poses.insert(rq.tip_poses.end(), f.v, f.v + 7);
                 }
-                g->gpuParams(row);
-                gi++;
-            }
-            for (size_t i = 0; i < P; i++) params[k * P + i] = row.at(i);
-        }
-        bioik_solve_params sp;
-        bioik_default_solve_params(&sp);
-        sp.mode = solverMode(mode);
-        sp.fk_mode = gpu_fk == "linear" ? BIOIK_FK_LINEAR : BIOIK_FK_EXACT;
-        sp.population = gpu_population, sp.islands = gpu_islands, sp.max_steps = gpu_max_steps;
-        sp.random_seed = (uint64_t)(uint32_t)random_seed;
-        sp.dpos = dpos, sp.drot = drot, sp.dtwist = dtwist;
-        sp.no_wipeout = no_wipeout ? 1 : 0;
-        sp.timeout = timeout > 0.0 ? timeout : 0.0;  // problem.timeout = t0 + timeout (:504); the budget starts with the launch
-        std::vector<double> sol(n * V), fit(n);
-        std::vector<int32_t> suc(n), steps(n);
-        solutions.assign(n, std::vector<double>());
-        error_codes.assign(n, moveit_msgs::MoveItErrorCodes());
-        // one call for the whole batch: a single device, or contiguous shards over the configured devices (no exchange between shards)
-        const int rc = shards.size() == 1 ? bioik_solve_batch(problem, &sp, n, seeds.data(), params.data(), sol.data(), fit.data(), suc.data(), steps.data())
-                                          : bioik_solve_batch_multi(shards.data(), (int)shards.size(), &sp, n, seeds.data(), params.data(), sol.data(), fit.data(),
-                                                                    suc.data(), steps.data());
-        if (rc != BIOIK_OK) {
-            for (auto& e : error_codes) e.val = moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;  // device errors never abort the caller
-            return false;
-        }
-        std::vector<int32_t> active((size_t)bioik_problem_active_variable_count(problem));
-        bioik_problem_active_variables(problem, active.data());
-        bool all_ok = true;
-        for (size_t k = 0; k < n; k++) {
-            double* st = &sol[k * V];
-            // wrap angles (:580-613)
-            for (int ivar : active) {
-                double v = st[ivar];
-                const moveit::core::JointModel* jm = robot_model->getJointOfVariable(ivar);
-                if (jm->getType() == moveit::core::JointModel::REVOLUTE && robot_model->getMimicJointModels().empty()) {
-                    const moveit::core::VariableBounds& b = jm->getVariableBounds()[(size_t)(ivar - jm->getFirstVariableIndex())];
-                    const double rr = seeds[k * V + ivar], lo = b.min_position_, hi = b.max_position_;
-                    if (rr < v - M_PI || rr > v + M_PI) {  // move close to initial guess
-                        v -= rr, v /= (2 * M_PI), v += 0.5, v -= std::floor(v), v -= 0.5, v *= (2 * M_PI), v += rr;
-                    }
-                    if (v > hi) v -= std::ceil(std::max(0.0, v - hi) / (2 * M_PI)) * (2 * M_PI);  // wrap at joint limits
-                    if (v < lo) v += std::ceil(std::max(0.0, lo - v) / (2 * M_PI)) * (2 * M_PI);
-                    if (v < lo) v = lo;  // clamp at edges
-                    if (v > hi) v = hi;
-                }
-                st[ivar] = v;
-            }
-            robot_model->enforcePositionBounds(st);  // :616
-            for (auto& joint_name : getJointNames()) {  // map result to jointgroup variables (:619-629)
-                auto* joint_model = robot_model->getJointModel(joint_name);
-                if (!joint_model) continue;
-                for (size_t vi = 0; vi < joint_model->getVariableCount(); vi++) solutions[k].push_back(st[joint_model->getFirstVariableIndex() + vi]);
-            }
-            const bool ok = suc[k] || options.return_approximate_solution;  // :638-641
-            error_codes[k].val = ok ? moveit_msgs::MoveItErrorCodes::SUCCESS : moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;
-            all_ok = all_ok && ok;
-        }
-        if (bio_ik_options && n) bio_ik_options->solution_fitness = fit[n - 1];  // :632-634
+        rq.timeout = timeout, rq.return_approximate_solution = options.return_approximate_solution, rq.bio = bio_ik_options;
+        return engine.submit(rq);
+    }
+    bool finishBatch(bio_ik::core::Engine::Ticket& ticket, std::vector<std::vector<double>>& solutions, std::vector<moveit_msgs::MoveItErrorCodes>& error_codes) const {
+        std::vector<uint8_t> ok;
+        const bool all_ok = engine.wait(ticket, solutions, ok);  // (the wait itself needs no lock: the ticket owns its arrays)
+        error_codes.assign(ok.size(), moveit_msgs::MoveItErrorCodes());
+        for (size_t k = 0; k < ok.size(); k++) error_codes[k].val = ok[k] ? moveit_msgs::MoveItErrorCodes::SUCCESS : moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION;
         return all_ok;
+    }
+    bool solveBatch(const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses, const std::vector<std::vector<double>>& ik_seed_states, double timeout,
+                    std::vector<std::vector<double>>& solutions, std::vector<moveit_msgs::MoveItErrorCodes>& error_codes,
+                    const kinematics::KinematicsQueryOptions& options, const moveit::core::RobotState* context_state) const {
+        auto ticket = submitBatch(ik_poses, ik_seed_states, timeout, options, context_state);
+        return finishBatch(*ticket, solutions, error_codes);
     }
 
     // :437-655, the overload every other one forwards to
@@ -497,14 +389,40 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
     bool supportsGroup(const moveit::core::JointModelGroup*, std::string* = nullptr) const override { return true; }  // :657-662
 };
 
+static const BioIKKinematicsPlugin& pluginOf(const kinematics::KinematicsBase& solver, const char* who) {
+    auto* plugin = dynamic_cast<const BioIKKinematicsPlugin*>(&solver);
+    if (!plugin) throw std::runtime_error(std::string(who) + ": not a bio_ik (MI355X) kinematics plugin");
+    return *plugin;
+}
 // the additive batched entry point of the north star ("a batched searchPositionIK()"), reachable from a KinematicsBase pointer
 bool searchPositionIKBatch(const kinematics::KinematicsBase& solver, const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses,
                            const std::vector<std::vector<double>>& ik_seed_states, double timeout, std::vector<std::vector<double>>& solutions,
                            std::vector<moveit_msgs::MoveItErrorCodes>& error_codes, const kinematics::KinematicsQueryOptions& options,
                            const moveit::core::RobotState* context_state) {
-    auto* plugin = dynamic_cast<const BioIKKinematicsPlugin*>(&solver);
-    if (!plugin) throw std::runtime_error("searchPositionIKBatch: not a bio_ik (MI355X) kinematics plugin");
-    return plugin->solveBatch(ik_poses, ik_seed_states, timeout, solutions, error_codes, options, context_state);
+    return pluginOf(solver, "searchPositionIKBatch").solveBatch(ik_poses, ik_seed_states, timeout, solutions, error_codes, options, context_state);
+}
+
+
+struct BatchTicket::Impl {
+    std::shared_ptr<bio_ik::core::Engine::Ticket> ticket;
+};
+BatchTicket::BatchTicket() {}
+BatchTicket::~BatchTicket() {}
+BatchTicket::BatchTicket(BatchTicket&&) = default;
+BatchTicket& BatchTicket::operator=(BatchTicket&&) = default;
+BatchTicket searchPositionIKBatchAsync(const kinematics::KinematicsBase& solver, const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses,
+                                       const std::vector<std::vector<double>>& ik_seed_states, double timeout, const kinematics::KinematicsQueryOptions& options,
+                                       const moveit::core::RobotState* context_state) {
+    BatchTicket t;
+    t.impl.reset(new BatchTicket::Impl{pluginOf(solver, "searchPositionIKBatchAsync").submitBatch(ik_poses, ik_seed_states, timeout, options, context_state)});
+    return t;
+}
+bool searchPositionIKBatchWait(const kinematics::KinematicsBase& solver, BatchTicket& ticket, std::vector<std::vector<double>>& solutions,
+                               std::vector<moveit_msgs::MoveItErrorCodes>& error_codes) {
+    if (!ticket.impl || !ticket.impl->ticket) throw std::runtime_error("searchPositionIKBatchWait: empty ticket");
+    const bool ok = pluginOf(solver, "searchPositionIKBatchWait").finishBatch(*ticket.impl->ticket, solutions, error_codes);
+    ticket.impl.reset();
+    return ok;
 }
 
 }  // namespace bio_ik_kinematics_plugin

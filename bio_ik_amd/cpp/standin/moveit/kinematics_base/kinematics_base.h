@@ -69,3 +69,27 @@ protected:
     double search_discretization_ = 0.0;
 };
 }  // namespace kinematics
+
+// RobotState::setFromIK (declared in the robot_state stand-in): MoveIt's flow reduced to what a kinematics plugin sees -- the seed is
+// the state's own group variables in the solver's joint order, the poses go to the solver unchanged (callers of this stand-in give them
+// in the solver's base frame), the state is the context state, and a solution is written back into the state.
+inline bool moveit::core::RobotState::setFromIK(const JointModelGroup* group, const EigenSTL::vector_Affine3d& poses, const std::vector<std::string>& /*tips*/,
+                                                unsigned int /*attempts*/, double timeout, const GroupStateValidityCallbackFn& /*constraint*/,
+                                                const kinematics::KinematicsQueryOptions& options) {
+    const std::shared_ptr<kinematics::KinematicsBase>& solver = group->getSolverInstance();
+    if (!solver) return false;
+    std::vector<double> seed, solution;
+    for (auto& jn : solver->getJointNames()) seed.push_back(getVariablePosition(jn));
+    std::vector<geometry_msgs::Pose> ik_poses;
+    for (auto& T : poses) {
+        const Eigen::Quaterniond q(T.rotation());
+        geometry_msgs::Pose p;
+        p.position.x = T.translation().x(), p.position.y = T.translation().y(), p.position.z = T.translation().z();
+        p.orientation.x = q.x(), p.orientation.y = q.y(), p.orientation.z = q.z(), p.orientation.w = q.w();
+        ik_poses.push_back(p);
+    }
+    moveit_msgs::MoveItErrorCodes error;
+    if (!solver->searchPositionIK(ik_poses, seed, timeout, std::vector<double>(), solution, kinematics::KinematicsBase::IKCallbackFn(), error, options, this)) return false;
+    for (size_t i = 0; i < solution.size(); i++) setVariablePosition(solver->getJointNames()[i], solution[i]);
+    return true;
+}

@@ -33,6 +33,9 @@ struct ModelInterface {
 };
 typedef std::shared_ptr<ModelInterface> ModelInterfaceSharedPtr;
 }  // namespace urdf
+namespace kinematics {
+class KinematicsBase;
+}
 namespace moveit {
 namespace core {
 struct VariableBounds {
@@ -95,6 +98,11 @@ public:
 class RobotModel;
 class JointModelGroup {
 public:
+    std::shared_ptr<kinematics::KinematicsBase> solver_instance_;  // what the kinematics plugin loader attaches to the group
+    const std::shared_ptr<kinematics::KinematicsBase>& getSolverInstance() const { return solver_instance_; }
+    void setSolverInstance(const std::shared_ptr<kinematics::KinematicsBase>& s) { solver_instance_ = s; }  // stand-in only
+    const RobotModel* parent_model_ = nullptr;
+    const RobotModel& getParentModel() const { return *parent_model_; }
     std::string name_;
     std::vector<const JointModel*> joint_models_, active_joint_models_;
     std::vector<std::string> end_effector_tips_;
@@ -227,6 +235,24 @@ public:
                 mimic_joints_.push_back(j.get());
             }
     }
+    // a group from an explicit joint list (SRDF <group><joint .../>...) with its end-effector tips
+    void addJointsGroup(const std::string& name, const std::vector<std::string>& joints, const std::vector<std::string>& tips) {
+        std::unique_ptr<JointModelGroup> g(new JointModelGroup());
+        g->name_ = name;
+        for (auto& jn : joints) {
+            const JointModel* j = getJointModel(jn);
+            if (!j) throw std::runtime_error("stand-in RobotModel: unknown joint " + jn);
+            g->joint_models_.push_back(j);
+            if (j->getType() != JointModel::FIXED && !j->getMimic()) g->active_joint_models_.push_back(j);
+        }
+        g->end_effector_tips_ = tips;
+        g->parent_model_ = this;
+        groups_[name] = std::move(g);
+    }
+    JointModelGroup* getJointModelGroup(const std::string& name) {  // (non-const: the stand-in's loader attaches the solver instance)
+        auto it = groups_.find(name);
+        return it == groups_.end() ? nullptr : it->second.get();
+    }
     void addChainGroup(const std::string& name, const std::string& base, const std::string& tip) {
         std::unique_ptr<JointModelGroup> g(new JointModelGroup());
         g->name_ = name;
@@ -236,6 +262,7 @@ public:
             g->joint_models_.push_back(j);
             if (j->getType() != JointModel::FIXED && !j->getMimic()) g->active_joint_models_.push_back(j);
         }
+        g->parent_model_ = this;
         groups_[name] = std::move(g);
     }
 };

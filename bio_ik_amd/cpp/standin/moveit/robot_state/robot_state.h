@@ -1,8 +1,16 @@
 // stand-in for moveit/robot_state/robot_state.h: variable positions and global link transforms (see ../../README.md)
 #pragma once
+#include <functional>
+
+#include <eigen_stl_containers/eigen_stl_containers.h>
 #include <moveit/robot_model/robot_model.h>
+namespace kinematics {
+struct KinematicsQueryOptions;
+}
 namespace moveit {
 namespace core {
+class RobotState;
+typedef std::function<bool(RobotState* robot_state, const JointModelGroup* joint_group, const double* joint_group_variable_values)> GroupStateValidityCallbackFn;
 class RobotState {
     RobotModelConstPtr model_;
     std::vector<double> position_;
@@ -15,6 +23,11 @@ public:
     double* getVariablePositions() { return position_.data(); }
     void setVariablePositions(const std::vector<double>& p) { position_ = p; }
     void setVariablePosition(const std::string& name, double v) { position_[(size_t)model_->getVariableIndex(name)] = v; }
+    double getVariablePosition(const std::string& name) const { return position_[(size_t)model_->getVariableIndex(name)]; }
+    // RobotState::setFromIK, the multi-tip overload with explicit options (defined with the KinematicsBase stand-in, kinematics_base.h):
+    // the group's solver instance is asked for a solution seeded with this state, which is written back on success
+    bool setFromIK(const JointModelGroup* group, const EigenSTL::vector_Affine3d& poses, const std::vector<std::string>& tips, unsigned int attempts,
+                   double timeout, const GroupStateValidityCallbackFn& constraint, const kinematics::KinematicsQueryOptions& options);
     Eigen::Isometry3d getGlobalLinkTransform(const std::string& link_name) const {
         std::vector<const LinkModel*> chain;
         for (const LinkModel* l = model_->getLinkModel(link_name); l; l = l->getParentLinkModel()) chain.insert(chain.begin(), l);

@@ -192,6 +192,54 @@ int main(int argc, char** argv) {
         CHECK(sols.size() == 3);
         for (size_t k = 0; k < 3; k++) CHECK(codes[k].val == moveit_msgs::MoveItErrorCodes::SUCCESS && tipError(sols[k], poses[k]) < 1.0);
     }
+    // ... and without waiting: three batches in flight on the plugin's streams, waited for out of order; retries of one query draw from
+    // advancing random streams (like the reference's generator state) and still solve it
+    {
+        std::vector<std::vector<geometry_msgs::Pose>> bp;
+        for (auto& p : poses) bp.push_back({p});
+        bio_ik_kinematics_plugin::BatchTicket t0 = bio_ik_kinematics_plugin::searchPositionIKBatchAsync(*solver, bp, seeds, TEST_TIMEOUT);
+        bio_ik_kinematics_plugin::BatchTicket t1 = bio_ik_kinematics_plugin::searchPositionIKBatchAsync(*solver, bp, seeds, TEST_TIMEOUT);
+        bio_ik_kinematics_plugin::BatchTicket t2 = bio_ik_kinematics_plugin::searchPositionIKBatchAsync(*solver, bp, seeds, TEST_TIMEOUT);
+        for (auto* t : {&t2, &t0, &t1}) {
+            std::vector<std::vector<double>> sols;
+            std::vector<moveit_msgs::MoveItErrorCodes> codes;
+            CHECK(bio_ik_kinematics_plugin::searchPositionIKBatchWait(*solver, *t, sols, codes) && sols.size() == 3);
+            for (size_t k = 0; k < 3; k++) CHECK(codes[k].val == moveit_msgs::MoveItErrorCodes::SUCCESS && tipError(sols[k], poses[k]) < 1.0);
+        }
+        bool threw = false;
+        try {
+            std::vector<std::vector<double>> sols;
+            std::vector<moveit_msgs::MoveItErrorCodes> codes;
+            bio_ik_kinematics_plugin::searchPositionIKBatchWait(*solver, t0, sols, codes);  // a ticket is waited for once
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
+    // a goal without a device implementation is refused with a message, not ignored
+    {
+        bio_ik::BioIKKinematicsQueryOptions opts;
+        opts.goals.emplace_back(new bio_ik::LinkFunctionGoal("r_wrist_roll_link", [](const bio_ik::Vector3& p, const bio_ik::Quaternion&) { return p.z() * p.z(); }));
+        bool threw = false;
+        try {
+            solver->searchPositionIK(std::vector<geometry_msgs::Pose>{poses[0]}, seeds[0], TEST_TIMEOUT, no_limits, solution, kinematics::KinematicsBase::IKCallbackFn(), code, opts);
+        } catch (const std::runtime_error& e) {
+            threw = std::string(e.what()).find("without a device implementation") != std::string::npos;
+        }
+        CHECK(threw);
+    }
+    // re-initialising with an unknown group reports the failure and leaves no half-initialised plugin behind
+    {
+        std::unique_ptr<kinematics::KinematicsBase> other(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
+        other->initialize(*rm, "no_such_group", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0);
+        bool threw = false;
+        try {
+            other->searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, solution, code);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
     // configuration errors throw, as the reference's ERROR macro does
     {
         ros::set_param("mode", "gd_r_42");

@@ -21,7 +21,7 @@ SRDF_FIXED_BASE = SRDF.replace('<group name="arm_chain">', "<virtual_joint name=
 def build(libdir, libname, tmp_path, timeout_s=None):
     exe = str(tmp_path / "test_urdf")
     cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s] if timeout_s else []) + [
-        "-I", os.path.join(ROOT, "bio_ik_amd", "cpp"), os.path.join(ROOT, "tests", "cpp", "test_urdf.cpp"),
+        "-I", os.path.join(ROOT, "bio_ik_amd", "cpp"), "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_urdf.cpp"),
         "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread", "-o", exe]
     subprocess.run(cmd, check=True)
     return exe
