@@ -4,8 +4,9 @@
 // What the reference gets from moveit::core::RobotModel / JointModelGroup (src/forward_kinematics.h:192-213,
 // include/bio_ik/robot_info.h:70-106, src/kinematics_plugin.cpp:167-189) is built from the robot description itself, with the same
 // conventions as the Python reader (bio_ik_amd/urdf.py; tests/test_cpp_urdf.py holds the two against each other):
-//   * links in the order RobotModel::buildRecursive visits them (depth first from the root, children in file order), so link and
-//     variable indices match a MoveIt-loaded model of the same URDF;
+//   * links in the order RobotModel::buildRecursive visits them (depth first from the root, the children of a link in alphabetical
+//     order of their joint names: urdfdom keeps joints in a name-keyed map), so link and variable indices match a MoveIt-loaded
+//     model of the same URDF;
 //   * joints: fixed | revolute | continuous | prismatic | floating | planar, <origin xyz rpy>, <axis> (URDF default 1 0 0), <limit lower upper velocity>,
 //     <mimic joint multiplier offset> (the followed joint may come later in the file); <inertial> mass and origin (BalanceGoal);
 //   * SRDF <group>: <chain base_link tip_link>, <joint name>, <link name> (= its parent joint), nested <group name>; <end_effector
@@ -280,6 +281,10 @@ inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const s
         children[j.parent].push_back(&j);
         if (!is_child.insert(j.child).second) throw std::runtime_error("link " + j.child + " has two parent joints");
     }
+    // urdfdom keeps a model's joints in a map keyed by joint name and fills every link's child list from it (urdf::ModelInterface::
+    // initTree), so the siblings MoveIt's RobotModel::buildRecursive walks are in ALPHABETICAL order of their joint names, whatever
+    // the order of the file
+    for (auto& kv : children) std::sort(kv.second.begin(), kv.second.end(), [](const UrdfJoint* a, const UrdfJoint* b) { return a->name < b->name; });
     std::vector<std::string> roots;
     for (auto& l : links)
         if (!is_child.count(l)) roots.push_back(l);
@@ -305,7 +310,7 @@ inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const s
     } else {
         m->addLink(roots[0], "", "", "fixed", zero, zero, z_axis);
     }
-    std::vector<std::pair<const std::vector<const UrdfJoint*>*, size_t>> stack;  // depth first, children in file order
+    std::vector<std::pair<const std::vector<const UrdfJoint*>*, size_t>> stack;  // depth first, siblings by joint name
     static const std::vector<const UrdfJoint*> none;
     auto kids = [&](const std::string& l) -> const std::vector<const UrdfJoint*>* {
         auto it = children.find(l);

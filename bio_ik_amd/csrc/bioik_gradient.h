@@ -85,7 +85,7 @@ BIOIK_DEV void pinv_solve_lds(const double* J, int rows, int cols, const double*
         sigma[k] = sqrt(n2);
         if (sigma[k] > smax) smax = sigma[k];
     }
-    const double threshold = 2.220446049250313e-16 * (double)(rows > cols ? rows : cols) * smax;
+    const double threshold = 2.220446049250313e-16 * (double)(rows < cols ? rows : cols) * smax;  // Eigen: epsilon * diagSize = min(rows, cols)
     for (int i = 0; i < cols; i++) x[i] = 0.0;
     for (int k = 0; k < q; k++) {
         if (!(sigma[k] > threshold)) continue;

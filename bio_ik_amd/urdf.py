@@ -2,7 +2,8 @@
 
 What the reference gets from moveit::core::RobotModel (src/forward_kinematics.h:192-213, include/bio_ik/robot_info.h:70-106,
 src/kinematics_plugin.cpp:167-189) is built here from the robot description itself:
-  * links in the order MoveIt's RobotModel::buildRecursive visits them (depth first from the root, children in file order), so
+  * links in the order MoveIt's RobotModel::buildRecursive visits them (depth first from the root, siblings in alphabetical order of
+    their joint names, as urdfdom's name-keyed joint map yields them), so
     link / variable indices match a MoveIt-loaded model of the same URDF;
   * joints: fixed | revolute | continuous | prismatic | floating | planar, <origin xyz rpy>, <axis> (URDF default 1 0 0),
     <limit lower upper velocity>, <mimic joint multiplier offset>;
@@ -65,6 +66,10 @@ def load_urdf(urdf_xml, srdf_xml=None):
         if j["child"] in is_child:
             raise ValueError("link %r has two parent joints" % j["child"])
         is_child.add(j["child"])
+    # urdfdom keeps a model's joints in a map keyed by joint name and fills every link's child list from it (ModelInterface::initTree):
+    # the siblings RobotModel::buildRecursive walks are in alphabetical order of their joint names, whatever the order of the file
+    for l in children:
+        children[l].sort(key=lambda j: j["name"])
     roots = [l for l in links if l not in is_child]
     if len(roots) != 1:
         raise ValueError("a URDF tree has exactly one root link, found %r" % roots)
@@ -86,7 +91,7 @@ def load_urdf(urdf_xml, srdf_xml=None):
     else:
         m.add_link(roots[0])
     stack = [iter(children[roots[0]])]
-    while stack:  # depth first, children in file order (RobotModel::buildRecursive)
+    while stack:  # depth first, siblings by joint name (RobotModel::buildRecursive over urdfdom's child lists)
         j = next(stack[-1], None)
         if j is None:
             stack.pop()

@@ -6,7 +6,7 @@
 //
 // The reference's `jac` solves its least-squares step with Eigen::JacobiSVD (ik_gradient.cpp:117); Eigen is a third-party library that
 // is absent here, so the step is restated from the published definition — the minimum-norm least-squares solution through the
-// singular value decomposition, singular values below epsilon * max(rows, cols) * sigma_max treated as zero (Eigen's default
+// singular value decomposition, singular values below epsilon * min(rows, cols) * sigma_max treated as zero (Eigen's default
 // threshold) — with a one-sided Jacobi SVD (Hestenes).  The solution is unique, the path to it is not: parity with Eigen would be to
 // rounding, not to the bit; against the reference's own sources compiled with the stand-in Eigen of oracle/ref_shim it is exact.
 #pragma once
@@ -63,7 +63,7 @@ inline void pinv_solve(const double* J, int rows, int cols, const double* b, dou
         sigma[k] = std::sqrt(n2);
         if (sigma[k] > smax) smax = sigma[k];
     }
-    const double threshold = 2.220446049250313e-16 * (double)(rows > cols ? rows : cols) * smax;
+    const double threshold = 2.220446049250313e-16 * (double)(rows < cols ? rows : cols) * smax;  // Eigen: epsilon * diagSize = min(rows, cols)
     for (int i = 0; i < cols; i++) x[i] = 0.0;
     for (int k = 0; k < q; k++) {
         if (!(sigma[k] > threshold)) continue;

@@ -111,11 +111,12 @@ def mimic_robot():
     m.add_link("l4", "l3", "e2", "revolute", xyz=(0.25, 0.0, 0.0), axis=(0, 1, 0), lower=-3.0, upper=3.0, velocity=2.5, mimic=("s2", -0.5, 0.1))
     m.add_link("l5", "l4", "w1", "revolute", xyz=(0.2, 0.0, 0.0), axis=(1, 0, 0), lower=-3.0, upper=3.0, velocity=3.0)
     m.add_link("l6", "l5", "w2", "revolute", xyz=(0.1, 0.0, 0.0), axis=(0, 1, 0), lower=-2.0, upper=2.0, velocity=3.0)
-    m.add_link("tool", "l6", "tool_joint", "fixed", xyz=(0.08, 0.0, 0.0))
+    # (the children of l6 in the order a MoveIt-loaded model has them: alphabetical by joint name, bio_ik_amd/urdf.py)
     m.add_link("finger_l", "l6", "finger_l_joint", "prismatic", xyz=(0.05, 0.03, 0.0), axis=(0, 1, 0), lower=0.0, upper=0.04, velocity=0.1)
     m.add_link("finger_r", "l6", "finger_r_joint", "prismatic", xyz=(0.05, -0.03, 0.0), axis=(0, -1, 0), lower=0.0, upper=0.04, velocity=0.1,
                mimic=("finger_l_joint", 1.0, 0.0))
     m.add_link("finger_r_tip", "finger_r", "finger_r_tip_joint", "fixed", xyz=(0.04, 0.0, 0.0))
+    m.add_link("tool", "l6", "tool_joint", "fixed", xyz=(0.08, 0.0, 0.0))
     m.add_group("arm", joints=["s1", "s2", "e1", "e2", "w1", "w2", "finger_l_joint", "finger_r_joint"], tips=["tool", "finger_r_tip"])
     return m
 
