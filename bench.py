@@ -47,6 +47,18 @@ HBM_PEAK = 8.0e12
 FP64_PEAK = 78.6e12  # MI355X FP64 vector (non-matrix) peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def kernel_sources_hash():
+    """sha256 over the kernel sources (bio_ik_amd/csrc/*.h, *.hip): what a profile under profiles/ is valid for"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bio_ik_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def flops_per_evaluation(n_moving, n_revolute, n_pose_goals):
     """algorithmic flops of ONE exact-FK fitness evaluation of ONE individual"""
     return 130.0 * n_moving + 40.0 * n_revolute + 25.0 * n_pose_goals
@@ -76,8 +88,10 @@ def _timed_device_solves(h, p, n, inputs, bufs, streams, reps):
     return dt, float(sum(a.elapsed_time(b) for a, b in ev) / len(ev))
 
 
-def other_configs(dev, nfl, streams):
+def other_configs(dev, nfl, streams, cpu_baseline=False):
     """BASELINE.json configs[2] and configs[3] at 4096 queries per launch, the same issue pattern as the headline figure"""
+    import time
+
     import numpy as np
     import torch
 
@@ -114,6 +128,27 @@ def other_configs(dev, nfl, streams):
                      "roofline": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                                   "frac": flops / (kernel_ms * 1e-3) / FP64_PEAK, "chip_level_frac": flops / dt / FP64_PEAK,
                                   "hbm_notional_frac": gens * b_gen / (kernel_ms * 1e-3) / HBM_PEAK}}
+        if cpu_baseline:
+            # the reference's own code on one host core, the first queries of the same batch (a bounded sample: it solves tens to hundreds
+            # of these per second): its hard-coded population, linearised phenotypes, success test after every step, <= 512 steps
+            try:
+                from oracle import ref
+                if ref.release_available():
+                    ns = 96 if name == "c3" else 192
+                    seeds0, params0, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=0xB101C)
+                    r = ref.Reference(template, abi.default_solve_params(mode="bio2_memetic", random_seed=1), release=True)
+                    r.solve_batch(seeds0[:2], params0[:2], 8)  # (constructs the solver outside the timing)
+                    t1 = time.perf_counter()
+                    _, _, rsuc, rsteps = r.solve_batch(seeds0[:ns], params0[:ns], 512)
+                    dtc = time.perf_counter() - t1
+                    res[name]["cpu_baseline"] = {"value": float(rsuc.sum()) / dtc, "unit": "solves/s", "cores": 1, "kind": "reference", "seconds": dtc,
+                                                 "success_rate": float(rsuc.mean()), "mean_steps": float(rsteps.mean()),
+                                                 "sample": "first %d queries of the batch on stream 0; the reference's own bio2_memetic (oracle/_ref, Release flags), "
+                                                           "2 species x (2+16), linearised FK, <= 512 steps, 1 thread" % ns}
+                    if res[name]["cpu_baseline"]["value"] > 0:
+                        res[name]["speedup_vs_cpu_1thread"] = res[name]["value"] / res[name]["cpu_baseline"]["value"]
+            except Exception as e:  # (the headline line must not depend on this leg)
+                res[name]["cpu_baseline"] = {"error": repr(e)}
     return res
 
 
@@ -344,13 +379,19 @@ def main():
     fpe = flops_per_evaluation(n_moving, n_rev, 1)
     evaluations = generations * POP + 4.0 * steps_per_launch
     alg_flops = evaluations * fpe
-    traffic = None
+    # measured HBM traffic of a solve: a rocprofv3 PMC figure from profiles/ (it cannot be collected inside this process), valid only for
+    # the kernel sources it was measured on -- traffic.json carries their hash, and a figure taken on other sources is not reported
+    traffic, traffic_note = None, "no profiles/traffic.json"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_solve_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            tj = json.load(open(tpath))
+            if tj.get("kernel_sources_sha256") == kernel_sources_hash():
+                traffic, traffic_note = tj.get("k_solve_hbm_bytes_per_launch"), "measured on these kernel sources (%s)" % tj.get("source")
+            else:
+                traffic_note = "profiles/traffic.json was measured on other kernel sources (%s): not reported" % tj.get("source")
+        except Exception as e:
+            traffic_note = "profiles/traffic.json unreadable: %r" % e
 
     out = {
         "metric": "IK solves/sec (pop=128, 7-DOF PoseGoal batch)",
@@ -374,7 +415,7 @@ def main():
         "max_pos_err_m_of_successes": pos_err,
         "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic,
+                     "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
                      "kernel": "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
                      "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
@@ -420,6 +461,8 @@ def main():
         out["streamed_fitness"] = {"kernel": "k_stream_fitness", "individuals_per_launch": units * POP, "ms": ms,
                                    "evaluations_per_s": units * POP / (ms * 1e-3), "algorithmic_bytes_per_launch": sbytes,
                                    "achieved_GBps": sbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": sbytes / (ms * 1e-3) / HBM_PEAK,
+                                   "fp64_TFLOPs": units * POP / (ms * 1e-3) * fpe / 1e12, "frac_of_fp64_peak": units * POP / (ms * 1e-3) * fpe / FP64_PEAK,
+                                   "bound": "fp64_valu (the walk's arithmetic, not the 8 (D + 1) bytes per individual, limits this kernel: both roofs of SURVEY.md section 8(d) are on the line)",
                                    "layout": "genes [unit][D][pop] f64 in HBM, 512-byte segments per wavefront load"}
 
     if rank == 0 and world == 1 and not args.timed_only:
@@ -432,6 +475,28 @@ def main():
         out["host_pointer_entry"] = {"ms_per_call": min(ts) * 1e3, "solves_per_s": float(hs[2].sum()) / min(ts),
                                      "results_identical_to_device_entry": bool(np.array_equal(hs[0], sol) and np.array_equal(hs[2], suc)),
                                      "note": "bioik_solve_batch: host arrays in and out (PCIe-inclusive), one launch at a time; never `value`"}
+
+    if rank == 0 and world == 1 and not args.timed_only:
+        # a stream of batches through the host-pointer boundary WITHOUT waiting for each: bioik_solve_batch_submit / _wait (what
+        # searchPositionIKBatchAsync of the plugin calls), three solves of the handle in flight, PCIe transfers included
+        host_in = [(seeds, params)] + [tuple(x.cpu().numpy() for x in inputs[k]) for k in range(1, len(inputs))]
+        kp = 18
+        pending = []
+        got_success = 0.0
+        for i in range(3):
+            h.wait_batch(h.submit_batch(p, *host_in[i % len(host_in)]))
+        t1 = time.perf_counter()
+        for i in range(kp):
+            pending.append(h.submit_batch(p, *host_in[i % len(host_in)]))
+            if len(pending) == 3:
+                got_success += float(h.wait_batch(pending.pop(0))[2].sum())
+        while pending:
+            got_success += float(h.wait_batch(pending.pop(0))[2].sum())
+        dtp = (time.perf_counter() - t1) / kp
+        out["host_pointer_pipelined"] = {"value": got_success / kp / dtp, "unit": "solves/s", "ms_per_step": dtp * 1e3, "batches_in_flight": 3,
+                                         "note": "bioik_solve_batch_submit / bioik_solve_batch_wait: host arrays in and out (page-locked staging, PCIe-inclusive), "
+                                                 "three solves of one handle in flight on the library's own streams; the rate a C++ caller of "
+                                                 "searchPositionIKBatchAsync gets; never `value`"}
 
     if rank == 0 and world == 1 and not args.timed_only:
         # The same queries at the REFERENCE'S OWN parameters (2 species x (2 elites + 16 children), linearised phenotypes, budget
@@ -480,7 +545,7 @@ def main():
                                  "sample": "4096 queries per stream, seed = target configuration + N(0, 0.1 rad) clipped to the joint limits"}
 
     if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_CONFIGS", "1") != "0":
-        out["configs"] = other_configs(dev, nfl, streams)
+        out["configs"] = other_configs(dev, nfl, streams, cpu_baseline=not args.no_cpu_baseline)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle import orc, ref

@@ -30,7 +30,10 @@ summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format
                                     "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "
                                             "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; the rest is scratch traffic (register spills of cold paths)."}}
 json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
-json.dump({"k_solve_hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "source": "profiles/%s_pmc_k_solve.json" % rnd}, open(os.path.join(p, "traffic.json"), "w"), indent=1)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_sources_hash: the figure is valid for the kernel sources it was measured on, and bench.py checks that)
+json.dump({"k_solve_hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "source": "profiles/%s_pmc_k_solve.json" % rnd, "kernel_sources_sha256": bench.kernel_sources_hash()},
+          open(os.path.join(p, "traffic.json"), "w"), indent=1)
 # bench.py reads `roofline.traffic` from profiles/traffic.json as it was BEFORE this session's PMC passes ran; the copy kept under
 # profiles/ carries the figure of its own session (same library, same box), with the value the line was printed with beside it
 b = json.load(open(os.path.join(p, rnd + "_bench.json")))
