@@ -601,12 +601,17 @@ BIOIK_DEV double joint_value(const XA& x, int k, int mimic_src, double mimic_fac
     return v;
 }
 
-#ifndef BIOIK_FK_BLOCK
-#define BIOIK_FK_BLOCK 1  // measured on MI355X: 1, 2 and 4 are within 3 % (the kernel is not latency-bound here)
-#endif
 //   prefix     LDS or null, [7]: the frame behind ops[0..n_prefix), which is the same for every individual of the query; the
 //              walk then starts at op n_prefix (the kernels that own a query compute it once, fk_prefix)
-template <class PB, class XA, class TipFn>
+//   COOP       lanes that walk the SAME individual together (0: every lane its own).  The solver evaluates single individuals --
+//              an elite for the species ranking, the linearisation point of the memetic phase, the solution's success test -- on a
+//              whole wavefront (64), or on one half of it per species (32), and in the plain walk every one of those lanes repeats
+//              every joint's trigonometry.  With COOP lane k of the group takes the value of op k and its sincos ONCE, all joints at a
+//              time, and the chain loop fetches the three numbers of its joint from that lane (v_readlane / ds_bpermute): the
+//              composition -- the part that has to be sequential -- is what is left in the loop, about a third of a joint's
+//              instructions, and the frames are the same bits (the same sincos of the same value, composed in the same order).
+//              Needs n_chain_ops <= COOP (else the plain walk runs).
+template <int COOP = 0, class PB, class XA, class TipFn>
 BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int tid = p_tid(), nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
@@ -620,68 +625,69 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
             tip_fn(t, f);
         }
     }
-    // BIOIK_FK_BLOCK joints per trip.  Phase A: their values and half-angle trigonometry — independent polynomial
-    // chains the scheduler can interleave (sincos is computed for prismatic joints too and discarded: no branch).
-    // Phase B: the four rigid transforms, which are inherently sequential.
     int k_begin = 0;
     if (prefix) {
         k_begin = pb->n_prefix;
         if (k_begin > 0) f = f7_load(prefix);
     }
     if constexpr (pb_flavour<PB>::general && std::is_same<XA, XV>::value) multi_joint_prologue(pb, x, slots);
-    for (int k0 = k_begin; k0 < n_chain; k0 += BIOIK_FK_BLOCK) {
-        double xv[BIOIK_FK_BLOCK], sn[BIOIK_FK_BLOCK], cs[BIOIK_FK_BLOCK];
-#pragma unroll
-        for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
-            const int kk = k0 + j < n_chain ? k0 + j : n_chain - 1;
-            xv[j] = joint_value(x, kk, pb->ops[kk].mimic_src, pb->ops[kk].mimic_factor, pb->ops[kk].mimic_offset);
+    // COOP: this lane's joint, its value and half-angle trigonometry (computed for prismatic joints too and discarded: no branch)
+    const bool coop = COOP > 0 && n_chain <= COOP;
+    const int coop_base = COOP > 0 ? ((tid & 63) & ~(COOP - 1)) : 0;  // first lane of this lane's group inside its wavefront
+    double my_xv = 0.0, my_sn = 0.0, my_cs = 1.0;
+    if (coop) {
+        const int mine = (tid & 63) - coop_base, kk = mine < n_chain ? mine : n_chain - 1;
+        my_xv = joint_value(x, kk, pb->ops[kk].mimic_src, pb->ops[kk].mimic_factor, pb->ops[kk].mimic_offset);
+        p_sincos(my_xv * 0.5, &my_sn, &my_cs);
+    }
+    for (int k = k_begin; k < n_chain; k++) {
+        double xv, sn, cs;
+        if (coop) {
+            if (COOP >= 64) xv = p_read_lane(my_xv, k), sn = p_read_lane(my_sn, k), cs = p_read_lane(my_cs, k);
+            else xv = p_shfl(my_xv, coop_base + k), sn = p_shfl(my_sn, coop_base + k), cs = p_shfl(my_cs, coop_base + k);
+        } else {
+            xv = joint_value(x, k, pb->ops[k].mimic_src, pb->ops[k].mimic_factor, pb->ops[k].mimic_offset);
+            p_sincos(xv * 0.5, &sn, &cs);
         }
-#pragma unroll
-        for (int j = 0; j < BIOIK_FK_BLOCK; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
-#pragma unroll
-        for (int j = 0; j < BIOIK_FK_BLOCK; j++) {
-            const int k = k0 + j;
-            if (k >= n_chain) break;
-            const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
-            const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
-            const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
-            const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
-            const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
-            if (ls >= 0) {
-                const double* s = slots + (size_t)ls * 7 * nth + tid;
-                f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
-            } else if (k > 0 && src < 0) {
-                f = f7_identity();
-            }
-            if (type == BIOIK_OP_REVOLUTE) {  // (wavefront-uniform: a scalar branch)
-                F7 fj[1] = {f};
-                const double s1[1] = {sn[j]}, c1[1] = {cs[j]};
-                revolute_apply<1>(fj, s1, c1, RevConst{cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3, pb->ops[k].pos_kind, pb->ops[k].rot_kind});
-                f = fj[0];
+        const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
+        const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
+        const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
+        const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
+        const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
+        if (ls >= 0) {
+            const double* s = slots + (size_t)ls * 7 * nth + tid;
+            f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
+        } else if (k > 0 && src < 0) {
+            f = f7_identity();
+        }
+        if (type == BIOIK_OP_REVOLUTE) {  // (wavefront-uniform: a scalar branch)
+            F7 fj[1] = {f};
+            const double s1[1] = {sn}, c1[1] = {cs};
+            revolute_apply<1>(fj, s1, c1, RevConst{cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3, pb->ops[k].pos_kind, pb->ops[k].rot_kind});
+            f = fj[0];
+        } else {
+            const V3 lp = v3(BK_FMA(xv, cb0, cp0), BK_FMA(xv, cb1, cp1), BK_FMA(xv, cb2, cp2));
+            f.p = f.p + qrot(f.q, lp);
+            f.q = qmul(f.q, Q4{ca0, ca1, ca2, ca3});
+        }
+        if (ss >= 0) {
+            double* sl = slots + (size_t)ss * 7 * nth + tid;
+            sl[0] = f.p.x;
+            sl[(size_t)nth] = f.p.y;
+            sl[(size_t)2 * nth] = f.p.z;
+            sl[(size_t)3 * nth] = f.q.x;
+            sl[(size_t)4 * nth] = f.q.y;
+            sl[(size_t)5 * nth] = f.q.z;
+            sl[(size_t)6 * nth] = f.q.w;
+        }
+        if (frames_out) f7_store(frames_out + k * 7, f);  // only the publishing lane passes a non-null pointer
+        for (int t = t0; t < t1; t++) {
+            if (pb->tips[t].has_e) {
+                double e[7];
+                for (int c2 = 0; c2 < 7; c2++) e[c2] = pb->tips[t].e[c2];
+                tip_fn(t, f7_concat(f, f7_load(e)));
             } else {
-                const V3 lp = v3(BK_FMA(xv[j], cb0, cp0), BK_FMA(xv[j], cb1, cp1), BK_FMA(xv[j], cb2, cp2));
-                f.p = f.p + qrot(f.q, lp);
-                f.q = qmul(f.q, Q4{ca0, ca1, ca2, ca3});
-            }
-            if (ss >= 0) {
-                double* sl = slots + (size_t)ss * 7 * nth + tid;
-                sl[0] = f.p.x;
-                sl[(size_t)nth] = f.p.y;
-                sl[(size_t)2 * nth] = f.p.z;
-                sl[(size_t)3 * nth] = f.q.x;
-                sl[(size_t)4 * nth] = f.q.y;
-                sl[(size_t)5 * nth] = f.q.z;
-                sl[(size_t)6 * nth] = f.q.w;
-            }
-            if (frames_out) f7_store(frames_out + k * 7, f);  // only the publishing lane passes a non-null pointer
-            for (int t = t0; t < t1; t++) {
-                if (pb->tips[t].has_e) {
-                    double e[7];
-                    for (int c2 = 0; c2 < 7; c2++) e[c2] = pb->tips[t].e[c2];
-                    tip_fn(t, f7_concat(f, f7_load(e)));
-                } else {
-                    tip_fn(t, f);
-                }
+                tip_fn(t, f);
             }
         }
     }
@@ -1361,13 +1367,13 @@ struct FitCheck {
     double fitness;
     int ok;
 };
-template <class PB>
+template <int COOP = 0, class PB>
 BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* slots, double dpos, double drot, double dtwist, int do_check,
                                             const double* prefix = nullptr) {
     bool good = true;
     double sum = 0.0;
     V3 bal = v3(0.0, 0.0, 0.0);
-    fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
+    fk_walk<COOP>(pb, x, slots, nullptr, [&](int t, const F7& f) {
         sum += tip_goals(pb, t, f, x, qc);
         balance_tip(pb, t, f, bal);
         if (do_check) {

@@ -17,6 +17,10 @@
 #include "bioik_device.h"
 
 
+#ifndef BIOIK_COOP_WALKS
+#define BIOIK_COOP_WALKS 1  // single-individual walks of the solver share the joints' trigonometry over the lanes (fk_walk<COOP>); 0: every lane repeats it
+#endif
+
 struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species group (stride g_stride)
     int seed, par, pop, sol, prefix, state, clip, xcol, slots, g_first, g_stride, total;
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
@@ -205,14 +209,19 @@ BIOIK_DEV void top2_xwave(double& b1f, int& b1p, double& b2f, int& b2p, double* 
 // RobotFK::applyConfiguration + initializeMutationApproximator at the (workgroup-shared) individual x:
 // the joint frames are published to LDS by lane 0 (the per-joint frame chain), then lanes fan out over (tip, op).
 // (gtid, G): index and size of the cooperating lane group (the whole workgroup, or one species group of it)
-template <class PB>
+// COOP != 0: the lanes of the group walk ONE individual x (the solver); 0: every lane its own or no full wavefront (the function-level kernels)
+template <int COOP = 0, class PB>
 BIOIK_NOINLINE void build_approximator(PB pb, XV x, double* slots, double* s_frames, double* s_tips, double* s_delta, double* s_base, int gtid, int G,
                                        const double* prefix = nullptr) {
     const int n_ops = pb->n_ops, T = pb->T;
-    if (gtid < 64)  // one wavefront walks the chain (lane 0 publishes); the others wait at the barrier
-        fk_walk(pb, x, slots, gtid == 0 ? s_frames : nullptr, [&](int t, const F7& f) {
+    if (gtid < 64) {  // one wavefront walks the chain (lane 0 publishes), its lanes sharing the joints' trigonometry; the others wait at the barrier
+        auto publish = [&](int t, const F7& f) {
             if (gtid == 0) f7_store(s_tips + t * 7, f);
-        }, prefix);
+        };
+        if (COOP == 0) fk_walk(pb, x, slots, gtid == 0 ? s_frames : nullptr, publish, prefix);
+        else if (G >= 64) fk_walk<64>(pb, x, slots, gtid == 0 ? s_frames : nullptr, publish, prefix);
+        else fk_walk<32>(pb, x, slots, gtid == 0 ? s_frames : nullptr, publish, prefix);  // half-wavefront groups: one individual per half
+    }
     for (int k = gtid; k < n_ops; k += G) s_base[k] = x(k);
     group_sync(G);
     for (int idx = gtid; idx < T * n_ops; idx += G) {
@@ -263,7 +272,8 @@ struct SpeciesState {
 // computes its LDS addresses where it uses them instead of inheriting them from in front of the step loop, where the compiler had
 // parked them in scratch memory (r02: 36 spilled VGPRs, every one of them an address of this kind).
 #define BIOIK_LANE_SCOPE                                                                                                            \
-    const int tid = p_fresh(tid0), grp = p_fresh(grp0), gtid = p_fresh(gtid0);                                                       \
+    const int tid = p_fresh(tid0); /* (the one lane number kept across the phases; group and index inside it follow from it) */     \
+    const int grp = g_shift >= 0 ? tid >> g_shift : tid / G, gtid = tid - grp * G;                                                  \
     double* const gbase = lds + L.g_first + grp * L.g_stride; /* this group's scratch */                                            \
     double* const s_xn = gbase + L.xn;                                                                                              \
     double* const s_gv = gbase + L.gv;                                                                                              \
@@ -317,7 +327,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
     const int groups = sp.species_parallel ? 2 : 1;
     const int G = nth / groups;        // lanes per species group (a multiple of 64)
-    const int grp0 = tid0 / G, gtid0 = tid0 - grp0 * G;
+    const int g_shift = (G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1;  // the group sizes the launcher produces are powers of two: no integer division
     const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, sp.child_pairs ? 2 : 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
@@ -358,7 +368,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     };
     auto group_check = [&](bool glead, int gtid, double* s_bc, const XV& x) -> FitCheck {  // exact fitness + success test of a group's vector, known to the whole group
         FitCheck fc{0.0, 0};
-        if (glead) fc = exact_fitness_check(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
+        if (glead) {  // (the group's leading wavefront, or its half of the wavefront: the lanes share the walk of x)
+            if (BIOIK_COOP_WALKS == 0) fc = exact_fitness_check(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
+            else if (G >= 64) fc = exact_fitness_check<64>(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
+            else fc = exact_fitness_check<32>(pb, x, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
+        }
         if (G > 64) {
             if (gtid == 0) s_bc[0] = fc.fitness, s_bc[2] = (double)fc.ok;
             p_barrier();
@@ -370,7 +384,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     };
     auto wg_check = [&](bool wlead, int tid, const XV& x, double dpos, double drot, double dtwist, int do_check) -> FitCheck {
         FitCheck fc{0.0, 0};
-        if (wlead) fc = exact_fitness_check(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);
+        if (wlead) fc = exact_fitness_check<BIOIK_COOP_WALKS ? 64 : 0>(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);  // (a vector of the whole workgroup)
         if (nth > 64) {
             if (tid == 0) s_wbc[0] = fc.fitness, s_wbc[1] = (double)fc.ok;
             p_barrier();
@@ -431,7 +445,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         s_solst[0] = sol_fit, s_solst[1] = (double)fc0.ok;
     }
     p_barrier();
-    const int rank_begin = groups == 2 ? grp0 : 0, rank_end = groups == 2 ? grp0 + 1 : 2;
+    // (species-parallel: a lane group runs the species of its own number; its loop below is one trip with a per-lane index)
     PHASE_MARK(PH_INIT);
 
     // ik_parallel.h:160: the caller's timeout bounds the call, not the query.  The launch's clock starts when its first workgroup
@@ -449,6 +463,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double final_fit = BIOIK_DBL_MAX;
     const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
     for (int step = a.step_begin; step < step_end; step++) {
+        const int rank_begin = groups == 2 ? (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
         for (int rank = rank_begin; rank < rank_end; rank++) {
             SpeciesState S = species_load(rank);
             double* popS = s_pop + S.slot * SP;
@@ -456,7 +471,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
                 BIOIK_LANE_SCOPE;
                 const double* cb = popS + S.cur * BF;
-                build_approximator(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);
+                build_approximator<BIOIK_COOP_WALKS>(pb, XV{cb, 1}, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);
                 S.pf0 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
                 S.pf1 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
             }
@@ -682,7 +697,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 BIOIK_LANE_SCOPE;
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
                 const XV xe{el, 1};
-                if (exact) build_approximator(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);  // fresh linearisation at the elite
+                if (exact) build_approximator<BIOIK_COOP_WALKS>(pb, xe, s_slots, s_frames, s_tips, s_delta, s_base, gtid, G, s_prefix);  // fresh linearisation at the elite
                 PHASE_MARK(PH_MEM_APPROX);
                 if (gtid < 64) {
                     const int Gw = G < 64 ? G : 64;  // lanes at work
@@ -851,7 +866,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 S.ok = fc.ok;
                 PHASE_MARK(PH_RANK);
             }
-            if (p_fresh(gtid0) == 0) species_store(rank, S);
+            {
+                BIOIK_LANE_SCOPE;
+                if (gtid == 0) species_store(rank, S);
+            }
         }
         p_barrier();  // both species are ranked and their bookkeeping is in LDS
         BIOIK_LANE_SCOPE;  // species management and the checks at the end of the step

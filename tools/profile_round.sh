@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 python bench.py > $O/bench_$rnd.json 2> $O/bench_$rnd.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$rnd -o $rnd -- python $R/bench.py --timed-only > $O/prof_bench.log 2>&1
-pmc() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$d -o $d -- python $R/bench.py --timed-only --steps 5 --warmup 1 > $O/pmc_$d.log 2>&1; }
+pmc() { d=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$d -o $d -- python $R/bench.py --timed-only --steps 5 --warmup 1 --in-flight 1 > $O/pmc_$d.log 2>&1; }
 BIOIK_BENCH_STREAM=0 pmc fetch FETCH_SIZE
 BIOIK_BENCH_STREAM=0 pmc write WRITE_SIZE
 BIOIK_BENCH_STREAM=0 pmc sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY
