@@ -112,6 +112,15 @@ __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_
     extern __shared__ double lds[];
     solve_body<true, true>(a, blockIdx.x, lds);
 }
+// The same body under the register budget of FOUR wavefronts per SIMD (128 VGPRs instead of 168).  The hot loops of the computed-children
+// flavour fit it; its once-per-step code then keeps some values in scratch memory, so a lone step is slower (110 against 102 us) and it
+// only pays where the LDS footprint lets the fourth wavefront be resident AND the generation loops dominate a step: the launcher
+// picks it when a CU holds at least 16 wavefronts of the problem and a lane walks eight or more children per generation (the
+// 31-joint, 512-children configuration: +12 %; the first launch of a 7-joint, 128-children solve: -2 %; profiles/r03_ab_four_waves.log).
+__global__ void __launch_bounds__(256, 4) k_solve_lean_cl4(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true>(a, blockIdx.x, lds);
+}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -154,6 +163,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -431,7 +441,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         a.steps = (int32_t*)w;
     }
     auto launch = [&](const SolveArgs& args, int lanes, size_t lds_b) {
-        if (lean && args.sp.columnless)
+        // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
+        // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
+        const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
+        const bool four_waves = (160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !std::getenv("BIOIK_SOLVE_THREE_WAVES");
+        if (lean && args.sp.columnless && four_waves)
+            LAUNCH(k_solve_lean_cl4, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean && args.sp.columnless)
             LAUNCH(k_solve_lean_cl, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean)
             LAUNCH(k_solve_lean, solve_body<true>(args, b_, l_), units, lanes, lds_b, stream, args);

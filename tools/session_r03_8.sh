@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 3, GPU session 8: kernels restructured so that nothing but the lane's best two is live across the chain walk: three against four wavefronts per SIMD
+O=gpurun_out/s8; mkdir -p $O
+export TMPDIR=/tmp
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/gputests.log 2>&1
+grep -E "passed|failed" $O/gputests.log
+ROUNDS=2 bash tools/step_rate.sh build/lib_k_coop.so build/lib_n_w3.so build/lib_n_w4.so > $O/step_rate.log 2>&1
+cat $O/step_rate.log
+for rep in 1 2; do for lib in build/lib_k_coop.so build/lib_n_w3.so build/lib_n_w4.so; do
+  BIOIK_HIP_LIBRARY=$lib python bench.py --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null > $O/bench_$(basename $lib .so).json
+  python -c "import sys,json; d=json.load(open('$O/bench_$(basename $lib .so).json')); print('$lib bench: %.0f solves/s %.2f ms success %.4f one-at-a-time %.0f chip_frac %.3f pipelined %.0f | configs' % (d['value'], d['ms_per_step'], d['success_rate'], d['one_batch_at_a_time']['value'], d['roofline'].get('chip_level_frac', -1), d['host_pointer_pipelined']['value']), {k:(round(v['value']),round(v['success_rate'],3), round(v['roofline']['chip_level_frac'],3)) for k,v in d.get('configs',{}).items()}, 'ref-params %.0f tracking %.0f' % (d['reference_parameters']['value'], d['tracking_seeds']['value']))"
+done; done 2>&1 | tee $O/bench_ab.log
