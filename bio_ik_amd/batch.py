@@ -62,9 +62,9 @@ def _scatter(solver, seeds, goal_params, dev, group):
         full = torch.from_numpy(np.concatenate([seeds, goal_params], axis=1))
         chunks = []
         for r in range(world):
-            c = torch.zeros((s.cap, V + P), dtype=torch.float64)
+            c = torch.zeros((s.cap, V + P), dtype=torch.float64, pin_memory=dev.type == "cuda")  # (page-locked: one DMA per shard, no staging copy)
             c[:s.b[r + 1] - s.b[r]] = full[s.b[r]:s.b[r + 1]]
-            chunks.append(c.to(dev))
+            chunks.append(c.to(dev, non_blocking=dev.type == "cuda"))
         dist.scatter(s.inbuf, scatter_list=chunks, src=0, group=group)
     else:
         dist.scatter(s.inbuf, src=0, group=group)
@@ -133,6 +133,19 @@ def _gather(s, dev, group):
     return None
 
 
+_STREAMS = {}
+
+
+def _block_stream(dev, k):
+    """the HIP stream block k of a mixed batch runs on: created once per (device, k) and kept (HIP multiplexes streams onto four hardware
+    queues per device; a fresh stream per call would also pay its creation inside every solve)"""
+    import torch
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), k)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(dev)
+    return _STREAMS[key]
+
+
 def _device(device):
     import torch
     return torch.device(device) if device is not None else torch.device("cpu")
@@ -156,7 +169,7 @@ def solve_mixed(blocks, device=None, group=None):
     shards = [_scatter(solver, seeds, gp, dev, group) for solver, _, seeds, gp in blocks]
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)  # the scattered rows are complete before the solver streams read them
-    for s, (_, params, _, _) in zip(shards, blocks):
-        _launch(s, params, dev, torch.cuda.Stream(dev) if dev.type == "cuda" else None)
+    for k, (s, (_, params, _, _)) in enumerate(zip(shards, blocks)):
+        _launch(s, params, dev, _block_stream(dev, k) if dev.type == "cuda" else None)
     out = [_gather(s, dev, group) for s in shards]
     return None if out[0] is None else out

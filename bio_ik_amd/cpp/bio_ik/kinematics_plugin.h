@@ -81,16 +81,8 @@ public:
         bio_ik::core::Settings s = params;
         s.devices = {params.gpu_device};
         engine.initialize(rm.desc(), mv, s);
-        default_goals.clear();  // :279-329
-        for (auto& tip : tip_frames) {
-            auto* g = new bio_ik::PoseGoal();
-            g->setLinkName(tip);
-            g->setRotationScale(params.position_only_ik ? 0.0 : params.rotation_scale);
-            default_goals.emplace_back(g);
-        }
-        if (params.center_joints_weight > 0) default_goals.emplace_back(new bio_ik::CenterJointsGoal(params.center_joints_weight));
-        if (params.avoid_joint_limits_weight > 0) default_goals.emplace_back(new bio_ik::AvoidJointLimitsGoal(params.avoid_joint_limits_weight));
-        if (params.minimal_displacement_weight > 0) default_goals.emplace_back(new bio_ik::MinimalDisplacementGoal(params.minimal_displacement_weight));
+        bio_ik::core::makeDefaultGoals(tip_frames, params.rotation_scale, params.position_only_ik, params.center_joints_weight, params.avoid_joint_limits_weight,
+                                       params.minimal_displacement_weight, default_goals);  // :279-329
         rm.linkTransform(rm.linkIndex(base), rm.defaultPositions(), base_default);
         return true;
     }

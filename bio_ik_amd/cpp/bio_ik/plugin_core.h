@@ -85,6 +85,22 @@ inline void concat7(const double* a, const double* b, double* r) {  // a o b for
     for (int i = 0; i < 7; i++) r[i] = o[i];
 }
 
+// The goals a plugin solves for when the caller brings none of its own (kinematics_plugin.cpp:279-329): a PoseGoal per tip frame, then
+// the optional regularisers whose weight is positive.
+inline void makeDefaultGoals(const std::vector<std::string>& tip_frames, double rotation_scale, bool position_only_ik, double center_joints_weight,
+                             double avoid_joint_limits_weight, double minimal_displacement_weight, std::vector<std::unique_ptr<Goal>>& out) {
+    out.clear();
+    for (auto& tip : tip_frames) {
+        auto* g = new PoseGoal();
+        g->setLinkName(tip);
+        g->setRotationScale(position_only_ik ? 0.0 : rotation_scale);
+        out.emplace_back(g);
+    }
+    if (center_joints_weight > 0) out.emplace_back(new CenterJointsGoal(center_joints_weight));
+    if (avoid_joint_limits_weight > 0) out.emplace_back(new AvoidJointLimitsGoal(avoid_joint_limits_weight));
+    if (minimal_displacement_weight > 0) out.emplace_back(new MinimalDisplacementGoal(minimal_displacement_weight));
+}
+
 // One batch of queries that share a goal structure, as every face hands it over.
 struct Request {
     std::vector<const Goal*> goals;         // all goals: the plugin's defaults first (unless `replace`), then the caller's (:550-556)
@@ -288,9 +304,23 @@ public:
         bool all_ok = true;
         for (size_t k = 0; k < n; k++) {
             double* st = &tk.sol[k * V];
-            const double* seed = &tk.seeds[k * V];
+            postprocess(st, &tk.seeds[k * V], tk.active);
+            for (int gv : mv_.group_vars) solutions[k].push_back(st[gv]);  // map the result to the group's variables (:619-629)
+            ok[k] = (tk.suc[k] || tk.approximate) ? 1 : 0;
+            all_ok = all_ok && ok[k];
+        }
+        if (tk.bio && n) tk.bio->solution_fitness = tk.fit[n - 1];  // :632-634
+        return all_ok;
+    }
+
+    // What the reference does to the solver's answer before it hands it out (:580-616), on ONE full variable vector `st` solved from `seed`:
+    // the angle wrap of the active revolute variables, then RobotModel::enforcePositionBounds.
+    void postprocess(double* st, const double* seed, const std::vector<int32_t>& active) const {
+        const size_t V = mv_.n_variables;
+        {
+            {
             if (!mv_.has_mimic)
-                for (int ivar : tk.active) {  // wrap angles (:580-613)
+                for (int ivar : active) {  // wrap angles (:580-613)
                     if (!mv_.var_revolute[ivar]) continue;
                     double v = st[ivar];
                     const double r = seed[ivar], lo = mv_.var_min[ivar], hi = mv_.var_max[ivar];
@@ -316,13 +346,17 @@ public:
                     }
                 }
             }
-            for (int gv : mv_.group_vars) solutions[k].push_back(st[gv]);  // map the result to the group's variables (:619-629)
-            ok[k] = (tk.suc[k] || tk.approximate) ? 1 : 0;
-            all_ok = all_ok && ok[k];
+            }
         }
-        if (tk.bio && n) tk.bio->solution_fitness = tk.fit[n - 1];  // :632-634
-        return all_ok;
     }
+    // the settings a caller may change between calls (budgets, thresholds, seed); the devices stay as initialised
+    void updateSettings(const Settings& s) {
+        solverMode(s.mode);
+        const std::vector<int> devices = settings_.devices;
+        settings_ = s;
+        settings_.devices = devices;
+    }
+    const ModelView& modelView() const { return mv_; }
 };
 
 }  // namespace core

@@ -240,27 +240,14 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         mv.enforce_bounds = [rm](double* st) { rm->enforcePositionBounds(st); };
         engine.initialize(flat->desc(), mv, p);  // (throws on an unknown solver mode or a missing HIP device: configuration errors)
 
-        default_goals.clear();  // :279-329
-        for (size_t i = 0; i < tip_frames_.size(); i++) {
-            auto* goal = new bio_ik::PoseGoal();
-            goal->setLinkName(tip_frames_[i]);
-            double rotation_scale = 0.5;
-            lookupParam("rotation_scale", rotation_scale, rotation_scale);
-            bool position_only_ik = false;
-            lookupParam("position_only_ik", position_only_ik, position_only_ik);
-            if (position_only_ik) rotation_scale = 0;
-            goal->setRotationScale(rotation_scale);
-            default_goals.emplace_back(goal);
-        }
-        double weight = 0;
-        lookupParam("center_joints_weight", weight, 0.0);
-        if (weight > 0.0) default_goals.emplace_back(new bio_ik::CenterJointsGoal(weight));
-        weight = 0;
-        lookupParam("avoid_joint_limits_weight", weight, 0.0);
-        if (weight > 0.0) default_goals.emplace_back(new bio_ik::AvoidJointLimitsGoal(weight));
-        weight = 0;
-        lookupParam("minimal_displacement_weight", weight, 0.0);
-        if (weight > 0.0) default_goals.emplace_back(new bio_ik::MinimalDisplacementGoal(weight));
+        double rotation_scale = 0.5, center = 0, avoid = 0, minimal = 0;  // :279-329
+        bool position_only_ik = false;
+        lookupParam("rotation_scale", rotation_scale, rotation_scale);
+        lookupParam("position_only_ik", position_only_ik, position_only_ik);
+        lookupParam("center_joints_weight", center, 0.0);
+        lookupParam("avoid_joint_limits_weight", avoid, 0.0);
+        lookupParam("minimal_displacement_weight", minimal, 0.0);
+        bio_ik::core::makeDefaultGoals(tip_frames_, rotation_scale, position_only_ik, center, avoid, minimal, default_goals);
         return true;
     }
 

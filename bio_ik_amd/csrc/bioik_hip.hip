@@ -484,7 +484,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         launch(a, nth, lds);
     } else {
         const size_t nh = handovers.size();
-        const size_t carry_n = 17 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;
+        const size_t carry_n = 9 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;  // (solve_body: carry_n)
         const size_t list_bytes = (units * 4 + 63) / 64 * 64;
         const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + nh * list_bytes;
         void* ws = be_alloc_async(count_off + nh * 64, stream);

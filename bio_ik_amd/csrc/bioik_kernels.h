@@ -250,7 +250,7 @@ struct SolveArgs {
     // end under the mapping with the fastest lone step.  What a unit is between two steps: the species' elites, the solution and
     // 24 numbers of bookkeeping (three LDS arrays); the RNG is a function of the step index.
     int32_t step_begin = 0, step_end = 0x7fffffff;  // this launch runs the steps [step_begin, min(step_end, sp.max_steps))
-    double* carry = nullptr;                  // [units][17 M + 24] state of the handed-over units (first launch writes, second reads)
+    double* carry = nullptr;                  // [units][9 M + 24] state of the handed-over units (first launch writes, second reads)
     int32_t* carry_list = nullptr;            // first launch: the units handed over, in the order they finish ...
     unsigned int* carry_count = nullptr;      // ... and how many (zeroed by the host)
     const int32_t* unit_list = nullptr;       // second launch: workgroup b continues unit_list[b] ...
@@ -397,7 +397,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
 
     // ik_evolution_2.cpp:129-179: solution = seed, 2 species x 2 clones of the seed, zero momentum.
     // Inactive ops carry the seed's value in every vector, so the chain walk never distinguishes them.
-    const int carry_n = 2 * SP + M + 24;  // doubles of a unit's state between two steps: s_pop, s_sol, s_state
+    // doubles of a unit's state between two steps: per species (in ranking order) the elite buffer in use -- two individuals, genes and
+    // momentum --, the solution, the bookkeeping block (the other elite buffer is written before it is read: it does not travel)
+    const int carry_n = 2 * BF + M + 24;
     if (!resume) {
         for (int k = tid; k < n_ops; k += nth) {
             double v = s_seed[pb->ops[k].var];
@@ -410,11 +412,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
     } else {
         const double* c = a.carry + unit * (uint64_t)carry_n;
-        for (int i = tid; i < carry_n; i += nth) {
-            const double v = c[i];
-            if (i < 2 * SP) s_pop[i] = v;
-            else if (i < 2 * SP + M) s_sol[i - 2 * SP] = v;
-            else s_state[i - 2 * SP - M] = v;
+        for (int i = tid; i < M + 24; i += nth) {
+            const double v = c[2 * BF + i];
+            if (i < M) s_sol[i] = v;
+            else s_state[i - M] = v;
+        }
+        for (int i = tid; i < 2 * BF; i += nth) {  // species of rank r: into buffer 0 of its slot (the record travels with cur = 0)
+            const int r = i >= BF ? 1 : 0;
+            s_pop[(int)c[2 * BF + M + r * 8 + 4] * SP + (i - r * BF)] = c[i];
         }
     }
     for (int k = tid; k < n_ops; k += nth) s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
@@ -938,9 +943,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     }
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
-    if (a.carry_list && !success && !expired && step_end < sp.max_steps) {  // neither solved nor out of time: the next launch goes on
+    const bool handed_over = a.carry_list && !success && !expired && step_end < sp.max_steps;  // neither solved nor out of time: the next launch goes on
+    if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;
-        for (int i = tid; i < carry_n; i += nth) c[i] = i < 2 * SP ? s_pop[i] : (i < 2 * SP + M ? s_sol[i - 2 * SP] : s_state[i - 2 * SP - M]);
+        for (int i = tid; i < 2 * BF; i += nth) {
+            const int r = i >= BF ? 1 : 0;
+            c[i] = s_pop[(int)s_state[r * 8 + 4] * SP + (int)s_state[r * 8 + 5] * BF + (i - r * BF)];  // (slot, cur of the species of rank r: species_store)
+        }
+        for (int i = tid; i < M + 24; i += nth) c[2 * BF + i] = i < M ? s_sol[i] : ((i - M == 5 || i - M == 13) ? 0.0 : s_state[i - M]);
         if (tid == 0) a.carry_list[p_atomic_inc(a.carry_count)] = (int32_t)unit;
     }
 
@@ -948,12 +958,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double rank_fit = final_fit;
     if (success && has_sec) rank_fit = final_fit + secondary_fitness(pb, XV{s_sol, 1}, qc);
     double* out = a.solutions + unit * (uint64_t)V;
-    for (int i = tid; i < V; i += nth) out[i] = s_seed[i];
+    if (!handed_over)  // (a handed-over unit's results are written by the launch that finishes it)
+        for (int i = tid; i < V; i += nth) out[i] = s_seed[i];
     p_barrier();
-    if (steps > 0)
+    if (steps > 0 && !handed_over)
         for (int k = tid; k < n_ops; k += nth)
             if (pb->ops[k].gene >= 0) out[pb->ops[k].var] = s_sol[k];
-    if (tid == 0) {
+    if (tid == 0 && !handed_over) {
         a.fitness[unit] = rank_fit;
         a.success[unit] = success ? 1 : 0;
         a.steps[unit] = steps;

@@ -182,3 +182,13 @@ def hostsim_lib():
     d = os.path.join(ROOT, "tests", "hostsim")
     subprocess.run(["make", "-C", d, "-s"], check=True)
     return solver.load_library(os.path.join(d, "libbioik_hostsim.so"))
+
+
+@pytest.fixture(scope="session")
+def hostsim_shim(hostsim_lib):
+    """TEST INFRASTRUCTURE: the Python package's plugin shim (bio_ik_amd/cpp/src/plugin_shim.cpp) linked against the host simulator"""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "hostsim")
+    out = os.path.join(d, "libbio_ik_shim_hostsim.so")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "bio_ik_amd", "cpp"), "-s", "shim", "SOLVER_DIR=" + d, "SOLVER=bioik_hostsim", "SHIM_OUT=" + out], check=True)
+    return out

@@ -446,6 +446,19 @@ def test_selection_ties_are_decided_by_position(monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
+    """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
+    residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""
+    h, o, t = gpus["c4"], oracles["c4"], templates["c4"]
+    pc.trajectory(h, o, t, n=3, pop=512, steps_list=(2,))
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 256, seed=31)
+    p = abi.default_solve_params(population=512, max_steps=6, random_seed=4)
+    a = h.solve_batch(p, seeds, params)
+    monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+    b = h.solve_batch(p, seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_sharded_batch_equals_whole_batch(gpus, templates):
     """the multi-GPU split: shards solved separately with their query offsets reproduce the unsharded batch"""
     h, t = gpus["c2"], templates["c2"]

@@ -1,20 +1,19 @@
-"""The plugin mirror (bio_ik_amd/plugin.py) against the reference's searchPositionIK contract
+"""The Python face of the plugin (bio_ik_amd/plugin.py over bio_ik/plugin_core.h) against the reference's searchPositionIK contract
 (src/kinematics_plugin.cpp:437-655), driven on CPU through the host simulator of the kernels."""
 import numpy as np
 import pytest
 
 from bio_ik_amd import (BioIKKinematicsPlugin, BioIKKinematicsQueryOptions, KinematicsQueryOptions, MoveItErrorCodes, PositionGoal, abi)
 from bio_ik_amd.robot import frame_concat, link_transform
-from bio_ik_amd.solver import HipSolver
 from conftest import random_configuration
 from oracle import orc
 
 
 @pytest.fixture(scope="module")
-def plugin(hostsim_lib, pr2):
-    p = BioIKKinematicsPlugin(solver_factory=lambda template, device: HipSolver(template, device=device, lib=hostsim_lib))
+def plugin(hostsim_shim, pr2):
+    p = BioIKKinematicsPlugin(lib=hostsim_shim)
     assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0,
-                        params={"gpu_population": 16, "gpu_fk": "linear", "gpu_max_steps": 40, "random_seed": 3})
+                        params={"gpu_population": 16, "gpu_fk": "linear", "gpu_max_steps": 40, "random_seed": 3, "gpu_reproducible_calls": True})
     return p
 
 
@@ -33,7 +32,7 @@ def test_interface_shape(plugin):
     assert plugin.getPositionFK([], [], []) is False and plugin.getPositionIK(None, [], [], MoveItErrorCodes()) is False
     assert plugin.supportsGroup(None)
     with pytest.raises(RuntimeError):
-        BioIKKinematicsPlugin().initialize(plugin.robot_model, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"mode": "nonsense"})
+        BioIKKinematicsPlugin(lib=plugin._lib_path).initialize(plugin.robot_model, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"mode": "nonsense"})
 
 
 def test_search_position_ik_round_trip(plugin, pr2):
@@ -97,7 +96,7 @@ def test_unreachable_goal_error_codes(plugin, pr2):
 
 
 def test_angle_wrapping_matches_oracle(plugin, oracles, pr2):
-    """kinematics_plugin.cpp:580-616 restated twice (oracle C++, plugin NumPy) must agree"""
+    """kinematics_plugin.cpp:580-616: the plugin core's post-processing (bio_ik/plugin_core.h, through the shim) against the oracle's restatement"""
     o = oracles["c2"]
     rng = np.random.default_rng(9)
     seed = random_configuration(pr2, rng, 64)
@@ -106,3 +105,43 @@ def test_angle_wrapping_matches_oracle(plugin, oracles, pr2):
     got = plugin._wrap_angles(state, seed, o.active_variables)
     act = o.active_variables
     assert np.abs(got[:, act] - want[:, act]).max() < 1e-12
+
+
+def test_product_shim_exports():
+    """libbio_ik_shim.so (linked against libbioik_hip.so) loads without a GPU and exports what plugin.py binds"""
+    import subprocess, os
+    from bio_ik_amd import plugin as pl
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(pl.SHIM_PATH)), "-s", "shim"], check=True)
+    L = pl.load_shim()
+    for name in ("bioik_plugin_create", "bioik_plugin_destroy", "bioik_plugin_update", "bioik_plugin_submit", "bioik_plugin_wait", "bioik_plugin_postprocess",
+                 "bioik_plugin_group_variables", "bioik_plugin_group_variable_count", "bioik_plugin_last_error"):
+        assert hasattr(L, name)
+
+
+@pytest.mark.gpu
+def test_python_plugin_on_the_device(pr2):
+    """the Python face over the product libraries: a batch through searchPositionIKBatch, two batches in flight through the submit / wait
+    form, every reported success reproducing its pose; the async form returns what the synchronous one does"""
+    p = BioIKKinematicsPlugin()
+    assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0, params={"gpu_max_steps": 100, "random_seed": 5, "gpu_reproducible_calls": True})
+    rng = np.random.default_rng(21)
+    gv = p._group_vars
+    n = 256
+    targets = np.tile(pr2.default_positions(), (n, 1))
+    targets[:, gv] = random_configuration(pr2, rng, n)[:, gv]
+    poses = np.stack([goal_in_base_frame(pr2, t) for t in targets]).reshape(n, 1, 7)
+    seeds = random_configuration(pr2, rng, n)[:, gv]
+    sols, ok, fit, codes = p.searchPositionIKBatch(poses, seeds)
+    assert ok.mean() > 0.9 and np.all(codes[ok] == MoveItErrorCodes.SUCCESS) and np.all(codes[~ok] == MoveItErrorCodes.NO_IK_SOLUTION)
+    base = link_transform(pr2, pr2.link_index("torso_lift_link"), pr2.default_positions())
+    for k in np.nonzero(ok)[0][:64]:
+        state = pr2.default_positions()
+        state[gv] = sols[k]
+        got = link_transform(pr2, pr2.link_index("r_wrist_roll_link"), state)
+        want = frame_concat(base, poses[k, 0])
+        assert np.linalg.norm(got[:3] - want[:3]) < 1e-4 and 2 * np.arccos(min(1.0, abs(got[3:] @ want[3:]))) < 1e-3
+    a = p.searchPositionIKBatchAsync(poses[:128], seeds[:128])
+    b = p.searchPositionIKBatchAsync(poses[:128], seeds[:128])
+    ra, rb = p.searchPositionIKBatchWait(a), p.searchPositionIKBatchWait(b)
+    assert np.array_equal(ra[0], sols[:128]) and np.array_equal(rb[0], sols[:128]) and np.array_equal(ra[1], ok[:128])
+    p.close()
