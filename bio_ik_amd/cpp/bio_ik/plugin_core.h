@@ -57,17 +57,27 @@ struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path rea
     std::vector<int> devices = {0};  // a batch is sharded over them (contiguous shards, no exchange)
 };
 
-// IKFactory names with a device implementation (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292).  Not available: bio1,
-// gd_r (random restarts) and the `_2 / _4 / _8` forms of gd / gd_c / jac (further solver threads started at random configurations,
-// ik_parallel.h:141-145), the cppoptlib and FANN families -- an unknown name is a configuration error, as in IKFactory::create.
-inline int solverMode(const std::string& name) {
-    if (name == "bio2") return BIOIK_MODE_BIO2;
-    if (name == "bio2_memetic") return BIOIK_MODE_BIO2_MEMETIC;
-    if (name == "bio2_memetic_l") return BIOIK_MODE_BIO2_MEMETIC_L;
-    if (name == "gd_c") return BIOIK_MODE_GD_C;
-    if (name == "gd") return BIOIK_MODE_GD;
-    if (name == "jac") return BIOIK_MODE_JAC;
-    throw std::runtime_error("bio_ik (MI355X): solver mode '" + name + "' has no device implementation (available: bio2, bio2_memetic, bio2_memetic_l, gd, gd_c, jac)");
+// IKFactory names with a device implementation (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292): the bio2 family, and gd /
+// gd_r / gd_c / jac with their `_2 / _4 / _8` forms -- N solver threads of which the threads 1 ... N - 1 start at random configurations
+// (ik_parallel.h:141-145, ik_gradient.cpp:157-159) are N islands of a query on the device.  Not available: bio1, the cppoptlib and FANN
+// families -- an unknown name is a configuration error, as in IKFactory::create.
+struct SolverMode {
+    int mode;     // BIOIK_MODE_*
+    int threads;  // IKSolver::concurrency() of the name where the device models it as islands (the gradient / Jacobian solvers), else 0
+};
+inline SolverMode solverMode(const std::string& name) {
+    if (name == "bio2") return {BIOIK_MODE_BIO2, 0};
+    if (name == "bio2_memetic") return {BIOIK_MODE_BIO2_MEMETIC, 0};
+    if (name == "bio2_memetic_l") return {BIOIK_MODE_BIO2_MEMETIC_L, 0};
+    static const struct { const char* stem; int mode; } stems[] = {{"gd_r", BIOIK_MODE_GD_R}, {"gd_c", BIOIK_MODE_GD_C}, {"gd", BIOIK_MODE_GD}, {"jac", BIOIK_MODE_JAC}};
+    for (auto& st : stems) {
+        const std::string stem = st.stem;
+        if (name == stem) return {st.mode, 1};
+        for (int n : {2, 4, 8})
+            if (name == stem + "_" + std::to_string(n)) return {st.mode, n};
+    }
+    throw std::runtime_error("bio_ik (MI355X): solver mode '" + name + "' has no device implementation (available: bio2, bio2_memetic, bio2_memetic_l, "
+                             "gd, gd_r, gd_c, jac and their _2 / _4 / _8 forms)");
 }
 
 inline void concat7(const double* a, const double* b, double* r) {  // a o b for frames px py pz qx qy qz qw (include/bio_ik/frame.h:174-187)
@@ -262,9 +272,10 @@ public:
         }
         bioik_solve_params sp;
         bioik_default_solve_params(&sp);
-        sp.mode = solverMode(settings_.mode);
+        const SolverMode sm = solverMode(settings_.mode);
+        sp.mode = sm.mode;
         sp.fk_mode = settings_.gpu_fk == "linear" ? BIOIK_FK_LINEAR : BIOIK_FK_EXACT;
-        sp.population = settings_.gpu_population, sp.islands = settings_.gpu_islands, sp.max_steps = settings_.gpu_max_steps;
+        sp.population = settings_.gpu_population, sp.islands = sm.threads > 1 ? sm.threads : settings_.gpu_islands, sp.max_steps = settings_.gpu_max_steps;
         sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
         sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;
         sp.no_wipeout = settings_.no_wipeout ? 1 : 0;

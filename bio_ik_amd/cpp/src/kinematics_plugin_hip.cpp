@@ -32,6 +32,7 @@
 #include <bio_ik/bio_ik.h>
 #include <bio_ik/kinematics_plugin_hip.h>
 #include <bio_ik/plugin_core.h>
+#include <moveit/rdf_loader/rdf_loader.h>
 
 namespace bio_ik_kinematics_plugin {
 
@@ -157,15 +158,29 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         return false;  // :147-155
     }
 
+    // :167-189: the model behind a robot description on the parameter server (URDF + SRDF through rdf_loader), built once per name
+    static moveit::core::RobotModelConstPtr modelOfDescription(const std::string& robot_description) {
+        static std::mutex mutex;
+        static std::map<std::string, moveit::core::RobotModelConstPtr> models;
+        std::lock_guard<std::mutex> lock(mutex);
+        auto it = models.find(robot_description);
+        if (it != models.end()) return it->second;
+        rdf_loader::RDFLoader loader(robot_description);
+        if (!loader.getURDF() || !loader.getSRDF()) return nullptr;  // "URDF and SRDF must be loaded for kinematics solver to work." (:178-181)
+        moveit::core::RobotModelConstPtr model(new moveit::core::RobotModel(loader.getURDF(), loader.getSRDF()));
+        models[robot_description] = model;
+        return model;
+    }
+
     // :191-335
-    bool load(const moveit::core::RobotModelConstPtr& model_ptr, const std::string& /*robot_description*/, const std::string& group_name) {
-        if (!model_ptr) {
-            // the reference parses URDF + SRDF from the parameter server here (rdf_loader, :167-189); the MoveIt versions this plugin
-            // targets hand over the RobotModel (initialize(const RobotModel&, ...)), and that is the overload this build supports
-            throw std::runtime_error("bio_ik (MI355X): initialize needs the moveit::core::RobotModel overload");
-        }
+    bool load(const moveit::core::RobotModelConstPtr& model_arg, const std::string& robot_description, const std::string& group_name) {
         engine.release();  // (a re-initialisation starts from nothing, also when it fails below)
         default_goals.clear();
+        const moveit::core::RobotModelConstPtr model_ptr = model_arg ? model_arg : modelOfDescription(robot_description);  // :205-208
+        if (!model_ptr) {
+            robot_model.reset();
+            return false;  // "failed to load robot model" (:209-212)
+        }
         robot_model = model_ptr;
         joint_model_group = robot_model->getJointModelGroup(group_name);
         if (!joint_model_group) {  // "failed to get joint model group" (:215-218)

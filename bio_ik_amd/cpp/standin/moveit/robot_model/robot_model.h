@@ -25,6 +25,7 @@ struct Link {
     std::shared_ptr<Inertial> inertial;
 };
 struct ModelInterface {
+    std::string xml_;  // stand-in only: the robot description a RobotModel(urdf, srdf) is built from (moveit/rdf_loader/rdf_loader.h)
     std::map<std::string, std::shared_ptr<Link>> links_;
     std::shared_ptr<const Link> getLink(const std::string& name) const {
         auto it = links_.find(name);
@@ -33,6 +34,12 @@ struct ModelInterface {
 };
 typedef std::shared_ptr<ModelInterface> ModelInterfaceSharedPtr;
 }  // namespace urdf
+namespace srdf {
+struct Model {
+    std::string xml_;  // stand-in only: the semantic description (groups, end effectors)
+};
+typedef std::shared_ptr<Model> ModelSharedPtr;
+}  // namespace srdf
 namespace kinematics {
 class KinematicsBase;
 }
@@ -125,6 +132,9 @@ class RobotModel {
     urdf::ModelInterfaceSharedPtr urdf_ = std::make_shared<urdf::ModelInterface>();
 
 public:
+    RobotModel() {}
+    // from URDF + SRDF, as MoveIt builds it (the stand-in parses with bio_ik/urdf.h; defined in moveit/rdf_loader/rdf_loader.h)
+    RobotModel(const urdf::ModelInterfaceSharedPtr& urdf_model, const srdf::ModelSharedPtr& srdf_model);
     const urdf::ModelInterfaceSharedPtr& getURDF() const { return urdf_; }
     void setInertial(const std::string& link, double mass, double cx, double cy, double cz) {  // stand-in only (a real model parses <inertial>)
         auto l = std::make_shared<urdf::Link>();
@@ -197,6 +207,14 @@ public:
     // type: "fixed" | "revolute" | "continuous" | "prismatic" (URDF semantics); rpy as in URDF <origin>
     void addLink(const std::string& link, const std::string& parent, const std::string& joint, const std::string& type, double x, double y, double z,
                  double roll, double pitch, double yaw, double ax, double ay, double az, double lower = 0, double upper = 0, double velocity = 0) {
+        const double cr = std::cos(roll / 2), sr = std::sin(roll / 2), cp = std::cos(pitch / 2), sp = std::sin(pitch / 2), cy = std::cos(yaw / 2), sy = std::sin(yaw / 2);
+        Eigen::Isometry3d origin;
+        origin.linear() = Eigen::Quaterniond(cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy).toRotationMatrix();
+        origin.translation() = Eigen::Vector3d(x, y, z);
+        addLink(link, parent, joint, type, origin, ax, ay, az, lower, upper, velocity);
+    }
+    void addLink(const std::string& link, const std::string& parent, const std::string& joint, const std::string& type, const Eigen::Isometry3d& origin,
+                 double ax, double ay, double az, double lower = 0, double upper = 0, double velocity = 0) {
         JointModel* j;
         if (type == "fixed") j = new FixedJointModel(), j->type_ = JointModel::FIXED;
         else if (type == "prismatic") j = new PrismaticJointModel(), j->type_ = JointModel::PRISMATIC;
@@ -209,10 +227,7 @@ public:
         l->name_ = link, l->link_index_ = (int)links_.size(), l->parent_joint_ = j;
         l->parent_link_ = parent.empty() ? nullptr : getLinkModel(parent);
         if (!parent.empty() && !l->parent_link_) throw std::runtime_error("stand-in RobotModel: unknown parent link " + parent);
-        const double cr = std::cos(roll / 2), sr = std::sin(roll / 2), cp = std::cos(pitch / 2), sp = std::sin(pitch / 2), cy = std::cos(yaw / 2), sy = std::sin(yaw / 2);
-        l->joint_origin_transform_.linear() =
-            Eigen::Quaterniond(cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy).toRotationMatrix();
-        l->joint_origin_transform_.translation() = Eigen::Vector3d(x, y, z);
+        l->joint_origin_transform_ = origin;
         j->child_link_ = l;
         if (j->type_ != JointModel::FIXED) {
             j->first_variable_index_ = (int)variable_names_.size();

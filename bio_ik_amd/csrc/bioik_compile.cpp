@@ -555,15 +555,14 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.random_seed = p.random_seed;
     o.first_query = first_query;
     if (p.mode != BIOIK_MODE_BIO2 && p.mode != BIOIK_MODE_BIO2_MEMETIC && p.mode != BIOIK_MODE_BIO2_MEMETIC_L && p.mode != BIOIK_MODE_GD_C &&
-        p.mode != BIOIK_MODE_JAC && p.mode != BIOIK_MODE_GD)
+        p.mode != BIOIK_MODE_JAC && p.mode != BIOIK_MODE_GD && p.mode != BIOIK_MODE_GD_R)
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown solver mode");
     o.memetic = p.mode == BIOIK_MODE_BIO2 ? 0 : (p.mode == BIOIK_MODE_BIO2_MEMETIC_L ? 'l' : 'q');
-    o.solver = p.mode == BIOIK_MODE_GD_C ? 1 : (p.mode == BIOIK_MODE_JAC ? 2 : (p.mode == BIOIK_MODE_GD ? 3 : 0));
+    o.solver = p.mode == BIOIK_MODE_GD_C ? 1 : (p.mode == BIOIK_MODE_JAC ? 2 : (p.mode == BIOIK_MODE_GD ? 3 : (p.mode == BIOIK_MODE_GD_R ? 4 : 0)));
     if (p.fk_mode != BIOIK_FK_LINEAR && p.fk_mode != BIOIK_FK_EXACT) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown fk_mode");
     o.fk_mode = p.fk_mode;
     o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
     o.islands = p.islands > 0 ? p.islands : 1;
-    if (o.solver != 0) o.islands = 1;  // gd / gd_c / jac run one island started at the seed (the reference's further threads start at random points)
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
     if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
         const double ticks = p.timeout * 1e8;

@@ -145,7 +145,7 @@ BIOIK_DEV void revolute_apply(F7 (&f)[N], const double (&sn)[N], const double (&
 // Counter-based RNG: Philox2x32-10 (Salmon et al., SC'11; Random123 constants) with integer-only
 // post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
-enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4 };
+enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4, RNG_POINT_RANDOM = 5 };
 // Random words of child c in one generation -- the bulk of all draws, 1 + D words per child -- come from a two-multiply
 // avalanche hash of the counter instead of Philox (a Philox2x32-10 call is twenty 32-bit multiplies, and an integer multiply
 // costs 2.4 issue slots of an FP64 FMA on gfx950: profiles/r01_gfx950_latency_microbench.log):

@@ -103,7 +103,9 @@ BIOIK_DEV void pinv_solve_lds(const double* J, int rows, int cols, const double*
     }
 }
 
-// one (query) per workgroup of ONE wavefront; the island loop in budget / wall-clock form as in solve_body
+// one (query, island) per workgroup of ONE wavefront; the island loop in budget / wall-clock form as in solve_body.  Island 0 is solver
+// thread 0 of the reference (started at the seed), the islands i > 0 its threads started at random configurations (the _2 / _4 / _8
+// factory names, ik_gradient.cpp:157-159, :283-285); solver 4 (gd_r) draws a new configuration after a step that did not improve.
 BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const ProbPtr pb = a.pb;
     const DevSolveParams& sp = a.sp;
@@ -117,13 +119,23 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
     const int M = n_ops > 0 ? n_ops : 1;
     double* xcol = lds + L.xcol + tid;
     const XV xl{xcol, nth};
-    const uint64_t q = unit;
+    const uint64_t q = unit / (uint64_t)sp.islands;
+    const uint32_t island = (uint32_t)(unit % (uint64_t)sp.islands);
+    const uint32_t key = rng_query_key(sp.random_seed, sp.first_query + q, island);
+    // random(modelInfo.getMin(vi), modelInfo.getMax(vi)) for the gene of op k, draw `count` of this island
+    auto random_gene = [&](int k, uint32_t count) {
+        BIOIK_FP_STRICT
+        uint32_t o0, o1;
+        philox2x32_10(key, rng_ctr0(0, (uint32_t)pb->ops[k].gene), rng_ctr1(count, 0u, RNG_POINT_RANDOM), o0, o1);
+        return rng_uniform(o0, o1) * (pb->ops[k].vmax - pb->ops[k].vmin) + pb->ops[k].vmin;
+    };
     for (int i = tid; i < V; i += nth) s_seed[i] = a.seeds[q * V + i];
     for (int i = tid; i < P; i += nth) s_par[i] = a.params[q * P + i];
     p_wave_sync();
     const QueryCtx qc{s_seed, s_par};
-    for (int k = tid; k < n_ops; k += nth) {  // solution = problem.initial_guess (ik_gradient.cpp:150, :281), thread_index 0
-        const double v = s_seed[pb->ops[k].var];
+    for (int k = tid; k < n_ops; k += nth) {  // solution = problem.initial_guess (ik_gradient.cpp:150, :281); threads > 0: a random one (:157-159, :283-285)
+        double v = s_seed[pb->ops[k].var];
+        if (island > 0u && ((active_mask >> k) & 1ull)) v = random_gene(k, 0u);
         s_sol[k] = v, s_best[k] = v, s_grad[k] = 0.0;
     }
     p_wave_sync();
@@ -150,12 +162,18 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
         return v;
     };
     int steps = 0;
-    bool success = false;
+    bool success = false, reset = false;
     double final_fit = BIOIK_DBL_MAX;
     for (int step = 0; step < sp.max_steps; step++) {
         if (sp.solver != 2) {
-            // ---- IKGradientDescent<'c'>::step (solver 1) / IKGradientDescent<' '>::step (solver 3), ik_gradient.cpp:162-247
+            // ---- IKGradientDescent<'c'>::step (solver 1) / <' '> (solver 3) / <'r'> (solver 4), ik_gradient.cpp:162-247
             BIOIK_FP_STRICT
+            if (reset) {  // random reset if stuck (:165-170)
+                reset = false;
+                for (int k = tid; k < n_ops; k += nth)
+                    if ((active_mask >> k) & 1ull) s_sol[k] = random_gene(k, (uint32_t)step + 1u);
+                p_wave_sync();
+            }
             const double jd = 0.0001;
             double g = 0.0;
             if (my_op >= 0) {
@@ -194,7 +212,7 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
             if (!__builtin_isfinite(joint_diff)) joint_diff = 0.0;
             p_wave_sync();
             bool accept = true;  // 'c': always accept and continue (:220-223)
-            if (sp.solver == 3) {  // ' ': has the solution improved? (:225-232) even lanes score the candidate, odd lanes the configuration
+            if (sp.solver >= 3) {  // ' ' / 'r': has the solution improved? (:225-232) even lanes score the candidate, odd lanes the configuration
                 const bool odd = tid & 1;
                 for (int k = 0; k < n_ops; k++)
                     xcol[(size_t)k * nth] = (!odd && ((active_mask >> k) & 1ull)) ? clip_op(s_sol[k] - s_grad[k] * joint_diff, k) : s_sol[k];
@@ -203,6 +221,7 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
                 p_wave_sync();
                 accept = s_ex[0] < s_ex[1];
                 p_wave_sync();
+                if (!accept && sp.solver == 4) reset = true;  // 'r': reset if stuck (:233-237)
             }
             if (accept)
                 for (int k = tid; k < n_ops; k += nth)

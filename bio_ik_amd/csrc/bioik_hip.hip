@@ -293,18 +293,47 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
-    if (sp.solver != 0) {  // gd_c / jac: one wavefront per query, its own (small) LDS layout
+    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered; released on every path out
+    struct AsyncFree {
+        void*& p;
+        stream_t s;
+        ~AsyncFree() { be_free_async(p, s); }
+    } island_ws_guard{island_ws, stream};
+    // where the launch writes its results: the caller's arrays, or (islands > 1) per-island arrays that select_islands then reduces
+    auto result_arrays = [&](SolveArgs& args) {
+        if (sp.islands == 1) {
+            args.solutions = d_solutions, args.fitness = d_fitness, args.success = d_success, args.steps = d_steps;
+            return;
+        }
+        const size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
+        island_ws = be_alloc_async(units * per + 64, stream);
+        char* w = (char*)island_ws;
+        args.solutions = (double*)w, w += units * dp.V * 8;
+        args.fitness = (double*)w, w += units * 8;
+        args.success = (int32_t*)w, w += units * 4;
+        args.steps = (int32_t*)w;
+    };
+    auto select_islands = [&](const SolveArgs& args) {  // ik_parallel.h:220-269: the best island of every query
+        if (sp.islands == 1) return;
+        SelectArgs s;
+        s.islands = sp.islands, s.V = dp.V, s.n = n;
+        s.isl_solutions = args.solutions, s.isl_fitness = args.fitness, s.isl_success = args.success, s.isl_steps = args.steps;
+        s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
+        LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
+    };
+    if (sp.solver != 0) {  // gd / gd_r / gd_c / jac: one wavefront per (query, island), its own (small) LDS layout
         const size_t lds_point = (size_t)make_point_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, dp.D, 64).total * 8;
-        if (lds_point > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem too large for the gd_c / jac kernels (more than 64 KiB of LDS per query)");
+        if (lds_point > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem too large for the gd / jac kernels (more than 64 KiB of LDS per query)");
         SolveArgs pa;
         pa.pb = p->pb(), pa.sp = sp, pa.seeds = d_seeds, pa.params = d_params;
-        pa.solutions = d_solutions, pa.fitness = d_fitness, pa.success = d_success, pa.steps = d_steps;
+        result_arrays(pa);
         pa.phase_cycles = nullptr, pa.launch_clock = nullptr;
         if (sp.timeout_ticks != 0) {
             pa.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
             be_zero_async(pa.launch_clock, sizeof(unsigned long long), stream);
         }
-        LAUNCH(k_solve_point, point_body(pa, b_, l_), n, 64, lds_point, stream, pa);
+        LAUNCH(k_solve_point, point_body(pa, b_, l_), units, 64, lds_point, stream, pa);
+        select_islands(pa);
         return;
     }
     // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
@@ -406,12 +435,6 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
     if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
         if (std::atoi(e) != 0) lean = false;
-    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered; released on every path out
-    struct AsyncFree {
-        void*& p;
-        stream_t s;
-        ~AsyncFree() { be_free_async(p, s); }
-    } island_ws_guard{island_ws, stream};
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;
@@ -428,18 +451,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
     if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
 #endif
-    if (sp.islands == 1) {
-        a.solutions = d_solutions, a.fitness = d_fitness, a.success = d_success, a.steps = d_steps;
-    } else {
-        size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
-        size_t need = units * per + 64;
-        island_ws = be_alloc_async(need, stream);
-        char* w = (char*)island_ws;
-        a.solutions = (double*)w, w += units * dp.V * 8;
-        a.fitness = (double*)w, w += units * 8;
-        a.success = (int32_t*)w, w += units * 4;
-        a.steps = (int32_t*)w;
-    }
+    result_arrays(a);
     auto launch = [&](const SolveArgs& args, int lanes, size_t lds_b) {
         // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
@@ -525,13 +537,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         }
     }
 #endif
-    if (sp.islands > 1) {
-        SelectArgs s;
-        s.islands = sp.islands, s.V = dp.V, s.n = n;
-        s.isl_solutions = a.solutions, s.isl_fitness = a.fitness, s.isl_success = a.success, s.isl_steps = a.steps;
-        s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
-        LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
-    }
+    select_islands(a);
 }
 
 // ------------------------------------------------------------------------------------------------------------

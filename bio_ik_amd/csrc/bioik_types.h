@@ -117,7 +117,7 @@ struct DevSolveParams {
     uint64_t first_query;       // global index of query 0 of this launch (multi-GPU shards keep their RNG streams)
     uint64_t timeout_ticks;     // wall-clock budget of the launch in ticks of the 100 MHz device clock, 0 = none (ik_parallel.h:160)
     int32_t memetic;            // 0, 'q', 'l'
-    int32_t solver;             // 0: the bio2 family (k_solve), 1: gd_c, 2: jac, 3: gd (k_solve_point, src/ik_gradient.cpp)
+    int32_t solver;             // 0: the bio2 family (k_solve), 1: gd_c, 2: jac, 3: gd, 4: gd_r (k_solve_point, src/ik_gradient.cpp)
     int32_t columnless;         // 1: children are computed where they are read (ChildX) instead of living in genotype columns in LDS
     int32_t fk_mode;            // BIOIK_FK_*
     int32_t lambda;             // children per species per generation

@@ -91,12 +91,16 @@ enum {
     BIOIK_MODE_BIO2 = 0,            /* "bio2":           16 generations per step, no memetic phase      */
     BIOIK_MODE_BIO2_MEMETIC = 1,    /* "bio2_memetic":   8 generations + quadratic ('q') line search    */
     BIOIK_MODE_BIO2_MEMETIC_L = 2,  /* "bio2_memetic_l": 8 generations + linear ('l') line search       */
-    /* IKFactory names of reference src/ik_gradient.cpp:254-292 (one island, started at the seed; population / fk_mode are not used) */
+    /* IKFactory names of reference src/ik_gradient.cpp:254-292 (population / fk_mode are not used).  Island 0 of a query starts at the seed;
+       with islands = N > 1 the islands 1 ... N - 1 start at random configurations, as the solver threads 1 ... N - 1 of the reference's
+       "gd_2" ... "gd_8", "gd_r_2" ..., "gd_c_2" ..., "jac_2" ... "jac_8" do (:157-159, :283-285), and the best island is returned        */
     BIOIK_MODE_GD_C = 3,            /* "gd_c": gradient descent by central differences of the exact fitness, linear step estimate,
                                        always continue (ik_gradient.cpp:136-251, if_stuck = 'c')                                   */
     BIOIK_MODE_GD = 5,              /* "gd":   as gd_c, but a step is kept only if it lowers the fitness (src/ik_gradient.cpp:225-232) */
-    BIOIK_MODE_JAC = 4              /* "jac":  pseudo-inverse-Jacobian steps on the twists between the tips and their pose goals
+    BIOIK_MODE_JAC = 4,             /* "jac":  pseudo-inverse-Jacobian steps on the twists between the tips and their pose goals
                                        (ik_gradient.cpp:42-133, 269-292)                                                          */
+    BIOIK_MODE_GD_R = 6             /* "gd_r": as gd, but a configuration that a step failed to improve is replaced by a random one
+                                       before the next step (:165-170, :233-237); the best configuration seen is returned          */
 };
 
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */

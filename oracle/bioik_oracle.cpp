@@ -402,8 +402,9 @@ struct OrcSolver {
     int rng_mode;
     std::unique_ptr<Evolution2<ReferenceRandom>> ref;
     std::unique_ptr<Evolution2<CounterRandom>> ctr;
-    std::unique_ptr<GradientDescent> gd;   // BIOIK_MODE_GD_C, BIOIK_MODE_GD
-    std::unique_ptr<JacobianSolver> jac;   // BIOIK_MODE_JAC
+    std::unique_ptr<GradientDescent<ReferenceRandom>> gd_ref;  // BIOIK_MODE_GD_C, BIOIK_MODE_GD, BIOIK_MODE_GD_R
+    std::unique_ptr<GradientDescent<CounterRandom>> gd_ctr;
+    std::unique_ptr<JacobianSolver<CounterRandom>> jac;        // BIOIK_MODE_JAC (thread 0 draws no random number)
     std::vector<double> seed, params;
 };
 
@@ -417,11 +418,18 @@ void* orc_solver_create(void* problem, const bioik_solve_params* params, int rng
         s->params.assign(goal_params, goal_params + p.param_count);
         s->params.push_back(0.0);
         Query q{s->seed.data(), s->params.data()};
-        if (params->mode == BIOIK_MODE_GD_C || params->mode == BIOIK_MODE_GD) {
-            s->gd.reset(new GradientDescent(&p, *params, params->mode == BIOIK_MODE_GD ? ' ' : 'c'));
-            s->gd->initialize(q);
+        if (params->mode == BIOIK_MODE_GD_C || params->mode == BIOIK_MODE_GD || params->mode == BIOIK_MODE_GD_R) {
+            if (rng_mode == ORC_RNG_REFERENCE) {
+                s->gd_ref.reset(new GradientDescent<ReferenceRandom>(&p, *params, gradient_if_stuck(params->mode), ReferenceRandom(rng_key)));
+                s->gd_ref->initialize(q);
+            } else {
+                CounterRandom r;
+                r.key = rng_key;
+                s->gd_ctr.reset(new GradientDescent<CounterRandom>(&p, *params, gradient_if_stuck(params->mode), r));
+                s->gd_ctr->initialize(q);
+            }
         } else if (params->mode == BIOIK_MODE_JAC) {
-            s->jac.reset(new JacobianSolver(&p, *params));
+            s->jac.reset(new JacobianSolver<CounterRandom>(&p, *params));
             s->jac->initialize(q);
         } else if (rng_mode == ORC_RNG_REFERENCE) {
             s->ref.reset(new Evolution2<ReferenceRandom>(&p, ReferenceRandom(rng_key), *params));
@@ -444,7 +452,8 @@ int orc_solver_step(void* solver) {
         auto* s = (OrcSolver*)solver;
         if (s->ref) s->ref->step();
         if (s->ctr) s->ctr->step();
-        if (s->gd) s->gd->step();
+        if (s->gd_ref) s->gd_ref->step();
+        if (s->gd_ctr) s->gd_ctr->step();
         if (s->jac) s->jac->step();
         return 0;
     } catch (const std::exception& e) {
@@ -455,8 +464,8 @@ int orc_solver_state(void* solver, double* species_genes, double* species_fitnes
     auto* s = (OrcSolver*)solver;
     if (s->ref) dump_state(*s->ref, species_genes, species_fitness, solution, solution_fitness);
     if (s->ctr) dump_state(*s->ctr, species_genes, species_fitness, solution, solution_fitness);
-    if (s->gd || s->jac) {  // point solvers: only the solution (getSolution(), ik_gradient.cpp:160, 287)
-        const std::vector<double>& v = s->gd ? s->gd->get_solution() : s->jac->get_solution();
+    if (s->gd_ref || s->gd_ctr || s->jac) {  // point solvers: only the solution (getSolution(), ik_gradient.cpp:160, 287)
+        const std::vector<double>& v = s->gd_ref ? s->gd_ref->get_solution() : (s->gd_ctr ? s->gd_ctr->get_solution() : s->jac->get_solution());
         for (size_t i = 0; i < v.size(); i++) solution[i] = v[i];
         *solution_fitness = 0.0;
     }
@@ -468,7 +477,8 @@ int orc_solver_check(void* solver, int32_t* success, double* fitness) {
     double f = 0;
     if (s->ref) s->ref->check(ok, f);
     if (s->ctr) s->ctr->check(ok, f);
-    if (s->gd) s->gd->check(ok, f);
+    if (s->gd_ref) s->gd_ref->check(ok, f);
+    if (s->gd_ctr) s->gd_ctr->check(ok, f);
     if (s->jac) s->jac->check(ok, f);
     *success = ok ? 1 : 0;
     *fitness = f;
@@ -504,11 +514,11 @@ int orc_solve_batch(void* problem, const bioik_solve_params* params, int rng_mod
                     for (int isl = 0; isl < islands; isl++) {
                         if (rng_mode == ORC_RNG_REFERENCE) {
                             // the reference clones the solver including its RNG state (utils.h:423): identical islands.
-                            rs.push_back(run_island(&local, ReferenceRandom((uint32_t)params->random_seed), *params, q, timeout_s));
+                            rs.push_back(run_island(&local, ReferenceRandom((uint32_t)params->random_seed), *params, q, timeout_s, isl));
                         } else {
                             CounterRandom r;
                             r.key = query_key(params->random_seed, first_query_index + k, (uint32_t)isl);
-                            rs.push_back(run_island(&local, r, *params, q, timeout_s));
+                            rs.push_back(run_island(&local, r, *params, q, timeout_s, isl));
                         }
                     }
                     size_t best_index = 0;

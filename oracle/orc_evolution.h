@@ -424,15 +424,17 @@ IslandResult run_island_loop(Solver& ik, size_t n_vars, const bioik_solve_params
 }
 
 // the solver behind an IKFactory name (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292)
+inline int gradient_if_stuck(int mode) { return mode == BIOIK_MODE_GD ? ' ' : (mode == BIOIK_MODE_GD_R ? 'r' : 'c'); }
+// `island`: the solver thread this island stands for (ik_parallel.h:127: thread_index)
 template <class Rng>
-IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_params& sp, const Query& q, double timeout_s) {
+IslandResult run_island(const Problem* problem, Rng rng, const bioik_solve_params& sp, const Query& q, double timeout_s, int island = 0) {
     const size_t nv = problem->model->vars.size();
-    if (sp.mode == BIOIK_MODE_GD_C || sp.mode == BIOIK_MODE_GD) {
-        GradientDescent ik(problem, sp, sp.mode == BIOIK_MODE_GD ? ' ' : 'c');
+    if (sp.mode == BIOIK_MODE_GD_C || sp.mode == BIOIK_MODE_GD || sp.mode == BIOIK_MODE_GD_R) {
+        GradientDescent<Rng> ik(problem, sp, gradient_if_stuck(sp.mode), rng, island);
         return run_island_loop(ik, nv, sp, q, timeout_s);
     }
     if (sp.mode == BIOIK_MODE_JAC) {
-        JacobianSolver ik(problem, sp);
+        JacobianSolver<Rng> ik(problem, sp, rng, island);
         return run_island_loop(ik, nv, sp, q, timeout_s);
     }
     Evolution2<Rng> ik(problem, rng, sp);

@@ -1,8 +1,11 @@
 // orc_gradient.h — ORACLE (test infrastructure): the gradient-descent and pseudo-inverse-Jacobian solvers.
 //
-// Restates reference src/ik_gradient.cpp:136-251 (IKGradientDescent<if_stuck, threads>, factory names gd / gd_c / gd_r) and
-// :42-133, 269-292 (IKJacobianBase / IKJacobian, factory name jac) for ONE island started at the seed (thread_index 0; the further
-// threads of gd_2 ... jac_8 start at random configurations, :157-159, :283-285).
+// Restates reference src/ik_gradient.cpp:136-251 (IKGradientDescent<if_stuck, threads>, factory names gd / gd_c / gd_r and their _2 / _4 /
+// _8 forms) and :42-133, 269-292 (IKJacobianBase / IKJacobian, factory names jac, jac_2 ... jac_8).  Solver thread 0 starts at the seed,
+// the further threads of the _N forms at random configurations (:157-159, :283-285) -- here: the islands 1 ... N - 1 of a query --, and
+// gd_r replaces a configuration that a step failed to improve by a random one (:165-170, :233-237).  The random numbers come from
+// the solver's generator: the reference's own (ReferenceRandom, whose clones share one state: its threads 1 ... N - 1 all start at
+// the SAME point) or the counter-based one the device uses (one stream per query and island).
 //
 // The reference's `jac` solves its least-squares step with Eigen::JacobiSVD (ik_gradient.cpp:117); Eigen is a third-party library that
 // is absent here, so the step is restated from the published definition — the minimum-norm least-squares solution through the
@@ -14,6 +17,7 @@
 #include <vector>
 
 #include "orc_problem.h"
+#include "orc_rng.h"
 
 namespace orc {
 
@@ -112,19 +116,42 @@ struct PointSolverBase {
     }
 };
 
-// ik_gradient.cpp:136-251; if_stuck: ' ' (keep the best), 'c' (always continue)
+// random(modelInfo.getMin(vi), modelInfo.getMax(vi)) for every active variable, in their order (:157-159, :165-170, :283-285)
+inline void randomize_configuration(ReferenceRandom& rng, const Problem* problem, uint32_t /*count*/, std::vector<double>& x) {
+    for (size_t ivar : problem->active_variables) x[ivar] = rng.random(problem->model->vars[ivar].min, problem->model->vars[ivar].max);
+}
+inline void randomize_configuration(CounterRandom& rng, const Problem* problem, uint32_t count, std::vector<double>& x) {
+    for (size_t g = 0; g < problem->active_variables.size(); g++) {
+        const size_t ivar = problem->active_variables[g];
+        x[ivar] = rng.point_random(g, count, problem->model->vars[ivar].min, problem->model->vars[ivar].max);
+    }
+}
+
+// ik_gradient.cpp:136-251; if_stuck: ' ' (keep the best), 'c' (always continue), 'r' (random restart)
+template <class Rng>
 struct GradientDescent : PointSolverBase {
     int if_stuck;
+    Rng rng;
+    int thread_index;
+    bool reset = false;
+    uint32_t steps_done = 0;
     std::vector<double> solution, best_solution, gradient, temp;
-    GradientDescent(const Problem* p, const bioik_solve_params& sp, int stuck) : PointSolverBase(p, sp), if_stuck(stuck) {}
-    void initialize(const Query& q) {  // :147-158 (thread_index 0)
+    GradientDescent(const Problem* p, const bioik_solve_params& sp, int stuck, Rng r = Rng(), int thread = 0)
+        : PointSolverBase(p, sp), if_stuck(stuck), rng(r), thread_index(thread) {}
+    void initialize(const Query& q) {  // :147-158
         query = q;
         fk.initialize(problem->tip_link_indices);
         solution.assign(q.initial_guess, q.initial_guess + model->vars.size());
+        if (thread_index > 0) randomize_configuration(rng, problem, 0, solution);
         best_solution = solution;
+        reset = false, steps_done = 0;
     }
     const std::vector<double>& get_solution() const { return best_solution; }
     void step() {  // :162-247
+        if (reset) {  // random reset if stuck (:165-170)
+            reset = false;
+            randomize_configuration(rng, problem, steps_done + 1, solution);
+        }
         temp = solution;
         const double jd = 0.0001;
         gradient.assign(solution.size(), 0.0);
@@ -154,18 +181,24 @@ struct GradientDescent : PointSolverBase {
             solution = temp;
         } else if (compute_fitness(temp) < compute_fitness(solution)) {
             solution = temp;
+        } else if (if_stuck == 'r') {
+            reset = true;  // (:233-237)
         }
         if (compute_fitness(solution) < compute_fitness(best_solution)) best_solution = solution;
+        steps_done++;
     }
     void check(bool& success, double& fitness) { check_vars(best_solution, success, fitness); }
 };
 
 // ik_gradient.cpp:42-133, 269-292
+template <class Rng>
 struct JacobianSolver : PointSolverBase {
+    Rng rng;
+    int thread_index;
     std::vector<double> solution, tip_diffs, joint_diffs;
     std::vector<Frame> tip_objectives;
-    JacobianSolver(const Problem* p, const bioik_solve_params& sp) : PointSolverBase(p, sp) {}
-    void initialize(const Query& q) {  // :61-67, :278-286 (thread_index 0)
+    JacobianSolver(const Problem* p, const bioik_solve_params& sp, Rng r = Rng(), int thread = 0) : PointSolverBase(p, sp), rng(r), thread_index(thread) {}
+    void initialize(const Query& q) {  // :61-67, :278-286
         query = q;
         fk.initialize(problem->tip_link_indices);
         // goal.frame of problem.cpp:152-174: identity, with the position / orientation of Position / Orientation / Pose goals
@@ -179,6 +212,7 @@ struct JacobianSolver : PointSolverBase {
             tip_objectives[g.tip_index >= 0 ? (size_t)g.tip_index : 0] = f;  // (goal_info.tip_index = 0 for goals without a link, problem.cpp:155)
         }
         solution.assign(q.initial_guess, q.initial_guess + model->vars.size());
+        if (thread_index > 0) randomize_configuration(rng, problem, 0, solution);
     }
     const std::vector<double>& get_solution() const { return solution; }
     void step() {  // optimizeJacobian, :69-132 (translational_scale = rotational_scale = 1)

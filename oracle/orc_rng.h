@@ -58,7 +58,7 @@ inline void philox4x32_10(const uint32_t* key2, const uint32_t* ctr4, uint32_t* 
 }
 
 // counter layout and integer->double post-processing
-enum { PURPOSE_REPRODUCE = 0, PURPOSE_PRESELECT = 1, PURPOSE_MEMETIC_SIGN = 2, PURPOSE_WIPEOUT = 3, PURPOSE_WIPEOUT_GENE = 4 };
+enum { PURPOSE_REPRODUCE = 0, PURPOSE_PRESELECT = 1, PURPOSE_MEMETIC_SIGN = 2, PURPOSE_WIPEOUT = 3, PURPOSE_WIPEOUT_GENE = 4, PURPOSE_POINT_RANDOM = 5 };
 // random words of child c in one generation (the bulk of all draws: 1 + D words per child):
 //     word w = mix32( ((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77) )
 // mix32 = the 32-bit finaliser of MurmurHash3 (Appleby, public domain: xor-shift 16, * 0x85EBCA6B, xor-shift 13, * 0xC2B2AE35,
@@ -132,6 +132,13 @@ struct CounterRandom {
     double wipeout_gene(size_t gene, double lo, double hi) {
         uint32_t o[2];
         philox2x32_10(key, ctr0_of(0, (uint32_t)gene), ctr1_of(generation, species, PURPOSE_WIPEOUT_GENE), o);
+        return counter_uniform_from(o[0], o[1]) * (hi - lo) + lo;
+    }
+    // the gradient / Jacobian solvers' random configurations (ik_gradient.cpp:157-159, :165-170, :283-285): draw `count` of the island
+    // (0: its starting point, s + 1: the reset in front of step s), one uniform number per gene
+    double point_random(size_t gene, uint32_t count, double lo, double hi) {
+        uint32_t o[2];
+        philox2x32_10(key, ctr0_of(0, (uint32_t)gene), ctr1_of(count, 0, PURPOSE_POINT_RANDOM), o);
         return counter_uniform_from(o[0], o[1]) * (hi - lo) + lo;
     }
 };

@@ -229,6 +229,7 @@ void* ref_create(const bioik_model_desc* md, const bioik_problem_desc* pd, const
     r->ikparams.solver_class_name = sp && sp->mode == BIOIK_MODE_BIO2 ? "bio2" : (sp && sp->mode == BIOIK_MODE_BIO2_MEMETIC_L ? "bio2_memetic_l" : "bio2_memetic");
     if (sp && sp->mode == BIOIK_MODE_GD_C) r->ikparams.solver_class_name = "gd_c";  // src/ik_gradient.cpp:263
     if (sp && sp->mode == BIOIK_MODE_GD) r->ikparams.solver_class_name = "gd";      // :253
+    if (sp && sp->mode == BIOIK_MODE_GD_R) r->ikparams.solver_class_name = "gd_r";  // :258
     if (sp && sp->mode == BIOIK_MODE_JAC) r->ikparams.solver_class_name = "jac";    // src/ik_gradient.cpp:289
     r->ikparams.enable_counter = false;
     r->ikparams.thread_count = 1;

@@ -11,6 +11,7 @@
 #include <sstream>
 
 #include <moveit/kinematics_base/kinematics_base.h>
+#include <moveit/rdf_loader/rdf_loader.h>
 #include <pluginlib/class_list_macros.h>
 #include <ros/ros.h>
 
@@ -98,6 +99,42 @@ int main(int argc, char** argv) {
         moveit_msgs::MoveItErrorCodes code;
         CHECK(!solver->getPositionFK({}, {}, poses));                                  // :140-145
         CHECK(!solver->getPositionIK(geometry_msgs::Pose(), {}, sol, code));           // :147-155
+    }
+    {
+        // the string overload (:337-360, :167-189): URDF + SRDF under the robot description's name on the parameter server, through rdf_loader
+        ros::set_param("arm_description",
+                       "<robot name='arm'><link name='base'/><link name='l1'/><link name='l2'/><link name='l3'/><link name='hand'/>"
+                       "<joint name='j1' type='revolute'><parent link='base'/><child link='l1'/><origin xyz='0 0 0.1'/><axis xyz='0 0 1'/><limit lower='-2' upper='2' velocity='1'/></joint>"
+                       "<joint name='j2' type='revolute'><parent link='l1'/><child link='l2'/><origin xyz='0.3 0 0' rpy='0.2 0 0'/><axis xyz='0 1 0'/><limit lower='-2' upper='2' velocity='1'/></joint>"
+                       "<joint name='j3' type='continuous'><parent link='l2'/><child link='l3'/><origin xyz='0.3 0 0'/><axis xyz='1 0 0'/><limit velocity='1'/></joint>"
+                       "<joint name='jh' type='fixed'><parent link='l3'/><child link='hand'/><origin xyz='0.1 0 0'/></joint></robot>");
+        ros::set_param("arm_description_semantic", "<robot name='arm'><group name='arm'><chain base_link='base' tip_link='hand'/></group></robot>");
+        std::unique_ptr<kinematics::KinematicsBase> by_name(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
+        CHECK(by_name->initialize("arm_description", "arm", "base", "hand", 0.0));
+        CHECK(by_name->getJointNames() == (std::vector<std::string>{"j1", "j2", "j3"}) && by_name->getLinkNames() == std::vector<std::string>{"hand"});
+        moveit::core::RobotModelPtr arm(new moveit::core::RobotModel(rdf_loader::RDFLoader("arm_description").getURDF(), rdf_loader::RDFLoader("arm_description").getSRDF()));
+        moveit::core::RobotState want(arm), got(arm);
+        want.setToDefaultValues(), got.setToDefaultValues();
+        const std::vector<double> q = {0.4, -0.7, 1.1};
+        for (size_t i = 0; i < 3; i++) want.setVariablePosition(by_name->getJointNames()[i], q[i]);
+        const geometry_msgs::Pose pose = poseInBase(want, "base", "hand");
+        std::vector<double> sol;
+        moveit_msgs::MoveItErrorCodes code;
+        CHECK(by_name->searchPositionIK(pose, {0.3, -0.6, 1.0}, 60.0, sol, code) && code.val == moveit_msgs::MoveItErrorCodes::SUCCESS && sol.size() == 3);
+        for (size_t i = 0; i < 3; i++) got.setVariablePosition(by_name->getJointNames()[i], sol[i]);
+        const geometry_msgs::Pose reached = poseInBase(got, "base", "hand");
+        CHECK(std::fabs(reached.position.x - pose.position.x) < 1e-4 && std::fabs(reached.position.y - pose.position.y) < 1e-4 && std::fabs(reached.position.z - pose.position.z) < 1e-4);
+        // a description that is not on the parameter server: the reference logs and fails to load; initialize still returns true (:337-360), and a
+        // query to the plugin that was never set up is a usage error (it throws, like one after a failed re-initialisation below)
+        std::unique_ptr<kinematics::KinematicsBase> missing(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
+        CHECK(missing->initialize("no_such_description", "arm", "base", "hand", 0.0));
+        bool threw = false;
+        try {
+            missing->searchPositionIK(pose, {0.3, -0.6, 1.0}, 1.0, sol, code);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
     }
     // FK -> IK -> FK round trips (reference README.md:404-447)
     std::mt19937 rng(5);

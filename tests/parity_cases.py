@@ -155,13 +155,23 @@ def point_solvers(h, o, template, n=8, exact_jac=True):
     shared exact-FK arithmetic: identical bits.  jac goes through acos (twist of the pose error), which the device math library and libm
     may round differently: identical where both sides run on the host, to 1e-9 on the device."""
     seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=41, kind="tracking")
-    for mode, budgets in (("gd_c", (1, 6, 20)), ("gd", (1, 6, 20)), ("jac", (1, 3, 10))):
+    # islands = N: the reference's gd_N / gd_r_N / gd_c_N / jac_N (solver threads 1 ... N - 1 start at random configurations, the best
+    # island wins); gd_r: random restarts after a step that did not improve (the draws of both are the counter generator's)
+    for mode, islands, budgets in (("gd_c", 1, (1, 6, 20)), ("gd", 1, (1, 6, 20)), ("jac", 1, (1, 3, 10)), ("gd_r", 1, (1, 6, 40)), ("gd_r", 2, (8,)),
+                                   ("gd", 4, (1, 6)), ("gd_c", 2, (6,)), ("jac", 4, (1, 5))):
         for st in budgets:
-            p = abi.default_solve_params(mode=mode, max_steps=st)
+            p = abi.default_solve_params(mode=mode, max_steps=st, islands=islands, random_seed=7)
             a = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
             b = h.solve_batch(p, seeds, params)
-            if mode in ("gd_c", "gd") or exact_jac:
-                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (mode, st, np.abs(a[0] - b[0]).max())
+            if mode != "jac" or exact_jac:
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (mode, islands, st, np.abs(a[0] - b[0]).max())
             else:
-                assert np.abs(a[0] - b[0]).max() < 1e-9 and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), (mode, st)
+                assert np.abs(a[0] - b[0]).max() < 1e-9 and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), (mode, islands, st)
+    # far goals (uniformly drawn seeds): steps that fail to improve, so gd_r restarts, and islands whose random starting points win
+    seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=43)
+    for mode, islands, st in (("gd_r", 1, 40), ("gd_r", 4, 24), ("gd", 8, 12)):
+        p = abi.default_solve_params(mode=mode, max_steps=st, islands=islands, random_seed=11)
+        a = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
+        c = h.solve_batch(p, seeds, params)
+        assert all(np.array_equal(x, y) for x, y in zip(a, c)), (mode, islands, st, np.abs(a[0] - c[0]).max())
     return b

@@ -107,6 +107,27 @@ def test_angle_wrapping_matches_oracle(plugin, oracles, pr2):
     assert np.abs(got[:, act] - want[:, act]).max() < 1e-12
 
 
+def test_factory_names_of_the_gradient_solvers(hostsim_shim, pr2):
+    """IKFactory names of src/ik_gradient.cpp:254-292 as the yaml `mode`: gd / gd_r / gd_c / jac and their _2 / _4 / _8 forms (N solver
+    threads, the further ones started at random configurations = N islands); bio1 and the optimiser-library names are configuration errors"""
+    rng = np.random.default_rng(3)
+    target = pr2.default_positions()
+    for mode, want_success in (("jac", True), ("jac_4", True), ("gd_r_2", False), ("gd_c_8", False), ("gd", False)):
+        p = BioIKKinematicsPlugin(lib=hostsim_shim)
+        assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0, params={"mode": mode, "gpu_max_steps": 12, "gpu_reproducible_calls": True})
+        gv = p._group_vars
+        target[gv] = random_configuration(pr2, rng)[gv]
+        pose = goal_in_base_frame(pr2, target)
+        seed = list(np.clip(target[gv] + 0.05 * rng.normal(size=len(gv)), np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv]))
+        sol, code = [], MoveItErrorCodes()
+        ok = p.searchPositionIK([pose], seed, 0.0, sol, code, options=KinematicsQueryOptions(return_approximate_solution=not want_success))
+        assert ok and len(sol) == 7, mode
+        p.close()
+    for mode in ("bio1", "gd_3", "jac_16", "optlib_bfgs"):
+        with pytest.raises(RuntimeError):
+            BioIKKinematicsPlugin(lib=hostsim_shim).initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"mode": mode})
+
+
 def test_product_shim_exports():
     """libbio_ik_shim.so (linked against libbioik_hip.so) loads without a GPU and exports what plugin.py binds"""
     import subprocess, os
