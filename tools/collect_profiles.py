@@ -40,6 +40,8 @@ b = json.load(open(os.path.join(p, rnd + "_bench.json")))
 if isinstance(b.get("roofline"), dict):
     b["roofline"]["traffic_as_printed"] = b["roofline"].get("traffic")
     b["roofline"]["traffic"] = 2 * fk * 1024 + wk * 1024
+    b["roofline"]["traffic_provenance_as_printed"] = b["roofline"].get("traffic_provenance")
+    b["roofline"]["traffic_provenance"] = "PMC passes of this same session on the same library (profiles/%s_pmc_k_solve.json), filled in by tools/collect_profiles.py" % rnd
     json.dump(b, open(os.path.join(p, rnd + "_bench.json"), "w"))
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
     print(k, "%.4g" % out[k]["mean_per_launch"])

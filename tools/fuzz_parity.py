@@ -52,6 +52,9 @@ def main():
             fk = abi.FK_EXACT
         islands = int(rng.choice([1, 1, 2, 3]))
         steps = int(rng.choice([1, 2, 5, 9]))
+        if name not in ("floating", "planar") and rng.random() < 0.12:  # the gradient family (round 3: gd_r, islands = the _N solver names)
+            mode, fk = str(rng.choice(["gd", "gd_r", "gd_c"])), abi.FK_EXACT
+            islands, steps = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 5, 20, 40]))
         n = int(rng.choice([3, 17, 40]))
         env = {}
         r = rng.random()
