@@ -472,6 +472,9 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
                 dev.primary[np++] = to_dev(g);
             }
         dev.tips[t].goal_count = np - dev.tips[t].goal_first;
+        const bool one_pose = dev.tips[t].goal_count == 1 && dev.primary[dev.tips[t].goal_first].type == BIOIK_GOAL_POSE;
+        dev.tips[t].pose_off = one_pose ? dev.primary[dev.tips[t].goal_first].param_off : -1;
+        dev.tips[t].pose_weight_sq = one_pose ? dev.primary[dev.tips[t].goal_first].weight_sq : 0.0;
     }
     dev.n_link_primary = np;
     for (const G& g : goals) {
@@ -500,6 +503,10 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
     dev.n_primary = np;
     dev.n_secondary = ns;
+    dev.pose_only = (T == 1 && np == 1 && ns == 0 && dev.n_balance == 0 && dev.n_link_primary == 1 && dev.primary[0].type == BIOIK_GOAL_POSE &&
+                     dev.primary[0].tip == 0) ? 1 : 0;
+    dev.pose_param_off = dev.pose_only ? dev.primary[0].param_off : 0;
+    dev.pose_weight_sq = dev.pose_only ? dev.primary[0].weight_sq : 0.0;
     dev.n_ops = (int)ops.size();
     dev.n_chain_ops = n_chain;
     // the memetic phase gives gene i to lane i of a 64-lane wavefront and the unperturbed elite to lane D

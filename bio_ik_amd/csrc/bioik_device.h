@@ -418,6 +418,15 @@ BIOIK_DEV double goal_eval_joint_set_inl(ProbPtr pb, int type, int var_op, int v
 BIOIK_CALL double goal_eval_joint_set(ProbPtr pb, int type, int var_op, int var_seed, double p0, const lds_f64* xp, int xs, const lds_f64* seed) {
     return goal_eval_joint_set_inl(pb, type, var_op, var_seed, p0, xp, xs, seed);
 }
+// PoseGoal::evaluate (goal_types.h:149-180); P: position, orientation, rotation scale
+BIOIK_DEV double pose_goal_cost(const double* P, const F7& fb) {
+    double e = dist2(fb.p, v3(P[0], P[1], P[2]));
+    const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
+    const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
+    double rs = P[7];
+    e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
+    return e;
+}
 // JS_INLINE: the goals over the joint values are inlined (the one hot site: secondary fitness of every child in the pre-selection)
 template <bool JS_INLINE = false, class XA = XV>
 BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const double* P, const F7& fb, const XA& x, const QueryCtx& qc) {
@@ -430,14 +439,8 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
             const Q4 a = Q4{P[0] + fb.q.x, P[1] + fb.q.y, P[2] + fb.q.z, P[3] + fb.q.w};
             return fmin(qdot(d, d), qdot(a, a));
         }
-        case G_POSE: {  // :149-180
-            double e = dist2(fb.p, v3(P[0], P[1], P[2]));
-            const Q4 d = Q4{P[3] - fb.q.x, P[4] - fb.q.y, P[5] - fb.q.z, P[6] - fb.q.w};
-            const Q4 a = Q4{P[3] + fb.q.x, P[4] + fb.q.y, P[5] + fb.q.z, P[6] + fb.q.w};
-            double rs = P[7];
-            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
-            return e;
-        }
+        case G_POSE:
+            return pose_goal_cost(P, fb);
         case G_AVOID_JOINT_LIMITS:
         case G_CENTER_JOINTS:
         case G_REGULARIZATION:
@@ -459,6 +462,10 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
 // Σ weight² · e over the primary link goals of one tip (problem.cpp:244-257, grouped by tip)
 template <class XA>
 BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XA& x, const QueryCtx& qc) {
+#if !defined(BIOIK_NO_POSE_ONLY)
+    // the usual tip: one PoseGoal (DevTip::pose_off).  0 + w² e = w² e: the sum below without the goal table's dependent scalar loads
+    if (pb->tips[t].pose_off >= 0) return pose_goal_cost(qc.par + pb->tips[t].pose_off, f) * pb->tips[t].pose_weight_sq;
+#endif
     double sum = 0.0;
     const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
     for (int g = g0; g < g1; g++)
@@ -841,7 +848,9 @@ BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc,
     fk_walk_n<N>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
 #pragma unroll
         for (int j = 0; j < N; j++) balance_tip(pb, t, f[j], bal[j]);
-        // the goals of the tip, each evaluated for the N individuals (per individual: the summation order of tip_goals)
+        // the goals of the tip, each evaluated for the N individuals (per individual: the summation order of tip_goals).  (No one-PoseGoal
+        // form here, unlike tip_goals: this loop is bound by issue slots, not by the latency of the goal table, and the second path costs
+        // the generation loop four registers -- three spilled values in the computed-children kernel, ten more under its 128-register budget.)
         const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
         for (int g = g0; g < g1; g++) {
             const int type = pb->primary[g].type, var_op = pb->primary[g].var_op, var_seed = pb->primary[g].var_seed, po = pb->primary[g].param_off;
@@ -1334,6 +1343,13 @@ BIOIK_CALL int check_frame_goal(int type, const lds_f64* P, F7 fb, double dpos, 
             ok = ok && (sqrt(len2(fb.p - fa.p)) <= dpos);
             ok = ok && (angle_shortest_path(fb.q, fa.q) * 180 / BIOIK_PI <= drot);
         }
+#if !defined(BIOIK_NO_POSE_ONLY)
+        // The linear part of the twist is the position error turned into the goal's frame: as long as the tip is further from the goal than
+        // 2 dtwist, one of its components is at least 2 / sqrt(3) dtwist and the test below fails whatever the rotation -- which is the case in
+        // every step but the last few of a solve; the twist (a frame change, two rotation matrices, an acos) is then not computed.
+        // (a goal orientation that is not a unit quaternion scales the twist: no shortcut then)
+        if (dtwist != BIOIK_DBL_MAX && dtwist < 1e100 && len2(fb.p - fa.p) > 4.0 * dtwist * dtwist && fabs(qdot(fa.q, fa.q) - 1.0) < 1e-6) return 0;
+#endif
         if (dtwist != BIOIK_DBL_MAX) {
             double tw[6];
             pose_twist(fa, fb, tw);
@@ -1376,6 +1392,11 @@ BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* sl
     fk_walk<COOP>(pb, x, slots, nullptr, [&](int t, const F7& f) {
         sum += tip_goals(pb, t, f, x, qc);
         balance_tip(pb, t, f, bal);
+#if !defined(BIOIK_NO_POSE_ONLY)
+        if (do_check && pb->tips[t].pose_off >= 0) {
+            good = check_frame_goal(G_POSE, (const lds_f64*)(qc.par + pb->tips[t].pose_off), f, dpos, drot, dtwist) != 0 && good;
+        } else
+#endif
         if (do_check) {
             const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
             for (int g = g0; g < g1; g++) good = check_goal(pb, g, f, x, qc, dpos, drot, dtwist) && good;

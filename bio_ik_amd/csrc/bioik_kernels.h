@@ -750,6 +750,24 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     auto frame_of = [&](const double* fc, int t) { return f7_load(fc + t * 8); };
                     // goal fitness of the lane's frames `fc` (+ its gene's delta * step): (primary, all goals); x: what joint-value goals read
                     auto goals_on = [&](const double* fc, int dop, double dstep, const PerturbX& x, double& prim, double& all) {
+#if !defined(BIOIK_NO_POSE_ONLY)
+                        if (pb->pose_only) {  // one PoseGoal on one tip and nothing else: the same operations without the goal tables (0 + w² e = w² e)
+                            F7 f = frame_of(fc, 0);
+                            if (dstep != 0.0 && dop >= 0) {
+                                const double* dl = s_delta + (size_t)dop * 7;
+                                f = F7{{BK_FMA(dl[0], dstep, f.p.x), BK_FMA(dl[1], dstep, f.p.y), BK_FMA(dl[2], dstep, f.p.z)},
+                                       {BK_FMA(dl[3], dstep, f.q.x), BK_FMA(dl[4], dstep, f.q.y), BK_FMA(dl[5], dstep, f.q.z), BK_FMA(dl[6], dstep, f.q.w)}};
+                            }
+                            const double* P = qc.par + pb->pose_param_off;
+                            double e = dist2(f.p, v3(P[0], P[1], P[2]));
+                            const Q4 d = Q4{P[3] - f.q.x, P[4] - f.q.y, P[5] - f.q.z, P[6] - f.q.w};
+                            const Q4 a = Q4{P[3] + f.q.x, P[4] + f.q.y, P[5] + f.q.z, P[6] + f.q.w};
+                            const double rs = P[7];
+                            e += fmin(qdot(d, d), qdot(a, a)) * (rs * rs);
+                            prim = all = e * pb->pose_weight_sq;
+                            return;
+                        }
+#endif
                         double acc = 0.0;
                         V3 bal = v3(0.0, 0.0, 0.0);
                         for (int t = 0; t < T; t++) {

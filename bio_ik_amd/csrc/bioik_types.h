@@ -56,6 +56,9 @@ struct DevTip {
     int32_t has_e;                     // 0: E is the identity
     int32_t out_index;                 // index in Problem::tip_link_indices (order of the public API)
     int32_t goal_first, goal_count;    // primary link goals reading this tip: DevProblem::primary[goal_first..)
+    int32_t pose_off;                  // >= 0: exactly ONE primary goal reads this tip and it is a PoseGoal whose numbers start at this offset of the
+    int32_t pad0;                      //       query's parameters -- the usual case, evaluated without a look at the goal table
+    double pose_weight_sq;             //       its weight_sq
     uint64_t dep_mask;                 // bit k: op k lies on the root->tip chain (tip_dependencies, forward_kinematics.h:588-598)
     int32_t obj_type;                  // `jac` solver: what last wrote tipObjectives[tip] (ik_gradient.cpp:64-66): BIOIK_GOAL_POSITION /
     int32_t obj_param_off;             // ORIENTATION / POSE with its parameter offset, -1 = an identity frame
@@ -93,6 +96,11 @@ struct DevProblem {
     int32_t n_primary;
     int32_t n_secondary;
     int32_t n_balance;     // BalanceGoals (goal_types.cpp:231-272): they read every tip with bal_w != 0; balance[0..n_balance)
+    // The plugin's default problem -- ONE tip link carrying ONE PoseGoal and no other goal (kinematics_plugin.cpp:279-297) -- spelled out, so that the
+    // latency-bound evaluations of a single individual (memetic phase, ranking) read three scalars instead of walking the goal tables:
+    int32_t pose_only;       // 1: the primary fitness is primary[0].weight_sq * PoseGoal cost of tip 0, and there is no secondary / balance goal
+    int32_t pose_param_off;  // primary[0].param_off
+    double pose_weight_sq;   // primary[0].weight_sq
     uint64_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
     double multi_c[7];     // constant frame in front of the floating / planar joint
     int32_t quat_op[4];    // op index of the first of the four orientation value ops
