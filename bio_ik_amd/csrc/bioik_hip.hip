@@ -456,7 +456,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
-        const bool four_waves = (160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !std::getenv("BIOIK_SOLVE_THREE_WAVES");
+        const bool four_waves = ((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !std::getenv("BIOIK_SOLVE_THREE_WAVES")) ||
+                                std::getenv("BIOIK_SOLVE_FOUR_WAVES");  // (diagnostic: the 128-register build wherever children are computed)
         if (lean && args.sp.columnless && four_waves)
             LAUNCH(k_solve_lean_cl4, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless)
