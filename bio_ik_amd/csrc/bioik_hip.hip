@@ -121,6 +121,13 @@ __global__ void __launch_bounds__(256, 4) k_solve_lean_cl4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true>(a, blockIdx.x, lds);
 }
+// Computed children with both species of a query on the halves of one wavefront AND secondary goals: the children of the two species are walked
+// as one list over the 64 lanes (solve_body<.., JOINT>), so that the wavefront does not wait for the longer of two random prefixes (C3: +7 %,
+// profiles/r03_ab_joint_walk.log)
+__global__ void __launch_bounds__(64, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_clj(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true, true>(a, blockIdx.x, lds);
+}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -164,6 +171,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -458,7 +466,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
         const bool four_waves = ((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !std::getenv("BIOIK_SOLVE_THREE_WAVES")) ||
                                 std::getenv("BIOIK_SOLVE_FOUR_WAVES");  // (diagnostic: the 128-register build wherever children are computed)
-        if (lean && args.sp.columnless && four_waves)
+        // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
+        // (with a wavefront per species -- 128 lanes, C4 -- the same walk gains nothing: a wavefront that waits at a barrier costs no issue slots,
+        // profiles/r03_ab_joint_walk.log)
+        const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
+                           !std::getenv("BIOIK_SOLVE_NO_JOINT");
+        if (lean && args.sp.columnless && joint)
+            LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean && args.sp.columnless && four_waves)
             LAUNCH(k_solve_lean_cl4, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless)
             LAUNCH(k_solve_lean_cl, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);

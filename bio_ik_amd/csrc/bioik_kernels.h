@@ -301,10 +301,15 @@ struct SpeciesState {
 // CL: children computed where they are read (no genotype columns, sp.columnless) — a kernel of its own, so that the accessor-templated
 // copies of the chain walk do not weigh on the register allocation of the column kernels (with both in one kernel the lean flavour
 // spilled 74 instead of 32 VGPRs and lost 4 % on C2)
-template <bool LEAN, bool CL = false>
+// JOINT: both species of a query on the halves of ONE wavefront (64 lanes) and a problem with secondary goals -- every species then walks a random
+// prefix of its pre-selected children (ik_evolution_2.cpp:366-378), and with one half per species the wavefront waits for the longer of
+// the two prefixes (2/3 of the children on average, against 1/2).  In this instantiation the 64 lanes walk the children of BOTH species as
+// one list, and each species' two best are found by a reduction over the whole wavefront.
+template <bool LEAN, bool CL = false, bool JOINT = false>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
+    static_assert(CL || !JOINT, "the joint walk of both species' children exists for computed children only");
     const bool resume = a.unit_list != nullptr;
     if (resume) {  // (uniform over the workgroup, before the first barrier)
         if (unit >= (uint64_t)*a.unit_count) return;
@@ -552,7 +557,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = !columnless && n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
-                if (stored && sp.child_pairs && exact) {
+                if (!JOINT && stored && sp.child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
                     for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
                         const int r1 = r + G;
@@ -570,7 +575,43 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         offer(f[0], r + 2);
                         if (two) offer(f[1], r1 + 2);
                     }
-                } else if (columnless && sp.child_pairs && exact) {
+                } else if (JOINT) {
+                    if constexpr (JOINT) {
+                        // the pre-selected children of both species as one list over the 64 lanes: item i < n0 is species 0's child at sorted position i,
+                        // item n0 + i species 1's; two items per lane and trip.  What a lane needs of the OTHER half's species -- its elites,
+                        // its random stream, its sorted order -- is uniform inside that half: one v_readlane each.
+                        const int cb_off = (int)(cb - lds);
+                        const int cbo[2] = {p_read_lane(cb_off, 0), p_read_lane(cb_off, 32)};
+                        const int ct[2] = {p_read_lane((int)ctr1, 0), p_read_lane((int)ctr1, 32)};
+                        const int ne0 = p_read_lane(n_eval, 0), total = ne0 + p_read_lane(n_eval, 32);
+                        const int32_t* const ord[2] = {(const int32_t*)(lds + L.g_first + L.order), (const int32_t*)(lds + L.g_first + L.g_stride + L.order)};
+                        double t1f[2] = {P_INF, P_INF}, t2f[2] = {P_INF, P_INF};  // the lane's best two per species
+                        int t1p[2] = {0x7fffffff, 0x7fffffff}, t2p[2] = {0x7fffffff, 0x7fffffff};
+                        for (int i0 = tid; i0 < total; i0 += 128) {
+                            const int i1 = i0 + 64 < total ? i0 + 64 : i0;  // (an odd tail repeats the first item and drops it)
+                            const int sp0 = i0 >= ne0 ? 1 : 0, sp1 = i1 >= ne0 ? 1 : 0;
+                            const int r0 = i0 - (sp0 ? ne0 : 0), r1 = i1 - (sp1 ? ne0 : 0);
+                            const int c0 = (sp0 ? ord[1] : ord[0])[r0], c1 = (sp1 ? ord[1] : ord[0])[r1];
+                            const double *pa = lds + (sp0 ? cbo[1] : cbo[0]), *pc = lds + (sp1 ? cbo[1] : cbo[0]);
+                            const ChildX<PB> cx[2] = {make_child_x(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, pa + M, pa + 3 * M),
+                                                      make_child_x(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, pc + M, pc + 3 * M)};
+                            PHASE_MARK(PH_REPRODUCE);
+                            double f[2];
+                            eval_exact_primary_n<2>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                            PHASE_MARK(PH_FITNESS);
+                            // (a candidate of the other species is offered as +inf at the last position, which never enters a best-two)
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                top2_insert(t1f[q], t1p[q], t2f[q], t2p[q], sp0 == q ? f[0] : P_INF, sp0 == q ? r0 + 2 : 0x7fffffff);
+                                const bool second = i0 + 64 < total && sp1 == q;
+                                top2_insert(t1f[q], t1p[q], t2f[q], t2p[q], second ? f[1] : P_INF, second ? r1 + 2 : 0x7fffffff);
+                            }
+                        }
+                        top2_wave64_minima(t1f[0], t1p[0], t2f[0], t2p[0]);
+                        top2_wave64_minima(t1f[1], t1p[1], t2f[1], t2p[1]);
+                        b1f = grp ? t1f[1] : t1f[0], b1p = grp ? t1p[1] : t1p[0], b2f = grp ? t2f[1] : t2f[0], b2p = grp ? t2p[1] : t2p[0];
+                    }
+                } else if (!JOINT && columnless && sp.child_pairs && exact) {
                     // two children per trip, both computed where they are read: two independent dependency chains per lane
                     for (int r = gtid; r < n_eval; r += 2 * G) {
                         const int r1 = r + G;
@@ -586,7 +627,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         offer(f[0], r + 2);
                         if (two) offer(f[1], r1 + 2);
                     }
-                } else if (columnless) {
+                } else if (!JOINT && columnless) {
                     for (int r = gtid; r < n_eval; r += G) {
                         const int c = has_sec ? s_order[r] : r;
                         const auto cx = make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d);
@@ -608,7 +649,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
-                top2_wave(b1f, b1p, b2f, b2p, G);
+                if (!JOINT) top2_wave(b1f, b1p, b2f, b2p, G);  // (the joint walk has reduced over the whole wavefront already)
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 PHASE_MARK(PH_SEL_XWAVE);

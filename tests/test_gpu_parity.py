@@ -234,6 +234,8 @@ def test_trajectory_bit_exact(gpus, oracles, templates, cfg, pop, kw):
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "1"},        # children computed where they are read: no genotype columns in LDS
     {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_COLUMNLESS": "1"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "2"},       # ... and scored two at a time
+    {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"},  # C3: the joint walk of both species' children
+    {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2", "BIOIK_SOLVE_NO_JOINT": "1"},
     {"BIOIK_SOLVE_THREADS": "256", "BIOIK_SOLVE_COLUMNLESS": "1"},
     {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "0", "BIOIK_SOLVE_STORE_CHILDREN": "0"},
     {"BIOIK_SOLVE_TWO_PHASE": "1"},                                      # two launches: hand-over after the first step (first launch: the species
@@ -455,6 +457,21 @@ def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, tem
     p = abi.default_solve_params(population=512, max_steps=6, random_seed=4)
     a = h.solve_batch(p, seeds, params)
     monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+    b = h.solve_batch(p, seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_joint_walk_of_both_species_children_full_size(gpus, oracles, templates, monkeypatch):
+    """C3 at its full population runs k_solve_lean_clj (both species on one wavefront, their pre-selected children walked as one list):
+    trajectories equal to the oracle's, and a 1024-query batch equal to the one-half-per-species form bit for bit"""
+    h, o, t = gpus["c3"], oracles["c3"], templates["c3"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 1024, seed=33)
+    p = abi.default_solve_params(population=128, max_steps=5, random_seed=6)
+    a = h.solve_batch(p, seeds, params)
+    with pc.oracle_arithmetic(1):
+        w = o.solve_batch(p, orc.RNG_COUNTER, seeds[:24], params[:24], n_threads=8)
+    assert all(np.array_equal(x[:24], y) for x, y in zip(a, w))
+    monkeypatch.setenv("BIOIK_SOLVE_NO_JOINT", "1")
     b = h.solve_batch(p, seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
 

@@ -97,6 +97,20 @@ def test_preselection_with_computed_children_several_per_lane(sims, oracles, tem
     pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=pop, steps_list=(1,))
 
 
+@pytest.mark.parametrize("pop", [9, 70, 128, 333])
+def test_joint_walk_of_both_species_children(sims, oracles, templates, monkeypatch, pop):
+    """both species on the halves of one wavefront, secondary goals, children in pairs: the 64 lanes walk the random prefixes of BOTH species'
+    pre-selected children as one list (solve_body<.., JOINT>, k_solve_lean_clj) and find each species' two best over the whole wavefront --
+    the same winners as with one half per species (BIOIK_SOLVE_NO_JOINT), which is the oracle's result"""
+    for k, v in {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}.items():
+        monkeypatch.setenv(k, v)
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=pop, steps_list=(1, 3))
+    if pop <= 128:
+        pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=pop, steps_list=(1,))
+    monkeypatch.setenv("BIOIK_SOLVE_NO_JOINT", "1")
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=pop, steps_list=(2,))
+
+
 @pytest.mark.parametrize("env", [
     {"BIOIK_SOLVE_TWO_PHASE": "1"},
     {"BIOIK_SOLVE_TWO_PHASE": "1", "BIOIK_SOLVE_GENERAL": "1"},

@@ -68,9 +68,13 @@ def main():
             env = {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1"}
         elif r < 0.6:
             env = {"BIOIK_SOLVE_GENERAL": "1"}
+        elif r < 0.7:  # both species on one wavefront, children computed in pairs: with a secondary goal and exact FK the joint walk (k_solve_lean_clj)
+            env = {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}
+            if rng.random() < 0.3:
+                env["BIOIK_SOLVE_NO_JOINT"] = "1"
         if rng.random() < 0.2:
             env["BIOIK_SOLVE_STORE_CHILDREN"] = "0"
-        elif rng.random() < 0.35 and "BIOIK_SOLVE_GENERAL" not in env:  # children computed where they are read (round 2), singly or in pairs
+        elif rng.random() < 0.35 and "BIOIK_SOLVE_GENERAL" not in env and "BIOIK_SOLVE_COLUMNLESS" not in env:  # children computed where they are read (round 2), singly or in pairs
             env["BIOIK_SOLVE_COLUMNLESS"] = str(rng.choice(["1", "2"]))
         if rng.random() < 0.3:  # the solve split over two or more launches (round 2), under whatever mapping was drawn above
             env["BIOIK_SOLVE_TWO_PHASE"] = str(rng.choice(["1", "2", "3", "1,2", "2,4,6", "init"]))
