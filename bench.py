@@ -6,12 +6,13 @@ right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), 
 `value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
 GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
-Consecutive steps are issued round-robin on three HIP streams (`--in-flight`, config.batches_in_flight): the tail of one
-launch — a handful of queries that use the whole step budget, 64 sequential steps wherever they start — overlaps the bulk
-of the next ones; `one_batch_at_a_time` holds the same measurement with strictly one solve after the other
-(profiles/r01_inflight_sweep.log, r02_two_launch_sweep.log: 1 / 2 / 3 in flight).  For a batch of this size the library enqueues a solve as
-TWO kernels (k_solve_lean_cl: the first step of every query, k_solve_lean: the unsolved queries to the end, state handed over through HBM;
-DESIGN.md section 5): a step of this bench is still one call of `bioik_solve_batch_device`.
+Consecutive steps are issued round-robin on six HIP streams (`--in-flight`, config.batches_in_flight) under
+bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT (`--schedule`): the library's mapping for streams of batches (both species of a query on
+one wavefront: 27 % more steps per ms on a full chip, a step 2.5 x as long), under which the tail of one launch — a handful of queries that
+use the whole step budget, 64 sequential steps wherever they start — lasts ~16 ms and six solves in flight (on six hardware queues:
+GPU_MAX_HW_QUEUES) keep the chip full (profiles/r03_inflight_and_schedule.log).  The same workload under BIOIK_SCHEDULE_LATENCY — the default of
+the library, what an isolated call wants — is on the line as `latency_schedule_three_in_flight` (the protocol of `value` in earlier rounds)
+and `one_batch_at_a_time` (strictly one solve after the other).  A step of this bench is one call of `bioik_solve_batch_device`.
 
 Extra objects on the JSON line:
   roofline     the solve's kernels (k_solve_lean dominant) against the roof that binds them, FP64 vector arithmetic: ALGORITHMIC flops per solve
@@ -38,6 +39,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the six solves this bench keeps in flight want a queue
+# each (profiles/r03_inflight_and_schedule.log).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BATCH = int(os.environ.get("BIOIK_BENCH_BATCH", "4096"))      # experiments only: the reported metric uses the defaults
 POP = int(os.environ.get("BIOIK_BENCH_POP", "128"))
@@ -224,8 +228,11 @@ def main():
                     help="c2 (default): BASELINE.json configs[1], the configuration the metric is quoted on.  c5: configs[4], a mixed PR2 / snake "
                          "batch that rank 0 holds, sorted by model and sharded over all ranks end to end (scatter -> solve -> gather, "
                          "bio_ik_amd.batch.solve_mixed); BIOIK_BENCH_C5_BATCH sets the global batch (default 262144)")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "3")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "6")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other)")
+    ap.add_argument("--schedule", default=os.environ.get("BIOIK_BENCH_SCHEDULE", "throughput"), choices=["throughput", "latency"],
+                    help="bioik_solve_params::schedule of the timed steps (include/bioik_hip.h): throughput = the mapping for streams of batches (six in "
+                         "flight), latency = the mapping for isolated calls (three in flight fill the chip); the one-at-a-time leg always runs under latency")
     args = ap.parse_args()
 
     import numpy as np
@@ -267,8 +274,10 @@ def main():
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank)
     h.set_first_query(rank * BATCH)
     p = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, fk_mode=abi.FK_EXACT if FK_MODE == "exact" else abi.FK_LINEAR)
+    p_latency = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, fk_mode=abi.FK_EXACT if FK_MODE == "exact" else abi.FK_LINEAR)
+    p.schedule = abi.SCHEDULE_BY_NAME[args.schedule]
     if "BIOIK_BENCH_DTWIST" in os.environ:  # experiments only (e.g. 1e-300: no query ever succeeds, every workgroup runs max_steps)
-        p.dtwist = float(os.environ["BIOIK_BENCH_DTWIST"])
+        p.dtwist = p_latency.dtwist = float(os.environ["BIOIK_BENCH_DTWIST"])
 
     if os.environ.get("BIOIK_BENCH_ORDER"):  # experiment: the queries of a batch sorted by the steps they will need (asc | desc), known from a first solve
         first = h.solve_batch(p, seeds, params)
@@ -298,10 +307,12 @@ def main():
             sk, pk, _ = make_queries(template, h.active_variables, h.fk_genes, BATCH, seed=0xB101C + rank + 1000 * k)
             inputs.append((torch.from_numpy(sk).to(dev), torch.from_numpy(pk).to(dev)))
 
+    step_params = [p]  # (the legs below swap the schedule)
+
     def step(i):
         o, st = bufs[i % nfl], streams[i % nfl]
         ds, dp = inputs[i % nfl]
-        h.solve_batch_device(p, BATCH, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+        h.solve_batch_device(step_params[0], BATCH, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
                              st.cuda_stream)
 
     def barrier():
@@ -341,12 +352,22 @@ def main():
                              streams[1].cuda_stream)
         torch.cuda.synchronize(dev)
         identical = bool(torch.equal(chk[0], d_sol)) and bool(torch.equal(chk[2], d_suc)) and bool(torch.equal(chk[3], d_steps))
-    sequential = None
-    if nfl > 1 and not args.timed_only:  # the same steps strictly one after the other, for the record
+    sequential = latency3 = None
+    if nfl > 1 and not args.timed_only:
+        # the same steps strictly one after the other, and three in flight, under BIOIK_SCHEDULE_LATENCY: what an isolated call takes, and the
+        # protocol of the rounds before the schedule existed
         nfl_saved, nfl = nfl, 1
+        step_params[0] = p_latency
         sel, skm = timed(min(args.steps, 10), 1)
-        nfl = nfl_saved
         sequential = (sel / max(min(args.steps, 10), 1), skm)
+        if nfl_saved >= 3:
+            nfl = 3
+            n3 = min(args.steps, 30)
+            l3, _ = timed(n3, 3)
+            sh3 = [len(range(k, n3, 3)) for k in range(3)]
+            latency3 = (float(sum(int(bufs[k][2].sum().item()) * sh3[k] for k in range(3))) / l3, l3 / n3)
+        nfl = nfl_saved
+        step_params[0] = p
 
     suc = d_suc.cpu().numpy()
     steps_q = d_steps.cpu().numpy()
@@ -408,7 +429,7 @@ def main():
         "data": "synthetic (one batch of queries per stream in flight: same recipe, different draws)",
         "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
                    "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective",
-                   "batches_in_flight": nfl},
+                   "batches_in_flight": nfl, "schedule": args.schedule, "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "success_rate": succ_timed / max(args.steps * BATCH, 1),
         "mean_steps_per_solve": steps_per_launch / BATCH,
         "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
@@ -416,14 +437,15 @@ def main():
         "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
-                     "kernel": "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": alg_flops,
+                     "kernel": "k_solve_lean_cl" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
+                     "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
                      "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
                      "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
                      "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
-                             "formula x fitness evaluations counted on the device; a batch of this size is solved in two launches (k_solve_lean_cl: the first "
-                             "step of every query under the half-wavefront mapping, k_solve_lean: the unsolved queries to the end); kernel_ms is the "
-                             "event-bracketed duration of the two (= the sum of their rocprofv3 averages) while %d solves "
+                             "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl (both "
+                             "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY two (k_solve_lean_cl: the first step of every query, "
+                             "k_solve_lean: the unsolved queries to the end); kernel_ms is the event-bracketed duration of a solve while %d solves "
                              "share the chip, so `frac` is per solve and `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
                              "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
                      "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
@@ -432,8 +454,12 @@ def main():
                                      "LDS-resident and the measured traffic is `roofline.traffic`"}},
         "results_identical_across_streams": identical,
     }
+    if latency3 is not None and world == 1:
+        out["latency_schedule_three_in_flight"] = {"value": latency3[0], "unit": "solves/s", "ms_per_step": latency3[1] * 1e3, "batches_in_flight": 3,
+                                                   "note": "BIOIK_SCHEDULE_LATENCY, three solves in flight: the protocol of `value` up to round 3's first profile"}
     if sequential is not None and world == 1:
         out["one_batch_at_a_time"] = {"value": n_success / sequential[0], "unit": "solves/s", "ms_per_step": sequential[0] * 1e3, "kernel_ms": sequential[1],
+                                      "schedule": "latency",
                                       "roofline_frac": alg_flops / (sequential[1] * 1e-3) / FP64_PEAK if sequential[1] > 0 else 0.0,
                                       "hbm_roofline_frac": alg_bytes / (sequential[1] * 1e-3) / HBM_PEAK if sequential[1] > 0 else 0.0}
 
@@ -470,7 +496,7 @@ def main():
         ts = []
         for _ in range(3):
             t1 = time.perf_counter()
-            hs = h.solve_batch(p, seeds, params)
+            hs = h.solve_batch(p_latency, seeds, params)  # (an isolated call: BIOIK_SCHEDULE_LATENCY)
             ts.append(time.perf_counter() - t1)
         out["host_pointer_entry"] = {"ms_per_call": min(ts) * 1e3, "solves_per_s": float(hs[2].sum()) / min(ts),
                                      "results_identical_to_device_entry": bool(np.array_equal(hs[0], sol) and np.array_equal(hs[2], suc)),
@@ -480,22 +506,24 @@ def main():
         # a stream of batches through the host-pointer boundary WITHOUT waiting for each: bioik_solve_batch_submit / _wait (what
         # searchPositionIKBatchAsync of the plugin calls), three solves of the handle in flight, PCIe transfers included
         host_in = [(seeds, params)] + [tuple(x.cpu().numpy() for x in inputs[k]) for k in range(1, len(inputs))]
-        kp = 18
+        kp = 24
         pending = []
         got_success = 0.0
-        for i in range(3):
+        npipe = 6 if args.schedule == "throughput" else 3
+        for i in range(npipe):
             h.wait_batch(h.submit_batch(p, *host_in[i % len(host_in)]))
         t1 = time.perf_counter()
         for i in range(kp):
             pending.append(h.submit_batch(p, *host_in[i % len(host_in)]))
-            if len(pending) == 3:
+            if len(pending) == npipe:
                 got_success += float(h.wait_batch(pending.pop(0))[2].sum())
         while pending:
             got_success += float(h.wait_batch(pending.pop(0))[2].sum())
         dtp = (time.perf_counter() - t1) / kp
-        out["host_pointer_pipelined"] = {"value": got_success / kp / dtp, "unit": "solves/s", "ms_per_step": dtp * 1e3, "batches_in_flight": 3,
+        out["host_pointer_pipelined"] = {"value": got_success / kp / dtp, "unit": "solves/s", "ms_per_step": dtp * 1e3, "batches_in_flight": npipe,
+                                         "schedule": args.schedule,
                                          "note": "bioik_solve_batch_submit / bioik_solve_batch_wait: host arrays in and out (page-locked staging, PCIe-inclusive), "
-                                                 "three solves of one handle in flight on the library's own streams; the rate a C++ caller of "
+                                                 "the solves of one handle in flight on the library's own streams; the rate a C++ caller of "
                                                  "searchPositionIKBatchAsync gets; never `value`"}
 
     if rank == 0 and world == 1 and not args.timed_only:

@@ -29,6 +29,8 @@ GOAL_PARAM_COUNT = {GOAL_POSITION: 3, GOAL_ORIENTATION: 4, GOAL_POSE: 8, GOAL_LO
 
 # ---- solver modes (IKFactory names, reference src/ik_evolution_2.cpp:652-654) ----
 MODE_BIO2, MODE_BIO2_MEMETIC, MODE_BIO2_MEMETIC_L, MODE_GD_C, MODE_JAC, MODE_GD, MODE_GD_R = 0, 1, 2, 3, 4, 5, 6
+SCHEDULE_LATENCY, SCHEDULE_THROUGHPUT = 0, 1
+SCHEDULE_BY_NAME = {"latency": SCHEDULE_LATENCY, "throughput": SCHEDULE_THROUGHPUT}
 MODE_BY_NAME = {"bio2": MODE_BIO2, "bio2_memetic": MODE_BIO2_MEMETIC, "bio2_memetic_l": MODE_BIO2_MEMETIC_L, "gd_c": MODE_GD_C, "jac": MODE_JAC, "gd": MODE_GD, "gd_r": MODE_GD_R}
 FK_LINEAR, FK_EXACT = 0, 1
 
@@ -59,7 +61,7 @@ class ProblemDesc(C.Structure):
 class SolveParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_int32), ("fk_mode", C.c_int32), ("population", C.c_int32),
                 ("islands", C.c_int32), ("max_steps", C.c_int32), ("random_seed", C.c_uint64), ("dpos", C.c_double),
-                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("reserved", C.c_int32), ("timeout", C.c_double)]
+                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("schedule", C.c_int32), ("timeout", C.c_double)]
 
 
 def default_solve_params(**kw):
@@ -76,10 +78,13 @@ def default_solve_params(**kw):
     p.drot = -1.0
     p.dtwist = 1e-5
     p.no_wipeout = 0
+    p.schedule = SCHEDULE_LATENCY
     p.timeout = 0.0
     for k, v in kw.items():
         if k == "mode" and isinstance(v, str):
             v = MODE_BY_NAME[v]
+        if k == "schedule" and isinstance(v, str):
+            v = SCHEDULE_BY_NAME[v]
         if not hasattr(p, k):
             raise TypeError("unknown solve parameter %r" % k)
         setattr(p, k, v)

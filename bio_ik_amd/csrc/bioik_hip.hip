@@ -192,7 +192,7 @@ struct bioik_problem {
     // handle are in flight together, the tail of one solve behind the bulk of the next.  Streams are created at a
     // slot's first use, not with the handle: HIP multiplexes streams onto four hardware queues per device, and a stream that a
     // device-pointer caller never uses would push one of the caller's own streams onto a shared queue.
-    static constexpr int kIoSlots = 3;
+    static constexpr int kIoSlots = 6;  // (three solves in flight fill the chip under BIOIK_SCHEDULE_LATENCY, six under BIOIK_SCHEDULE_THROUGHPUT)
     struct IoSlot {
         void* dev = nullptr;
         void* host = nullptr;
@@ -419,6 +419,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
             if (std::atoi(e) == 0) sp.child_pairs = 0;
     }
+    // BIOIK_SCHEDULE_THROUGHPUT: the whole solve under the mapping that retires most steps per ms on a full chip -- both species of a query on the
+    // halves of one wavefront, children computed where they are read and scored in pairs (the first launch's mapping of the two-launch solve
+    // below) -- for callers that keep six or more batches in flight (include/bioik_hip.h; profiles/r03_inflight_and_schedule.log)
+    const bool throughput = sp.schedule == BIOIK_SCHEDULE_THROUGHPUT && !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
+                            dp.n_secondary == 0;
+    if (throughput) nth = 64, sp.species_parallel = 1, sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 1;
     if (const char* e = std::getenv("BIOIK_SOLVE_COLUMNLESS"))
         if (std::atoi(e) != 0 && can_columnless) {
             sp.columnless = 1, sp.child_cols = 1;
@@ -502,7 +508,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
             c = *end == ',' ? end + 1 : end;
         }
-    } else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+    } else if (halves_ok && !manual && !throughput && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
         handovers.push_back(1);
     }
 #if defined(BIOIK_PHASE_TIMING)
@@ -704,9 +710,12 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
     be_h2d(dd, hd, in_bytes, st);
     DevSolveParams sp = bioik::normalize_params(params, first_query);
-    launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(dd + o_sol), (double*)(dd + o_fit), (int32_t*)(dd + o_suc),
-                 (int32_t*)(dd + o_steps), st);
-    be_d2h(hd + o_sol, dd + o_sol, total - in_bytes, st);
+    // The results go from the kernels straight into the page-locked arena (it is mapped into the device's address space; 1.5 MB per 4096 queries,
+    // written once per query).  A transfer out enqueued behind the solve would sit at the head of a DMA queue until the solve is over -- 12 ms
+    // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
+    // (profiles/r03_inflight_and_schedule.log, host pipeline).
+    launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
+                 (int32_t*)(hd + o_steps), st);
     sl.pending = true, sl.ticket = ticket, sl.n = n;
     sl.o_sol = o_sol, sl.o_fit = o_fit, sl.o_suc = o_suc, sl.o_steps = o_steps;
     sl.solutions = solutions, sl.fitness = fitness, sl.success = success, sl.steps = steps;

@@ -136,5 +136,6 @@ struct DevSolveParams {
     int32_t child_cols;         // genotype columns per lane: ceil(lambda / lanes) = every child of a generation stays in LDS
                                 // until selection; 1 = only the lane's current child (winners are re-derived from the RNG)
     int32_t species_parallel;   // 1: the workgroup splits into two lane groups, one species each, running concurrently
+    int32_t schedule;           // BIOIK_SCHEDULE_* (host side only: what the launcher optimises for)
     int32_t child_pairs;        // 1: a lane reproduces and scores its children two at a time (two independent dependency chains per lane)
 };

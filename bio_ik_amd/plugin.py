@@ -26,7 +26,7 @@ SHIM_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "lib
 
 
 class _Settings(C.Structure):  # bioik_plugin_settings (cpp/src/plugin_shim.cpp)
-    _fields_ = [("mode", C.c_char_p), ("gpu_fk", C.c_char_p), ("random_seed", C.c_int32), ("no_wipeout", C.c_int32),
+    _fields_ = [("mode", C.c_char_p), ("gpu_fk", C.c_char_p), ("gpu_schedule", C.c_char_p), ("random_seed", C.c_int32), ("no_wipeout", C.c_int32),
                 ("position_only_ik", C.c_int32), ("gpu_population", C.c_int32), ("gpu_islands", C.c_int32), ("gpu_max_steps", C.c_int32),
                 ("gpu_reproducible_calls", C.c_int32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)),
                 ("dpos", C.c_double), ("drot", C.c_double), ("dtwist", C.c_double), ("rotation_scale", C.c_double),
@@ -91,7 +91,7 @@ DEFAULT_PARAMS = {
     "rotation_scale": 0.5, "position_only_ik": False, "center_joints_weight": 0.0, "avoid_joint_limits_weight": 0.0,
     "minimal_displacement_weight": 0.0,
     # additive keys of the GPU build
-    "gpu_population": 128, "gpu_fk": "exact", "gpu_islands": 1, "gpu_max_steps": 64, "gpu_devices": None, "gpu_reproducible_calls": False,
+    "gpu_population": 128, "gpu_fk": "exact", "gpu_islands": 1, "gpu_max_steps": 64, "gpu_devices": None, "gpu_reproducible_calls": False, "gpu_schedule": "latency",
 }
 
 
@@ -121,7 +121,7 @@ class BioIKKinematicsPlugin:
     def _settings(self):
         p = self.params
         devices = np.asarray(p["gpu_devices"] or [0], dtype=np.int32)
-        s = _Settings(mode=str(p["mode"]).encode(), gpu_fk=str(p["gpu_fk"]).encode(), random_seed=int(p["random_seed"]),
+        s = _Settings(mode=str(p["mode"]).encode(), gpu_fk=str(p["gpu_fk"]).encode(), gpu_schedule=str(p["gpu_schedule"]).encode(), random_seed=int(p["random_seed"]),
                       no_wipeout=int(bool(p["no_wipeout"])), position_only_ik=int(bool(p["position_only_ik"])),
                       gpu_population=int(p["gpu_population"]), gpu_islands=int(p["gpu_islands"]), gpu_max_steps=int(p["gpu_max_steps"]),
                       gpu_reproducible_calls=int(bool(p["gpu_reproducible_calls"])), n_devices=len(devices), devices=abi.iptr(devices),

@@ -103,6 +103,17 @@ enum {
                                        before the next step (:165-170, :233-237); the best configuration seen is returned          */
 };
 
+/* What the launcher optimises a solve for.
+ * LATENCY (default): the time of THIS call.  A query gets the lanes that make its steps short (128: 96 us per step of the 7-joint arm), and a batch
+ *   that fills the chip runs its first step under the denser mapping below and hands the unsolved queries over.  Three such solves in flight
+ *   keep an MI355X busy.
+ * THROUGHPUT: solves per second of a STREAM of batches.  Both species of a query share one wavefront and the children are computed where they
+ *   are read: 27 % more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for up to 16 ms.  It pays
+ *   with six or more batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
+ *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call 60 % more time.  Problems the denser mapping does not exist for (secondary
+ *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      */
+enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1 };
+
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */
 enum {
     BIOIK_FK_LINEAR = 0, /* the reference's first-order extrapolation RobotFK_Mutator::computeApproximateMutations
@@ -175,7 +186,8 @@ typedef struct bioik_solve_params {
     uint64_t random_seed;    /* yaml "random_seed" (kinematics_plugin.cpp:256)                           */
     double dpos, drot, dtwist; /* yaml keys (kinematics_plugin.cpp:259-261); <0 or >=FLT_MAX disables   */
     int32_t no_wipeout;      /* debugging aid: disable species wipe-outs                                 */
-    int32_t reserved;
+    int32_t schedule;        /* BIOIK_SCHEDULE_*: what the launcher optimises for; new key "gpu_schedule".  The results do not
+                                depend on it (the lane mapping never changes a trajectory).                              */
     double timeout;          /* the caller's `timeout` of searchPositionIK [s] (kinematics_plugin.cpp:504, 574;
                                 ik_parallel.h:160 `ros::WallTime::now() < timeout`): wall-clock budget of ONE
                                 bioik_solve_batch* call, measured on the device from the moment the launch's first
@@ -236,10 +248,10 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
 /* The same solve without waiting for it — for a caller with a STREAM of batches, the batched counterpart of calling
  * IKParallel::solve() from several threads (reference src/ik_parallel.h:193-218 keeps its own worker threads busy the same way).
  * `submit` copies the inputs into a page-locked arena of the handle, enqueues transfer in / solve / transfer out on one of the
- * handle's THREE internal streams (tickets rotate over them) and returns a ticket; `wait` blocks until that solve is complete and
- * its results are in the arrays given to `submit`, which must stay valid until then.  Up to three solves of a handle are in flight
- * together: the slow tail of one (a few queries that use the whole step budget) runs behind the bulk of the next, which is worth
- * about a factor of two in solves per second on 4096-query batches.  Submitting a fourth solve first
+ * handle's SIX internal streams (tickets rotate over them) and returns a ticket; `wait` blocks until that solve is complete and
+ * its results are in the arrays given to `submit`, which must stay valid until then.  Up to six solves of a handle are in flight
+ * together (three fill the chip under BIOIK_SCHEDULE_LATENCY, six under BIOIK_SCHEDULE_THROUGHPUT): the slow tail of one (a few queries that use the whole step budget) runs behind the bulk of the next, which is worth
+ * about a factor of two in solves per second on 4096-query batches.  Submitting a seventh solve first
  * completes the oldest one (its results are delivered; its `wait` then returns at once).  Tickets may be waited for in any
  * order, from any thread; a ticket that is never waited for is completed by a later submit or by bioik_problem_destroy. */
 int bioik_solve_batch_submit(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds,

@@ -413,7 +413,7 @@ def test_solve_batch_multi_on_distinct_devices(gpus, templates):
 
 
 def test_submit_wait_pipelining_full_size(gpus, templates):
-    """bioik_solve_batch_submit / _wait: five 4096-query batches through the handle's three slots equal the synchronous solves bit for bit,
+    """bioik_solve_batch_submit / _wait: five 4096-query batches through the handle's slots equal the synchronous solves bit for bit,
     whatever the order of waiting; the pipelined sequence is not slower than the one-at-a-time sequence"""
     import time
     h, t = gpus["c2"], templates["c2"]
@@ -474,6 +474,17 @@ def test_joint_walk_of_both_species_children_full_size(gpus, oracles, templates,
     monkeypatch.setenv("BIOIK_SOLVE_NO_JOINT", "1")
     b = h.solve_batch(p, seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_throughput_schedule_changes_no_result(gpus, oracles, templates):
+    """bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT: a full-size batch solved in one launch with both species of a query on one
+    wavefront -- the oracle's trajectories, and the results of the default (latency) schedule bit for bit"""
+    h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
+    pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 6), schedule=abi.SCHEDULE_THROUGHPUT)
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 4096, seed=35)
+    a = h.solve_batch(abi.default_solve_params(population=128, max_steps=64, random_seed=2), seeds, params)
+    b = h.solve_batch(abi.default_solve_params(population=128, max_steps=64, random_seed=2, schedule="throughput"), seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[2].mean() > 0.99
 
 
 def test_sharded_batch_equals_whole_batch(gpus, templates):

@@ -309,23 +309,33 @@ def test_gradient_descent_and_jacobian_solvers(sims, oracles, templates, cfg):
 
 
 def test_submit_wait_pipelining(sims, templates):
-    """bioik_solve_batch_submit / _wait (host-simulated kernels): batches kept in flight on the handle's three slots return what the
-    synchronous call returns, in any order of waiting, and a fourth submit completes the oldest ticket by itself"""
+    """bioik_solve_batch_submit / _wait (host-simulated kernels): batches kept in flight on the handle's six slots return what the
+    synchronous call returns, in any order of waiting, and a seventh submit completes the oldest ticket by itself"""
     from bio_ik_amd.workload import make_queries
     h, t = sims["c2"], templates["c2"]
     p = abi.default_solve_params(population=16, max_steps=3, random_seed=5)
     batches = []
-    for k in range(5):
+    for k in range(8):
         seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=100 + k)
         batches.append((seeds, params, h.solve_batch(p, seeds, params)))
-    tickets = [h.submit_batch(p, b[0], b[1]) for b in batches]   # five submits on three slots: the first two complete on the way
-    for k in (4, 0, 2, 1, 3):
+    tickets = [h.submit_batch(p, b[0], b[1]) for b in batches]   # eight submits on six slots: the first two complete on the way
+    for k in (4, 0, 7, 2, 1, 6, 3, 5):
         sol, fit, suc, steps = h.wait_batch(tickets[k])
         ref = batches[k][2]
         assert np.array_equal(sol, ref[0]) and np.array_equal(fit, ref[1]) and np.array_equal(suc, ref[2]) and np.array_equal(steps, ref[3])
     h.wait_batch(tickets[0])  # waiting twice is harmless
     with pytest.raises(Exception):
         h.wait_batch((10 ** 6, None, None))
+
+
+def test_throughput_schedule_changes_no_result(sims, oracles, templates):
+    """bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT (the whole solve with both species of a query on one wavefront and computed
+    children): the oracle's trajectories, like every other lane mapping"""
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(1, 4), schedule=abi.SCHEDULE_THROUGHPUT)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=200, steps_list=(2,), schedule="throughput", islands=2)
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=128, steps_list=(2,), schedule=abi.SCHEDULE_THROUGHPUT)  # (no such mapping: as under LATENCY)
+    with pytest.raises(Exception):
+        sims["c2"].solve_batch(abi.default_solve_params(schedule=7), np.zeros((1, sims["c2"].V)), np.zeros((1, sims["c2"].P)))
 
 
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):

@@ -128,6 +128,30 @@ def test_factory_names_of_the_gradient_solvers(hostsim_shim, pr2):
             BioIKKinematicsPlugin(lib=hostsim_shim).initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"mode": mode})
 
 
+def test_gpu_schedule_key(hostsim_shim, pr2):
+    """gpu_schedule: "latency" (default) | "throughput" (bioik_solve_params::schedule); the answer does not depend on it, anything else is a
+    configuration error"""
+    rng = np.random.default_rng(4)
+    target = pr2.default_positions()
+    sols = []
+    for schedule in ("latency", "throughput"):
+        p = BioIKKinematicsPlugin(lib=hostsim_shim)
+        assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0,
+                            params={"gpu_schedule": schedule, "gpu_population": 128, "gpu_max_steps": 6, "random_seed": 2, "gpu_reproducible_calls": True})
+        if not sols:
+            gv = p._group_vars
+            target[gv] = random_configuration(pr2, rng)[gv]
+            pose = goal_in_base_frame(pr2, target)
+            seed = list(np.clip(target[gv] + 0.3 * rng.normal(size=len(gv)), np.asarray(pr2.var_min)[gv], np.asarray(pr2.var_max)[gv]))
+        sol = []
+        p.searchPositionIK([pose], seed, 0.0, sol, MoveItErrorCodes(), options=KinematicsQueryOptions(return_approximate_solution=True))
+        sols.append(sol)
+        p.close()
+    assert sols[0] == sols[1]
+    with pytest.raises(RuntimeError):
+        BioIKKinematicsPlugin(lib=hostsim_shim).initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"gpu_schedule": "fast"})
+
+
 def test_product_shim_exports():
     """libbio_ik_shim.so (linked against libbioik_hip.so) loads without a GPU and exports what plugin.py binds"""
     import subprocess, os
