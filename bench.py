@@ -40,8 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the six solves this bench keeps in flight want a queue
-# each (profiles/r03_inflight_and_schedule.log).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# each (eight suffice for them: profiles/r03_inflight_and_schedule.log), and so do the library's own six streams of the host-pointer leg, which
+# live in the same process: sixteen.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 BATCH = int(os.environ.get("BIOIK_BENCH_BATCH", "4096"))      # experiments only: the reported metric uses the defaults
 POP = int(os.environ.get("BIOIK_BENCH_POP", "128"))
