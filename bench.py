@@ -500,6 +500,8 @@ def main():
     if rank == 0 and world == 1 and not args.timed_only:
         # the host-pointer entry point (what the plugin calls): staging into page-locked memory, one DMA each way, the launch
         ts = []
+        for _ in range(6):  # (every IO slot of the handle once, untimed: its stream and its arenas are made at first use)
+            h.solve_batch(p_latency, seeds, params)
         for _ in range(3):
             t1 = time.perf_counter()
             hs = h.solve_batch(p_latency, seeds, params)  # (an isolated call: BIOIK_SCHEDULE_LATENCY)
