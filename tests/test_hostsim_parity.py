@@ -97,7 +97,7 @@ def test_preselection_with_computed_children_several_per_lane(sims, oracles, tem
     pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=pop, steps_list=(1,))
 
 
-@pytest.mark.parametrize("pop", [9, 70, 128, 333])
+@pytest.mark.parametrize("pop", [9, 70, 333])
 def test_joint_walk_of_both_species_children(sims, oracles, templates, monkeypatch, pop):
     """both species on the halves of one wavefront, secondary goals, children in pairs: the 64 lanes walk the random prefixes of BOTH species'
     pre-selected children as one list (solve_body<.., JOINT>, k_solve_lean_clj) and find each species' two best over the whole wavefront --
@@ -313,10 +313,10 @@ def test_submit_wait_pipelining(sims, templates):
     synchronous call returns, in any order of waiting, and a seventh submit completes the oldest ticket by itself"""
     from bio_ik_amd.workload import make_queries
     h, t = sims["c2"], templates["c2"]
-    p = abi.default_solve_params(population=16, max_steps=3, random_seed=5)
+    p = abi.default_solve_params(population=16, max_steps=2, random_seed=5)
     batches = []
     for k in range(8):
-        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=100 + k)
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 1 + k % 2, seed=100 + k)
         batches.append((seeds, params, h.solve_batch(p, seeds, params)))
     tickets = [h.submit_batch(p, b[0], b[1]) for b in batches]   # eight submits on six slots: the first two complete on the way
     for k in (4, 0, 7, 2, 1, 6, 3, 5):
