@@ -289,6 +289,25 @@ int main(int argc, char** argv) {
         }
         CHECK(threw);
         ros::set_param("mode", "bio2_memetic");
+        // gpu_schedule: "latency" | "throughput" (bioik_solve_params::schedule); the answer does not depend on it
+        ros::set_param("gpu_schedule", "fast");
+        threw = false;
+        try {
+            bad->initialize(*rm, "right_arm", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0);
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        CHECK(threw);
+        ros::set_param("gpu_schedule", "throughput");
+        ros::set_param("gpu_reproducible_calls", true);
+        std::vector<double> a, b;
+        CHECK(bad->initialize(*rm, "right_arm", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0));
+        CHECK(bad->searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, a, code));
+        ros::set_param("gpu_schedule", "latency");
+        CHECK(bad->initialize(*rm, "right_arm", "torso_lift_link", std::vector<std::string>{"r_wrist_roll_link"}, 0.0));
+        CHECK(bad->searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, b, code));
+        CHECK(a == b);
+        ros::set_param("gpu_reproducible_calls", false);
     }
     std::printf("ok\n");
     return 0;
