@@ -29,8 +29,8 @@ GOAL_PARAM_COUNT = {GOAL_POSITION: 3, GOAL_ORIENTATION: 4, GOAL_POSE: 8, GOAL_LO
 
 # ---- solver modes (IKFactory names, reference src/ik_evolution_2.cpp:652-654) ----
 MODE_BIO2, MODE_BIO2_MEMETIC, MODE_BIO2_MEMETIC_L, MODE_GD_C, MODE_JAC, MODE_GD, MODE_GD_R = 0, 1, 2, 3, 4, 5, 6
-SCHEDULE_LATENCY, SCHEDULE_THROUGHPUT = 0, 1
-SCHEDULE_BY_NAME = {"latency": SCHEDULE_LATENCY, "throughput": SCHEDULE_THROUGHPUT}
+SCHEDULE_LATENCY, SCHEDULE_THROUGHPUT, SCHEDULE_AUTO = 0, 1, 2
+SCHEDULE_BY_NAME = {"latency": SCHEDULE_LATENCY, "throughput": SCHEDULE_THROUGHPUT, "auto": SCHEDULE_AUTO}
 MODE_BY_NAME = {"bio2": MODE_BIO2, "bio2_memetic": MODE_BIO2_MEMETIC, "bio2_memetic_l": MODE_BIO2_MEMETIC_L, "gd_c": MODE_GD_C, "jac": MODE_JAC, "gd": MODE_GD, "gd_r": MODE_GD_R}
 FK_LINEAR, FK_EXACT = 0, 1
 

@@ -51,8 +51,9 @@ struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path rea
     bool no_wipeout = false;
     int gpu_population = 128, gpu_islands = 1, gpu_max_steps = 4096;
     std::string gpu_fk = "exact";
-    std::string gpu_schedule = "latency";  // "latency": every call as fast as it can be; "throughput": for callers that keep six or more batches in
-                                           // flight (searchPositionIKBatchAsync): +25 % solves per second, an isolated call 60 % slower (bioik_hip.h)
+    std::string gpu_schedule = "auto";     // "latency": every call as fast as it can be; "throughput": for callers that keep six or more batches in
+                                           // flight (searchPositionIKBatchAsync): +30 % solves per second, an isolated call a quarter slower; "auto":
+                                           // throughput for a batch submitted while two or more are in flight, else latency (bioik_hip.h)
     bool gpu_reproducible_calls = false;  // true: every call draws from the same random streams (query k of a call = stream k), so a repeated
                                           // call returns the same answer; false (default): the streams advance from call to call like the
                                           // reference's generator state, and a retry of a failed query explores differently
@@ -221,7 +222,8 @@ public:
         release();
         mv_ = mv, settings_ = s;
         solverMode(s.mode);  // (an unknown mode is a configuration error: throw here, as IKFactory::create does at load time)
-        if (s.gpu_schedule != "latency" && s.gpu_schedule != "throughput") throw std::runtime_error("bio_ik (MI355X): gpu_schedule must be 'latency' or 'throughput'");
+        if (s.gpu_schedule != "latency" && s.gpu_schedule != "throughput" && s.gpu_schedule != "auto")
+            throw std::runtime_error("bio_ik (MI355X): gpu_schedule must be 'latency', 'throughput' or 'auto'");
         if (settings_.devices.empty()) settings_.devices.push_back(0);
         for (int dev : settings_.devices) {
             bioik_model* m = nullptr;
@@ -278,7 +280,7 @@ public:
         const SolverMode sm = solverMode(settings_.mode);
         sp.mode = sm.mode;
         sp.fk_mode = settings_.gpu_fk == "linear" ? BIOIK_FK_LINEAR : BIOIK_FK_EXACT;
-        sp.schedule = settings_.gpu_schedule == "throughput" ? BIOIK_SCHEDULE_THROUGHPUT : BIOIK_SCHEDULE_LATENCY;
+        sp.schedule = settings_.gpu_schedule == "throughput" ? BIOIK_SCHEDULE_THROUGHPUT : (settings_.gpu_schedule == "auto" ? BIOIK_SCHEDULE_AUTO : BIOIK_SCHEDULE_LATENCY);
         sp.population = settings_.gpu_population, sp.islands = sm.threads > 1 ? sm.threads : settings_.gpu_islands, sp.max_steps = settings_.gpu_max_steps;
         sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
         sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;

@@ -209,7 +209,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         lookupParam("gpu_islands", p.gpu_islands, 1);
         lookupParam("gpu_max_steps", p.gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query
         lookupParam("gpu_fk", p.gpu_fk, std::string("exact"));  // "exact" | "linear" (the reference's linearised phenotypes)
-        lookupParam("gpu_schedule", p.gpu_schedule, std::string("latency"));  // "latency" | "throughput" (six or more batches in flight)
+        lookupParam("gpu_schedule", p.gpu_schedule, std::string("auto"));  // "auto" | "latency" | "throughput" (plugin_core.h: Settings)
         lookupParam("gpu_reproducible_calls", p.gpu_reproducible_calls, false);  // true: a repeated call replays the same random streams
         int gpu_device = 0;
         lookupParam("gpu_device", gpu_device, 0);

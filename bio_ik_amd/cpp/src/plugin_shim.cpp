@@ -81,7 +81,7 @@ static bio_ik::core::Settings coreSettings(const bioik_plugin_settings& s) {
     bio_ik::core::Settings c;
     c.mode = s.mode ? s.mode : "bio2_memetic";
     c.gpu_fk = s.gpu_fk ? s.gpu_fk : "exact";
-    c.gpu_schedule = s.gpu_schedule ? s.gpu_schedule : "latency";
+    c.gpu_schedule = s.gpu_schedule ? s.gpu_schedule : "auto";
     c.random_seed = s.random_seed, c.no_wipeout = s.no_wipeout != 0;
     c.dpos = s.dpos < 0 ? DBL_MAX : s.dpos, c.drot = s.drot < 0 ? DBL_MAX : s.drot, c.dtwist = s.dtwist;
     c.gpu_population = s.gpu_population, c.gpu_islands = s.gpu_islands, c.gpu_max_steps = s.gpu_max_steps;

@@ -576,7 +576,8 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
         o.timeout_ticks = ticks >= 9e18 ? (uint64_t)9e18 : (ticks < 1.0 ? 1ull : (uint64_t)ticks);
     }
     o.no_wipeout = p.no_wipeout;
-    if (p.schedule != BIOIK_SCHEDULE_LATENCY && p.schedule != BIOIK_SCHEDULE_THROUGHPUT) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown schedule");
+    if (p.schedule != BIOIK_SCHEDULE_LATENCY && p.schedule != BIOIK_SCHEDULE_THROUGHPUT && p.schedule != BIOIK_SCHEDULE_AUTO)
+        throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown schedule");
     o.schedule = p.schedule;
     o.generations = o.memetic ? 8 : 16;  // ik_evolution_2.cpp:349-351
     return o;

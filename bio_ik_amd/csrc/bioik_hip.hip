@@ -751,7 +751,13 @@ int bioik_solve_batch_submit(bioik_problem* p, const bioik_solve_params* params,
     const uint64_t t = p->next_ticket++;
     *ticket = t;
     if (n == 0) return BIOIK_OK;  // (nothing to do: waiting for this ticket returns at once)
-    io_begin(p, p->io[t % bioik_problem::kIoSlots], t, *params, p->first_query, n, seeds, goal_params, solutions, fitness, success, steps);
+    bioik_solve_params sp = *params;
+    if (sp.schedule == BIOIK_SCHEDULE_AUTO) {  // a pipeline three or more solves deep (this one and two before it) pays for the dense mapping (include/bioik_hip.h)
+        int in_flight = 0;
+        for (auto& sl : p->io) in_flight += (sl.pending && &sl != &p->io[t % bioik_problem::kIoSlots]) ? 1 : 0;
+        sp.schedule = in_flight >= 2 ? BIOIK_SCHEDULE_THROUGHPUT : BIOIK_SCHEDULE_LATENCY;
+    }
+    io_begin(p, p->io[t % bioik_problem::kIoSlots], t, sp, p->first_query, n, seeds, goal_params, solutions, fitness, success, steps);
     API_END
 }
 int bioik_solve_batch_wait(bioik_problem* p, uint64_t ticket) {

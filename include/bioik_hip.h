@@ -110,9 +110,12 @@ enum {
  * THROUGHPUT: solves per second of a STREAM of batches.  Both species of a query share one wavefront and the children are computed where they
  *   are read: 27 % more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for up to 16 ms.  It pays
  *   with six or more batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
- *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call 60 % more time.  Problems the denser mapping does not exist for (secondary
- *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      */
-enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1 };
+ *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call a quarter more time (12.6 against 10.3 ms for 4096 queries).  Problems the denser mapping does not exist for (secondary
+ *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      
+ * AUTO: LATENCY, except in bioik_solve_batch_submit when two or more solves of the handle are already in flight: THROUGHPUT then (a caller
+ *   that streams batches through the asynchronous entry gets the dense mapping once its pipeline is three deep: 8.4e5 against 8.0e5 solves/s
+ *   with three in flight, 0.94e6 with six; an isolated call stays as fast as it can be). */
+enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1, BIOIK_SCHEDULE_AUTO = 2 };
 
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */
 enum {

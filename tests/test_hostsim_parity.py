@@ -336,6 +336,16 @@ def test_throughput_schedule_changes_no_result(sims, oracles, templates):
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=128, steps_list=(2,), schedule=abi.SCHEDULE_THROUGHPUT)  # (no such mapping: as under LATENCY)
     with pytest.raises(Exception):
         sims["c2"].solve_batch(abi.default_solve_params(schedule=7), np.zeros((1, sims["c2"].V)), np.zeros((1, sims["c2"].P)))
+    # BIOIK_SCHEDULE_AUTO: the asynchronous entry turns to the dense mapping once two solves of the handle are in flight
+    from bio_ik_amd.workload import make_queries
+    h, t = sims["c2"], templates["c2"]
+    p = abi.default_solve_params(population=128, max_steps=2, random_seed=5, schedule="auto")
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 1, seed=300)
+    want = h.solve_batch(p, seeds, params)
+    tickets = [h.submit_batch(p, seeds, params) for _ in range(5)]
+    for tk in tickets:
+        got = h.wait_batch(tk)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
 
 
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):

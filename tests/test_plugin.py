@@ -129,12 +129,12 @@ def test_factory_names_of_the_gradient_solvers(hostsim_shim, pr2):
 
 
 def test_gpu_schedule_key(hostsim_shim, pr2):
-    """gpu_schedule: "latency" (default) | "throughput" (bioik_solve_params::schedule); the answer does not depend on it, anything else is a
-    configuration error"""
+    """gpu_schedule: "auto" (default) | "latency" | "throughput" (bioik_solve_params::schedule); the answer does not depend on it, anything else
+    is a configuration error"""
     rng = np.random.default_rng(4)
     target = pr2.default_positions()
     sols = []
-    for schedule in ("latency", "throughput"):
+    for schedule in ("latency", "throughput", "auto"):
         p = BioIKKinematicsPlugin(lib=hostsim_shim)
         assert p.initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], 0.0,
                             params={"gpu_schedule": schedule, "gpu_population": 128, "gpu_max_steps": 6, "random_seed": 2, "gpu_reproducible_calls": True})
@@ -147,7 +147,7 @@ def test_gpu_schedule_key(hostsim_shim, pr2):
         p.searchPositionIK([pose], seed, 0.0, sol, MoveItErrorCodes(), options=KinematicsQueryOptions(return_approximate_solution=True))
         sols.append(sol)
         p.close()
-    assert sols[0] == sols[1]
+    assert sols[0] == sols[1] == sols[2]
     with pytest.raises(RuntimeError):
         BioIKKinematicsPlugin(lib=hostsim_shim).initialize(pr2, "right_arm", "torso_lift_link", ["r_wrist_roll_link"], params={"gpu_schedule": "fast"})
 

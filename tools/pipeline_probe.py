@@ -16,7 +16,7 @@ from bio_ik_amd.workload import make_queries  # noqa: E402
 t = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
 h = HipSolver(t, device=0)
 batches = [make_queries(t, h.active_variables, h.fk_genes, 4096, seed=500 + k)[:2] for k in range(6)]
-for schedule in ("latency", "throughput"):
+for schedule in ("latency", "throughput", "auto"):
     p = abi.default_solve_params(population=128, max_steps=64, random_seed=1, schedule=schedule)
     for npipe in (1, 3, 6):
         for i in range(6):
