@@ -231,7 +231,7 @@ def main():
                          "bio_ik_amd.batch.solve_mixed); BIOIK_BENCH_C5_BATCH sets the global batch (default 262144)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "0")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other).  "
-                         "Default (0): six under the throughput schedule -- or five / four when that divides the K timed steps and six does not, so that "
+                         "Default (0): under the throughput schedule the first of eight / six / five / four that divides the K timed steps (else six), so that "
                          "every stream solves the same number of batches (K = 20: five; profiles/r03_inflight_and_schedule.log, short runs) --, three "
                          "under the latency schedule")
     ap.add_argument("--schedule", default=os.environ.get("BIOIK_BENCH_SCHEDULE", "throughput"), choices=["throughput", "latency"],
@@ -296,7 +296,7 @@ def main():
     # which the chip is nearly empty; with more launches in flight the next batches' bulk fills it.  Every step is a complete
     # pass of the hot path over one batch and every batch's results are complete when the timed region ends.
     if args.in_flight <= 0:
-        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (6, 5, 4) if args.steps % k == 0), 6)
+        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (8, 6, 5, 4) if args.steps % k == 0), 6)
     nfl = max(1, args.in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
     bufs = [(torch.empty((BATCH, V), dtype=torch.float64, device=dev), torch.empty(BATCH, dtype=torch.float64, device=dev),

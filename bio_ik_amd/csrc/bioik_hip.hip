@@ -121,6 +121,12 @@ __global__ void __launch_bounds__(256, 4) k_solve_lean_cl4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true>(a, blockIdx.x, lds);
 }
+// The computed-children kernel for BIOIK_SCHEDULE_THROUGHPUT: ONE wavefront per query (both species on its halves; the compiler knows it and drops the
+// barriers) under the register budget of four wavefronts per SIMD
+__global__ void __launch_bounds__(64, 4) k_solve_lean_cl64w4(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true, false, true>(a, blockIdx.x, lds);
+}
 // Computed children with both species of a query on the halves of one wavefront AND secondary goals: the children of the two species are walked
 // as one list over the 64 lanes (solve_body<.., JOINT>), so that the wavefront does not wait for the longer of two random prefixes (C3: +7 %,
 // profiles/r03_ab_joint_walk.log)
@@ -172,6 +178,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -479,6 +486,11 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                            !std::getenv("BIOIK_SOLVE_NO_JOINT");
         if (lean && args.sp.columnless && joint)
             LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean && args.sp.columnless && lanes == 64 && ((throughput && !std::getenv("BIOIK_SOLVE_THREE_WAVES")) || std::getenv("BIOIK_SOLVE_CL64W4")))
+            // the whole solve of a stream of batches under the dense mapping: sixteen queries per CU instead of twelve (+11 % with six solves in flight;
+            // 30 values -- the lane's best two across the chain walk, a few kernel-lifetime ones -- then live in scratch memory;
+            // profiles/r03_ab_dense_four_waves.log)
+            LAUNCH(k_solve_lean_cl64w4, (solve_body<true, true, false, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && four_waves)
             LAUNCH(k_solve_lean_cl4, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless)

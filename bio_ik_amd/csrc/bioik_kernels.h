@@ -305,7 +305,10 @@ struct SpeciesState {
 // prefix of its pre-selected children (ik_evolution_2.cpp:366-378), and with one half per species the wavefront waits for the longer of
 // the two prefixes (2/3 of the children on average, against 1/2).  In this instantiation the 64 lanes walk the children of BOTH species as
 // one list, and each species' two best are found by a reduction over the whole wavefront.
-template <bool LEAN, bool CL = false, bool JOINT = false>
+// SLIM: the instantiation for the 128-register budget of the dense mapping (one wavefront per query): the species record is read from LDS where a
+// generation begins and filed where it ends, so that nothing of it lives in registers -- or, under that budget, in scratch memory -- across the
+// chain walks (the record's reads are then LDS reads; a group is at most one wavefront there, so the hand-over needs no barrier)
+template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
@@ -485,10 +488,16 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 S.pf0 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb, 1}, qc, lm); });
                 S.pf1 = group_value(glead, gtid, s_bc, [&]() { return eval_linear_primary(pb, XV{cb + 2 * M, 1}, qc, lm); });
             }
+            if constexpr (SLIM) {
+                BIOIK_LANE_SCOPE;
+                if (gtid == 0) species_store(rank, S);
+                group_sync(G);
+            }
             for (int gen = 0; gen < sp.generations; gen++) {
                 BIOIK_LANE_SCOPE;
+                if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP;
                 const double* cb = popS + S.cur * BF;
-                const double *p0g = cb, *p0d = cb + M, *p1d = cb + 3 * M;
+                const double *p0g = cb, *p0d = cb + M, *p1d = cb + 3 * M;  // (pointers to const: re-derived after the walks under SLIM)
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
@@ -649,6 +658,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
+                if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP, cb = popS + S.cur * BF, p0g = cb, p0d = cb + M, p1d = cb + 3 * M;
                 if (!JOINT) top2_wave(b1f, b1p, b2f, b2p, G);  // (the joint walk has reduced over the whole wavefront already)
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
@@ -721,6 +731,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 S.cur ^= 1;
                 S.pf0 = first.f;
                 S.pf1 = second.f;
+                if constexpr (SLIM)
+                    if (gtid == 0) species_store(rank, S);
                 PHASE_MARK(PH_SEL_COPY);
                 group_sync(G);
                 PHASE_MARK(PH_SEL_BAR);
@@ -739,6 +751,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             //                    lanes; the candidate on all lanes alike (scalars of the line search are carried redundantly)
             // Hand-overs are LDS writes and reads of one wavefront in program order (p_wave_sync): no s_barrier inside the phase, so a
             // species stops as soon as a candidate is rejected, whatever the other species' wavefront is doing.
+            if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP;
             if (sp.memetic) {
                 BIOIK_LANE_SCOPE;
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place

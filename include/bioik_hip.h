@@ -108,8 +108,8 @@ enum {
  *   that fills the chip runs its first step under the denser mapping below and hands the unsolved queries over.  Three such solves in flight
  *   keep an MI355X busy.
  * THROUGHPUT: solves per second of a STREAM of batches.  Both species of a query share one wavefront and the children are computed where they
- *   are read: 27 % more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for up to 16 ms.  It pays
- *   with six or more batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
+ *   are read, sixteen queries per CU: a third more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for
+ *   up to 16 ms.  It pays with six to eight batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
  *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call a quarter more time (12.6 against 10.3 ms for 4096 queries).  Problems the denser mapping does not exist for (secondary
  *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      
  * AUTO: LATENCY, except in bioik_solve_batch_submit when two or more solves of the handle are already in flight: THROUGHPUT then (a caller

@@ -476,15 +476,19 @@ def test_joint_walk_of_both_species_children_full_size(gpus, oracles, templates,
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def test_throughput_schedule_changes_no_result(gpus, oracles, templates):
+def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeypatch):
     """bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT: a full-size batch solved in one launch with both species of a query on one
-    wavefront -- the oracle's trajectories, and the results of the default (latency) schedule bit for bit"""
+    wavefront (k_solve_lean_cl64w4: the 128-register build; BIOIK_SOLVE_THREE_WAVES: the 168-register one) -- the oracle's trajectories, and the
+    results of the default (latency) schedule bit for bit"""
     h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
     pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 6), schedule=abi.SCHEDULE_THROUGHPUT)
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 4096, seed=35)
     a = h.solve_batch(abi.default_solve_params(population=128, max_steps=64, random_seed=2), seeds, params)
     b = h.solve_batch(abi.default_solve_params(population=128, max_steps=64, random_seed=2, schedule="throughput"), seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[2].mean() > 0.99
+    monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+    c = h.solve_batch(abi.default_solve_params(population=128, max_steps=64, random_seed=2, schedule="throughput"), seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, c))
 
 
 def test_sharded_batch_equals_whole_batch(gpus, templates):
