@@ -443,13 +443,13 @@ def main():
         "max_rot_err_rad_of_successes": rot_err,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
-                     "kernel": "k_solve_lean_cl" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
+                     "kernel": "k_solve_lean_cl64w4" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
                      "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
                      "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
                      "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
                      "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
-                             "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl (both "
+                             "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl64w4 (both "
                              "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY two (k_solve_lean_cl: the first step of every query, "
                              "k_solve_lean: the unsolved queries to the end); kernel_ms is the event-bracketed duration of a solve while %d solves "
                              "share the chip, so `frac` is per solve and `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "

@@ -28,7 +28,7 @@ summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format
            "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
                                     "total_corrected": 2 * fk * 1024 + wk * 1024,
                                     "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "
-                                            "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; the rest is scratch traffic (register spills of cold paths)."}}
+                                            "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; under BIOIK_SCHEDULE_THROUGHPUT the rest is the scratch traffic of the dense kernel's 128-register build (30 spilled values, written through to HBM and read back from L2; its 168-register build moves 3.9 MB), under BIOIK_SCHEDULE_LATENCY the hand-over state of the two-launch solve (13 MB in all)."}}
 json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_sources_hash: the figure is valid for the kernel sources it was measured on, and bench.py checks that)
