@@ -117,9 +117,10 @@ __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_
 // only pays where the LDS footprint lets the fourth wavefront be resident AND the generation loops dominate a step: the launcher
 // picks it when a CU holds at least 16 wavefronts of the problem and a lane walks eight or more children per generation (the
 // 31-joint, 512-children configuration: +12 %; the first launch of a 7-joint, 128-children solve: -2 %; profiles/r03_ab_four_waves.log).
+// (solve_body<.., SLIM>: the species record is read from LDS per generation instead of living in scratch memory across the chain walks: 67 -> 31 spilled values)
 __global__ void __launch_bounds__(256, 4) k_solve_lean_cl4(SolveArgs a) {
     extern __shared__ double lds[];
-    solve_body<true, true>(a, blockIdx.x, lds);
+    solve_body<true, true, false, true>(a, blockIdx.x, lds);
 }
 // The computed-children kernel for BIOIK_SCHEDULE_THROUGHPUT: ONE wavefront per query (both species on its halves; the compiler knows it and drops the
 // barriers) under the register budget of four wavefronts per SIMD
@@ -492,7 +493,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             // profiles/r03_ab_dense_four_waves.log)
             LAUNCH(k_solve_lean_cl64w4, (solve_body<true, true, false, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && four_waves)
-            LAUNCH(k_solve_lean_cl4, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+            LAUNCH(k_solve_lean_cl4, (solve_body<true, true, false, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless)
             LAUNCH(k_solve_lean_cl, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean)

@@ -305,9 +305,10 @@ struct SpeciesState {
 // prefix of its pre-selected children (ik_evolution_2.cpp:366-378), and with one half per species the wavefront waits for the longer of
 // the two prefixes (2/3 of the children on average, against 1/2).  In this instantiation the 64 lanes walk the children of BOTH species as
 // one list, and each species' two best are found by a reduction over the whole wavefront.
-// SLIM: the instantiation for the 128-register budget of the dense mapping (one wavefront per query): the species record is read from LDS where a
-// generation begins and filed where it ends, so that nothing of it lives in registers -- or, under that budget, in scratch memory -- across the
-// chain walks (the record's reads are then LDS reads; a group is at most one wavefront there, so the hand-over needs no barrier)
+// SLIM: the instantiation for the 128-register budget (four wavefronts per SIMD): the species record is read from LDS where a generation begins
+// and filed where it ends, so that nothing of it lives in registers -- or, under that budget, in scratch memory -- across the chain walks (the
+// record's reads are then LDS reads; a species group is one wavefront or half of one in the mappings that run under this budget, so the
+// hand-over is a wavefront-level rendezvous, not a barrier)
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     uint64_t unit = unit_in;
