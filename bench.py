@@ -6,10 +6,11 @@ right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), 
 `value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
 GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
-Consecutive steps are issued round-robin on six HIP streams (`--in-flight`, config.batches_in_flight) under
+Consecutive steps are issued round-robin on six to ten HIP streams (`--in-flight`, config.batches_in_flight: by default the largest of ten, eight, six,
+five, four that divides the number of timed steps) under
 bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT (`--schedule`): the library's mapping for streams of batches (both species of a query on
 one wavefront: 27 % more steps per ms on a full chip, a step 2.5 x as long), under which the tail of one launch — a handful of queries that
-use the whole step budget, 64 sequential steps wherever they start — lasts ~16 ms and six solves in flight (on six hardware queues:
+use the whole step budget, 64 sequential steps wherever they start — lasts ~16 ms and six or more solves in flight (a hardware queue each:
 GPU_MAX_HW_QUEUES) keep the chip full (profiles/r03_inflight_and_schedule.log).  The same workload under BIOIK_SCHEDULE_LATENCY — the default of
 the library, what an isolated call wants — is on the line as `latency_schedule_three_in_flight` (the protocol of `value` in earlier rounds)
 and `one_batch_at_a_time` (strictly one solve after the other).  A step of this bench is one call of `bioik_solve_batch_device`.
@@ -231,8 +232,8 @@ def main():
                          "bio_ik_amd.batch.solve_mixed); BIOIK_BENCH_C5_BATCH sets the global batch (default 262144)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "0")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other).  "
-                         "Default (0): under the throughput schedule the first of eight / six / five / four that divides the K timed steps (else six), so that "
-                         "every stream solves the same number of batches (K = 20: five; profiles/r03_inflight_and_schedule.log, short runs) --, three "
+                         "Default (0): under the throughput schedule the first of ten / eight / six / five / four that divides the K timed steps (else six), so that "
+                         "every stream solves the same number of batches (K = 20 and K = 60: ten; profiles/r03_inflight_and_schedule.log, short runs) --, three "
                          "under the latency schedule")
     ap.add_argument("--schedule", default=os.environ.get("BIOIK_BENCH_SCHEDULE", "throughput"), choices=["throughput", "latency"],
                     help="bioik_solve_params::schedule of the timed steps (include/bioik_hip.h): throughput = the mapping for streams of batches (six in "
@@ -296,7 +297,7 @@ def main():
     # which the chip is nearly empty; with more launches in flight the next batches' bulk fills it.  Every step is a complete
     # pass of the hot path over one batch and every batch's results are complete when the timed region ends.
     if args.in_flight <= 0:
-        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (8, 6, 5, 4) if args.steps % k == 0), 6)
+        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (10, 8, 6, 5, 4) if args.steps % k == 0), 6)
     nfl = max(1, args.in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
     bufs = [(torch.empty((BATCH, V), dtype=torch.float64, device=dev), torch.empty(BATCH, dtype=torch.float64, device=dev),
