@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 3, GPU session 37: dry run of the N = 2 control flow of bench.py on a one-GPU box (two ranks sharing the device, gloo for the barrier and the reductions)
-O=gpurun_out/s37; mkdir -p $O
+# round 3, GPU session 50 (the same as 37, with the automatic ten solves in flight): dry run of the N = 2 control flow of bench.py on a one-GPU box (two ranks sharing the device, gloo for the barrier and the reductions)
+O=gpurun_out/s50; mkdir -p $O
 export TMPDIR=/tmp
 BIOIK_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_two_ranks.json 2> $O/bench_two_ranks.err
 echo rc=$?
