@@ -23,7 +23,8 @@ Extra objects on the JSON line:
                bytes per generation per species per query vs 8 TB/s): the fused kernel keeps the population in LDS, so those bytes
                are notional and `traffic` (measured, profiles/) is far below them.
   configs      the other single-GPU configurations of BASELINE.json (c3: PR2 `all`, two tips + MinimalDisplacement; c4: 31-DOF snake,
-               pop=512 + AvoidJointLimits) at 4096 queries per launch: solves/s, success, ms per batch, their own roofline figures.
+               pop=512 + AvoidJointLimits) at 4096 queries per launch, six timed launches per stream (`batches_timed`): solves/s, success, ms per
+               batch, their own roofline figures.
   cpu_baseline the reference's own CPU code (oracle/_ref: the reference sources compiled unmodified, Release flags) when the
                prebuilt library is present, else the oracle port; timed on this host, rank 0, N=1 only, one thread, on a
                bounded sample of the same queries.  The port at the GPU run's own parameters is reported beside it.
@@ -40,10 +41,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the six solves this bench keeps in flight want a queue
-# each (eight suffice for them: profiles/r03_inflight_and_schedule.log), and so do the library's own six streams of the host-pointer leg, which
-# live in the same process: sixteen.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the (up to) ten solves this bench keeps in flight want a
+# queue each (profiles/r03_inflight_and_schedule.log), and so do the library's own six streams of the host-pointer leg, which live in the same
+# process: with sixteen queues for those seventeen streams the host-pointer pipeline shared queues and ran at 7.3e5 instead of 9.0e5 (session 58 in
+# the same log): twenty-four.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 BATCH = int(os.environ.get("BIOIK_BENCH_BATCH", "4096"))      # experiments only: the reported metric uses the defaults
 POP = int(os.environ.get("BIOIK_BENCH_POP", "128"))
@@ -117,7 +119,7 @@ def other_configs(dev, nfl, streams, cpu_baseline=False):
             inputs.append((torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)))
         bufs = [(torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
                  torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(nfl)]
-        reps = max(reps, nfl)
+        reps = max(reps, nfl) * int(os.environ.get("BIOIK_BENCH_CONFIG_ROUNDS", "6"))  # timed launches: six per stream, what the headline's default K = 60 over ten streams gives (one per stream = start of the first to end of the last launch, no steady state: 5 % less; profiles/r03_c34_launches_per_stream.log)
         dt, kernel_ms = _timed_device_solves(h, p, n, inputs, bufs, streams, reps)
         share = [len(range(k, reps, nfl)) for k in range(nfl)]
         suc_mean = sum(float(o[2].double().mean().item()) * share[k] for k, o in enumerate(bufs)) / reps  # over the timed launches
@@ -130,7 +132,7 @@ def other_configs(dev, nfl, streams, cpu_baseline=False):
         flops = evaluations * flops_per_evaluation(n_moving, n_rev, n_pose)
         b_gen = 8 * (pop * (3 * h.D + 1) + 8 * h.D)
         res[name] = {"value": float(suc.sum()) / dt, "evaluations_note": "a generation walks pop / 2 children on average (random prefix of the pre-selection)", "unit": "solves/s", "ms_per_step": dt * 1e3, "success_rate": float(suc.mean()), "mean_steps_per_solve": float(steps.mean()),
-                     "batch": n, "population": pop, "max_steps": max_steps, "D": h.D, "tips": h.T, "batches_in_flight": nfl, "kernel_ms": kernel_ms,
+                     "batch": n, "population": pop, "max_steps": max_steps, "D": h.D, "tips": h.T, "batches_in_flight": nfl, "batches_timed": reps, "kernel_ms": kernel_ms,
                      "roofline": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                                   "frac": flops / (kernel_ms * 1e-3) / FP64_PEAK, "chip_level_frac": flops / dt / FP64_PEAK,
                                   "hbm_notional_frac": gens * b_gen / (kernel_ms * 1e-3) / HBM_PEAK}}
@@ -329,6 +331,13 @@ def main():
 
     stagger_ms = float(os.environ.get("BIOIK_BENCH_STAGGER_MS", "0"))
 
+    def open_streams():
+        # set-up, not a step: the first solve on a HIP stream creates its hardware queue and the queue's scratch memory (tens of ms on some boxes:
+        # profiles/r03_inflight_and_schedule.log, session 55).  With W < streams that would fall into the timed region.
+        for i in range(nfl):
+            step(i)
+        barrier()
+
     def timed(n_steps, n_warm):
         for i in range(n_warm):
             step(i)
@@ -345,6 +354,7 @@ def main():
         el = time.perf_counter() - t0
         return el, (float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else 0.0)
 
+    open_streams()
     elapsed, kernel_ms = timed(args.steps, args.warmup)
     d_sol, d_fit, d_suc, d_steps = bufs[0]
     # what the timed steps produced, per stream: successes and step() calls of the batch that stream solves, times its share of the steps
@@ -436,7 +446,8 @@ def main():
         "data": "synthetic (one batch of queries per stream in flight: same recipe, different draws)",
         "config": {"workload": "PR2-like right_arm 7-DOF, batch of 4096 independent PoseGoals per GPU, bio2_memetic pop=128, exact FK per individual",
                    "batch_per_gpu": BATCH, "population": POP, "max_steps": MAX_STEPS, "dtwist": 1e-5, "sharding": "queries split across ranks, no collective",
-                   "batches_in_flight": nfl, "schedule": args.schedule, "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                   "batches_in_flight": nfl, "schedule": args.schedule, "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "stream_setup": "one untimed solve per stream before the W warm-up steps (creates the stream's hardware queue and its scratch memory)"},
         "success_rate": succ_timed / max(args.steps * BATCH, 1),
         "mean_steps_per_solve": steps_per_launch / BATCH,
         "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
