@@ -65,3 +65,23 @@ if len(sf) == 2:
                        "a ratio near 1 = every gene byte crosses the HBM interface once, in full 512-byte wavefront segments"},
               open(os.path.join(p, rnd + "_pmc_k_stream_fitness.json"), "w"), indent=1)
     print("k_stream_fitness measured / algorithmic bytes: %.3f" % (meas / alg if alg else float("nan")))
+
+# The statistics file averages over EVERY launch of the profiled command (one per stream to open the streams, the warm-up, the timed steps);
+# the bench line's roofline.kernel_ms is the event-bracketed mean of the timed steps only.  The same mean from the kernel trace, next to the
+# figure the profiled process itself printed:
+tr = os.path.join(g, "prof_" + rnd, rnd + "_kernel_trace.csv")
+pl = os.path.join(g, "prof_bench.log")
+if os.path.exists(tr) and os.path.exists(pl):
+    line = json.loads([l for l in open(pl) if l.startswith("{")][-1])
+    kern, k_timed = line["roofline"]["kernel"], line["steps"]
+    rows = sorted((r for r in csv.DictReader(open(tr)) if r["Kernel_Name"].startswith(kern + "(")), key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
+    rec = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --timed-only", "kernel": kern, "launches": len(dur),
+           "mean_ms_all_launches (= %s_kernel_stats.csv AverageNs)" % rnd: sum(dur) / len(dur),
+           "timed_steps": k_timed, "mean_ms_of_the_timed_launches (the last %d of the trace)" % k_timed: sum(dur[-k_timed:]) / k_timed,
+           "roofline.kernel_ms printed by the profiled process (HIP events around the same launches)": line["roofline"]["kernel_ms"],
+           "value printed by the profiled process": line["value"], "batches_in_flight": line["config"]["batches_in_flight"],
+           "note": "launches overlap (batches_in_flight of them share the chip), so a launch lasts batches_in_flight x ms_per_step; the launches "
+                   "before the timed region start on an emptier chip and are shorter"}
+    json.dump(rec, open(os.path.join(p, rnd + "_kernel_stats_timed_region.json"), "w"), indent=1)
+    print("kernel trace: all %.2f ms, timed %.2f ms, events %.2f ms" % (sum(dur) / len(dur), sum(dur[-k_timed:]) / k_timed, line["roofline"]["kernel_ms"]))
