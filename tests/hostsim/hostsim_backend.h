@@ -1,9 +1,9 @@
 // hostsim_backend.h — TEST INFRASTRUCTURE (tests/hostsim): substitute for the HIP back end of bio_ik_amd/csrc/bioik_hip.hip.
-// "Device memory" is host memory and a launch runs every workgroup as a gang of OS threads (one per lane) that call the kernel body
+// "Device memory" is host memory and a launch runs every workgroup as a gang of fibres (one per lane) of the calling thread that call the kernel body
 // directly.  Injected with -DBIOIK_BACKEND_HEADER; never part of the product library.
-#include <barrier>
 #include <chrono>
-#include <thread>
+#include <functional>
+#include <ucontext.h>
 namespace sim {
 thread_local Block* blk = nullptr;
 thread_local int tid = 0;
@@ -28,24 +28,67 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy
 static void be_sync(stream_t) {}
 static stream_t be_stream_create() { return nullptr; }
 static void be_stream_destroy(stream_t) {}
+// One workgroup at a time; its lanes are fibres of the calling thread, scheduled round-robin: a lane runs until it waits at a rendezvous
+// (or ends), then the next unfinished lane continues.  sim::tid is the running lane.
+namespace sim {
+struct Fibres {
+    static constexpr size_t kStack = 2u << 20;  // per lane (the kernel bodies are one large inlined frame)
+    ucontext_t main;
+    std::vector<ucontext_t> ctx;
+    std::vector<char> done;
+    std::vector<std::unique_ptr<char[]>> stacks;  // kept across workgroups and launches
+    int n = 0, alive = 0;
+    std::function<void()> run;  // the kernel body of the running lane
+};
+static thread_local Fibres fib;
+static int next_unfinished(int me) {
+    int nx = me;
+    do nx = nx + 1 == fib.n ? 0 : nx + 1;
+    while (fib.done[nx] && nx != me);
+    return nx;
+}
+void yield() {
+    const int me = tid, nx = next_unfinished(me);
+    if (nx == me) return;
+    tid = nx;
+    swapcontext(&fib.ctx[me], &fib.ctx[nx]);  // (whoever resumes this lane has set tid back to it)
+}
+static void lane_main() {
+    fib.run();
+    const int me = tid;
+    fib.done[me] = 1;
+    if (--fib.alive == 0) setcontext(&fib.main);
+    tid = next_unfinished(me);
+    setcontext(&fib.ctx[tid]);
+}
+}  // namespace sim
 template <class Body>
 static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body body) {
     std::vector<double> lds(lds_bytes / 8 + 2);
+    sim::Fibres& f = sim::fib;
+    while ((int)f.stacks.size() < block) f.stacks.emplace_back(new char[sim::Fibres::kStack]);
     for (uint64_t b = 0; b < grid; b++) {
         sim::Block blk;
         blk.nthreads = block;
         blk.block_id = (int)b;
-        blk.bar.reset(new std::barrier<>(block));
-        for (int w = 0; w < block / 64; w++) blk.wave_bar.emplace_back(new std::barrier<>(64));
+        blk.bar.n = block;
+        blk.wave_bar.assign((size_t)(block / 64), sim::Rendezvous{64, 0, 0u});
         blk.xchg.assign((size_t)block, 0);
-        std::vector<std::thread> th;
-        for (int t = 0; t < block; t++)
-            th.emplace_back([&, t]() {
-                sim::blk = &blk;
-                sim::tid = t;
-                body(b, lds.data());
-            });
-        for (auto& t : th) t.join();
+        f.n = f.alive = block;
+        f.ctx.assign((size_t)block, ucontext_t());
+        f.done.assign((size_t)block, 0);
+        f.run = [&]() { body(b, lds.data()); };
+        for (int t = 0; t < block; t++) {
+            getcontext(&f.ctx[t]);
+            f.ctx[t].uc_stack.ss_sp = f.stacks[t].get();
+            f.ctx[t].uc_stack.ss_size = sim::Fibres::kStack;
+            f.ctx[t].uc_link = nullptr;
+            makecontext(&f.ctx[t], sim::lane_main, 0);
+        }
+        sim::blk = &blk;
+        sim::tid = 0;
+        swapcontext(&f.main, &f.ctx[0]);  // returns when the last lane has ended
+        sim::blk = nullptr;
     }
 }
 #define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args) be_launch(grid, block, lds, stream, [&](uint64_t b_, double* l_) { BODYCALL; })

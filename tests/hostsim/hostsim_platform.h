@@ -1,9 +1,9 @@
 // hostsim_platform.h — TEST INFRASTRUCTURE (tests/hostsim): substitute for the execution-model primitives of
-// bio_ik_amd/csrc/bioik_platform.h.  Every lane of a workgroup is an OS thread and the cross-lane primitives rendezvous on barriers,
-// so the kernel bodies of the product can be stepped against the CPU oracle on a machine without a GPU.  Injected with
+// bio_ik_amd/csrc/bioik_platform.h.  Every lane of a workgroup is a fibre (ucontext) of ONE OS thread and the cross-lane primitives
+// rendezvous on barriers that pass control to the next lane (a lane runs until it waits: 64 switches per rendezvous instead of 64 futex
+// wake-ups), so the kernel bodies of the product can be stepped against the CPU oracle on a machine without a GPU.  Injected with
 // -DBIOIK_PLATFORM_HEADER; never part of the product library.
 // ------------------------------------------------------------------------------------------------------------
-#include <barrier>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -16,11 +16,24 @@ typedef const DevProblem* ProbPtr;
 typedef const DevProblemLean* LeanProbPtr;
 
 namespace sim {
+struct Rendezvous {  // of `n` fibres of one OS thread
+    int n = 0, arrived = 0;
+    unsigned generation = 0;
+};
+void yield();  // to the next unfinished lane of the workgroup (hostsim_backend.h)
+inline void arrive_and_wait(Rendezvous& r) {
+    const unsigned g = r.generation;
+    if (++r.arrived == r.n) {
+        r.arrived = 0, r.generation++;
+        return;
+    }
+    while (r.generation == g) yield();
+}
 struct Block {
     int nthreads = 0;
     int block_id = 0;
-    std::unique_ptr<std::barrier<>> bar;
-    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    Rendezvous bar;
+    std::vector<Rendezvous> wave_bar;
     std::vector<uint64_t> xchg;  // [waves][64]
     char* lds = nullptr;
 };
@@ -30,8 +43,8 @@ extern thread_local int tid;
 
 BIOIK_DEV int p_tid() { return sim::tid; }
 BIOIK_DEV int p_nthreads() { return sim::blk->nthreads; }
-BIOIK_DEV void p_barrier() { sim::blk->bar->arrive_and_wait(); }
-BIOIK_DEV void p_wave_sync() { sim::blk->wave_bar[sim::tid >> 6]->arrive_and_wait(); }
+BIOIK_DEV void p_barrier() { sim::arrive_and_wait(sim::blk->bar); }
+BIOIK_DEV void p_wave_sync() { sim::arrive_and_wait(sim::blk->wave_bar[sim::tid >> 6]); }
 template <class T>
 BIOIK_DEV T p_shfl(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "");
@@ -40,9 +53,9 @@ BIOIK_DEV T p_shfl(T v, int src_lane) {
     std::memcpy(&bits, &v, sizeof(T));
     uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
     x[l] = bits;
-    sim::blk->wave_bar[w]->arrive_and_wait();
+    sim::arrive_and_wait(sim::blk->wave_bar[w]);
     uint64_t r = x[src_lane & 63];
-    sim::blk->wave_bar[w]->arrive_and_wait();
+    sim::arrive_and_wait(sim::blk->wave_bar[w]);
     T out;
     std::memcpy(&out, &r, sizeof(T));
     return out;
@@ -64,10 +77,10 @@ BIOIK_DEV unsigned long long p_ballot(bool pred) {  // every lane of the wavefro
     const int w = sim::tid >> 6, l = sim::tid & 63;
     uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
     x[l] = pred ? 1u : 0u;
-    sim::blk->wave_bar[w]->arrive_and_wait();
+    sim::arrive_and_wait(sim::blk->wave_bar[w]);
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) m |= (unsigned long long)x[i] << i;
-    sim::blk->wave_bar[w]->arrive_and_wait();
+    sim::arrive_and_wait(sim::blk->wave_bar[w]);
     return m;
 }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }

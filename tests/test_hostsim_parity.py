@@ -258,8 +258,8 @@ def test_solve_batch_multi_equals_single_handle(hostsim_lib, templates, sims):
     from bio_ik_amd.workload import make_queries
     h0 = sims["c2"]
     others = [HipSolver(t, lib=hostsim_lib) for _ in range(2)]
-    seeds, params, _ = make_queries(t, h0.active_variables, h0.fk_genes, 5, seed=31)
-    p = abi.default_solve_params(population=16, max_steps=2, random_seed=8)
+    seeds, params, _ = make_queries(t, h0.active_variables, h0.fk_genes, 7, seed=31)
+    p = abi.default_solve_params(population=16, max_steps=3, random_seed=8)
     for first in (0, 1000):
         h0.set_first_query(first)
         want = h0.solve_batch(p, seeds, params)
@@ -287,7 +287,7 @@ def test_balance_goal(hostsim_lib):
         assert h.T == o.T >= 10
         for mode in (0, 1):
             with pc.oracle_arithmetic(mode):
-                pc.function_level(h, o, m, np.random.default_rng(15), n=16, frame_tol=1e-12, fit_rtol=1e-10)
+                pc.function_level(h, o, m, np.random.default_rng(15), n=40, frame_tol=1e-12, fit_rtol=1e-10)
     t = ProblemTemplate(m, "body", [PoseGoal("a_tool"), BalanceGoal(weight=1.0)])
     h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
     with pc.oracle_arithmetic(0):
