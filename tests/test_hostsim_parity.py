@@ -1,4 +1,4 @@
-"""CPU-side parity of the KERNEL BODIES (bio_ik_amd/csrc built with -DBIOIK_HOSTSIM, every lane an OS thread) against
+"""CPU-side parity of the KERNEL BODIES (bio_ik_amd/csrc built with -DBIOIK_HOSTSIM, every lane a fibre of the calling thread) against
 the oracle.  Same source as the gfx950 kernels, so the solver logic (selection order, RNG contexts, memetic phase,
 species management, pre-selection by secondary goals, multi-wave reductions) is stepped against the reference
 restatement on a machine without a GPU.  The GPU suite (test_gpu_parity.py) repeats these cases through
