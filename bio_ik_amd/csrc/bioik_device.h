@@ -620,7 +620,7 @@ BIOIK_DEV double joint_value(const XA& x, int k, int mimic_src, double mimic_fac
 //              Needs n_chain_ops <= COOP (else the plain walk runs).
 template <int COOP = 0, class PB, class XA, class TipFn>
 BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, TipFn&& tip_fn, const double* prefix = nullptr) {
-    const int tid = p_tid(), nth = p_nthreads();
+    const int nth = p_nthreads();  // (the lane's own number: p_tid_fresh() where a parked frame is addressed -- rare, and nothing is carried through the walk for it)
     const int n_chain = pb->n_chain_ops;
     F7 f = f7_identity();
     for (int t = 0; t < pb->n_root_tips; t++) {
@@ -640,10 +640,11 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
     if constexpr (pb_flavour<PB>::general && std::is_same<XA, XV>::value) multi_joint_prologue(pb, x, slots);
     // COOP: this lane's joint, its value and half-angle trigonometry (computed for prismatic joints too and discarded: no branch)
     const bool coop = COOP > 0 && n_chain <= COOP;
-    const int coop_base = COOP > 0 ? ((tid & 63) & ~(COOP - 1)) : 0;  // first lane of this lane's group inside its wavefront
+    const int lane = COOP > 0 ? p_lane_fresh() : 0;  // (= tid & 63, computed here: the walk itself keeps no lane number alive)
+    const int coop_base = COOP > 0 ? (lane & ~(COOP - 1)) : 0;  // first lane of this lane's group inside its wavefront
     double my_xv = 0.0, my_sn = 0.0, my_cs = 1.0;
     if (coop) {
-        const int mine = (tid & 63) - coop_base, kk = mine < n_chain ? mine : n_chain - 1;
+        const int mine = lane - coop_base, kk = mine < n_chain ? mine : n_chain - 1;
         my_xv = joint_value(x, kk, pb->ops[kk].mimic_src, pb->ops[kk].mimic_factor, pb->ops[kk].mimic_offset);
         p_sincos(my_xv * 0.5, &my_sn, &my_cs);
     }
@@ -662,7 +663,7 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
         const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
         const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
         if (ls >= 0) {
-            const double* s = slots + (size_t)ls * 7 * nth + tid;
+            const double* s = slots + (size_t)ls * 7 * nth + p_tid_fresh();
             f = F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}};
         } else if (k > 0 && src < 0) {
             f = f7_identity();
@@ -678,7 +679,7 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
             f.q = qmul(f.q, Q4{ca0, ca1, ca2, ca3});
         }
         if (ss >= 0) {
-            double* sl = slots + (size_t)ss * 7 * nth + tid;
+            double* sl = slots + (size_t)ss * 7 * nth + p_tid_fresh();
             sl[0] = f.p.x;
             sl[(size_t)nth] = f.p.y;
             sl[(size_t)2 * nth] = f.p.z;
@@ -741,7 +742,7 @@ BIOIK_DEV double eval_exact_primary(PB pb, const XA& x, const QueryCtx& qc, doub
 // to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
 template <int N, class PB, class XA, class TipFn>
 BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
-    const int tid = p_tid(), nth = p_nthreads();
+    const int nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
     F7 f[N];
 #pragma unroll
@@ -785,6 +786,7 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
 #pragma unroll
         for (int j = 0; j < N; j++) xv[j] = joint_value(x[j], k, msrc, mf, mo);
         if (ls >= 0) {
+            const int tid = p_tid_fresh();
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 const double* s = slots + (size_t)j * slot_set_stride + (size_t)ls * 7 * nth + tid;
@@ -812,6 +814,7 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
             }
         }
         if (ss >= 0) {
+            const int tid = p_tid_fresh();
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 double* sl = slots + (size_t)j * slot_set_stride + (size_t)ss * 7 * nth + tid;
@@ -839,7 +842,9 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
         }
     }
 }
-template <int N, class PB, class XA>
+// LINKS_ONLY: the walk and the goals that read a tip; the caller adds nonlink_primary and balance_cost itself (the dense kernel: it re-derives
+// the children's accessors behind the walk instead of carrying them through it)
+template <int N, bool LINKS_ONLY = false, class PB, class XA>
 BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
                                     const double* prefix = nullptr) {
     V3 bal[N];
@@ -853,15 +858,20 @@ BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc,
         // the generation loop four registers -- three spilled values in the computed-children kernel, ten more under its 128-register budget.)
         const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
         for (int g = g0; g < g1; g++) {
-            const int type = pb->primary[g].type, var_op = pb->primary[g].var_op, var_seed = pb->primary[g].var_seed, po = pb->primary[g].param_off;
+            const int type = pb->primary[g].type, var_op = pb->primary[g].var_op, var_seed = pb->primary[g].var_seed;
+            // (p_fresh: the goal's numbers are read HERE, when a tip's frame is complete -- as a loop invariant the compiler reads them in front of the
+            // joint loop and carries up to sixteen registers of them through every joint of the walk)
+            const int po = p_fresh(pb->primary[g].param_off);
             const double w = pb->primary[g].weight_sq;
             const double* P = qc.par + po;
 #pragma unroll
             for (int j = 0; j < N; j++) out[j] += goal_eval<false, XA>(pb, type, var_op, var_seed, P, f[j], x[j], qc) * w;
         }
     }, prefix);
+    if constexpr (!LINKS_ONLY) {
 #pragma unroll
-    for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc), out[j] += balance_cost(pb, bal[j], qc);
+        for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc), out[j] += balance_cost(pb, bal[j], qc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1366,7 +1376,7 @@ BIOIK_DEV bool check_goal(ProbPtr pb, int g, const F7& fb, const XV& x, const Qu
     if (type == G_POSITION || type == G_ORIENTATION || type == G_POSE) {
         ok = check_frame_goal(type, (const lds_f64*)P, fb, dpos, drot, dtwist) != 0;
     } else {
-        double dmax = fmin(BIOIK_DBL_MAX, fmin(dpos, dtwist));
+        double dmax = fmin(BIOIK_DBL_MAX, fmin(p_fresh(dpos), dtwist));  // (p_fresh: computed here, not in front of the step loop and carried through it)
         double d = goal_eval(pb, type, pb->primary[g].var_op, pb->primary[g].var_seed, P, fb, x, qc) * pb->primary[g].weight_sq;
         ok = ok && (d < dmax * dmax);
     }

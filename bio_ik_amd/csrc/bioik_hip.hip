@@ -118,15 +118,17 @@ __global__ void __launch_bounds__(256, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_
 // picks it when a CU holds at least 16 wavefronts of the problem and a lane walks eight or more children per generation (the
 // 31-joint, 512-children configuration: +12 %; the first launch of a 7-joint, 128-children solve: -2 %; profiles/r03_ab_four_waves.log).
 // (solve_body<.., SLIM>: the species record is read from LDS per generation instead of living in scratch memory across the chain walks: 67 -> 31 spilled values)
-__global__ void __launch_bounds__(256, 4) k_solve_lean_cl4(SolveArgs a) {
+__global__ void __launch_bounds__(128, 4) k_solve_lean_cl4(SolveArgs a) {
     extern __shared__ double lds[];
-    solve_body<true, true, false, true>(a, blockIdx.x, lds);
+    solve_body<true, true, false, true, 2>(a, blockIdx.x, lds);
 }
 // The computed-children kernel for BIOIK_SCHEDULE_THROUGHPUT: ONE wavefront per query (both species on its halves; the compiler knows it and drops the
 // barriers) under the register budget of four wavefronts per SIMD
+// (solve_body<.., DENSE>: what the launcher guarantees for this kernel -- 64 lanes, the species on the halves of the wavefront, exact FK, children in
+// pairs, no secondary goal -- is known at compile time, and the fitness values of a generation cross its walks in LDS instead of in registers)
 __global__ void __launch_bounds__(64, 4) k_solve_lean_cl64w4(SolveArgs a) {
     extern __shared__ double lds[];
-    solve_body<true, true, false, true>(a, blockIdx.x, lds);
+    solve_body<true, true, false, true, 1>(a, blockIdx.x, lds);
 }
 // Computed children with both species of a query on the halves of one wavefront AND secondary goals: the children of the two species are walked
 // as one list over the 64 lanes (solve_body<.., JOINT>), so that the wavefront does not wait for the longer of two random prefixes (C3: +7 %,
@@ -244,12 +246,68 @@ static int fail(const std::exception& e) {
         return fail(e);              \
     }
 
+// ------------------------------------------------------------------------------------------------------------
+// Diagnostic switches (tools/README.md).  The environment is read ONCE, when the library is loaded, into this struct -- and again only when
+// a test or a probe asks for it (bioik_debug_reload_switches): nothing on the launch path touches the environment.
+// ------------------------------------------------------------------------------------------------------------
+struct SolveSwitches {
+    int threads = 0;            // BIOIK_SOLVE_THREADS: lanes per (query, island), 0 = the launcher's choice
+    int store_children = -1;    // BIOIK_SOLVE_STORE_CHILDREN (-1: not set)
+    int child_pairs = -1;       // BIOIK_SOLVE_CHILD_PAIRS
+    int species_parallel = -1;  // BIOIK_SOLVE_SPECIES_PARALLEL
+    int columnless = -1;        // BIOIK_SOLVE_COLUMNLESS (1: children computed where they are read, 2: ... and scored in pairs)
+    bool general = false, general_set = false;  // BIOIK_SOLVE_GENERAL
+    bool report = false;        // BIOIK_SOLVE_REPORT
+    bool three_waves = false, four_waves = false, no_joint = false;
+    bool two_phase_set = false, two_phase_init = false;
+    std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
+    std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
+    bool manual() const { return threads > 0 || store_children >= 0 || child_pairs >= 0 || species_parallel >= 0 || columnless >= 0; }
+};
+static SolveSwitches parse_switches() {
+    SolveSwitches w;
+    auto geti = [](const char* name, int unset) {
+        const char* e = std::getenv(name);
+        return e ? std::atoi(e) : unset;
+    };
+    w.threads = geti("BIOIK_SOLVE_THREADS", 0);
+    if (std::getenv("BIOIK_SOLVE_THREADS") && w.threads <= 0) w.threads = 64;
+    w.store_children = geti("BIOIK_SOLVE_STORE_CHILDREN", -1);
+    w.child_pairs = geti("BIOIK_SOLVE_CHILD_PAIRS", -1);
+    w.species_parallel = geti("BIOIK_SOLVE_SPECIES_PARALLEL", -1);
+    w.columnless = geti("BIOIK_SOLVE_COLUMNLESS", -1);
+    if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL")) w.general_set = true, w.general = std::atoi(e) != 0;
+    w.report = std::getenv("BIOIK_SOLVE_REPORT") != nullptr;
+    w.three_waves = std::getenv("BIOIK_SOLVE_THREE_WAVES") != nullptr;
+    w.four_waves = std::getenv("BIOIK_SOLVE_FOUR_WAVES") != nullptr;
+    w.no_joint = std::getenv("BIOIK_SOLVE_NO_JOINT") != nullptr;
+    if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
+        w.two_phase_set = true;
+        w.two_phase_init = std::strcmp(e, "init") == 0;
+        for (const char* c = e; *c && !w.two_phase_init;) {
+            char* end = nullptr;
+            const long k = std::strtol(c, &end, 10);
+            if (end == c) break;
+            w.two_phase.push_back(k);
+            c = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (const char* e = std::getenv("BIOIK_PHASE_DUMP")) w.phase_dump = e;
+    return w;
+}
+static std::mutex g_switch_mtx;
+static SolveSwitches g_switches = parse_switches();
+static SolveSwitches switches() {
+    std::lock_guard<std::mutex> lock(g_switch_mtx);
+    return g_switches;
+}
+
 // lanes per (query, island).  The two species run concurrently on two lane groups when the workgroup has >= 2 wavefronts;
 // each group gets one lane per child up to 128 lanes (pop=128 -> 256 lanes: 4 wavefronts on the 4 SIMDs of a CU).
-static int solve_threads(const DevSolveParams& sp, uint64_t units) {
+static int solve_threads(const DevSolveParams& sp, uint64_t units, const SolveSwitches& sw) {
     int t;
-    if (const char* e = std::getenv("BIOIK_SOLVE_THREADS")) {
-        t = std::atoi(e);
+    if (sw.threads > 0) {
+        t = sw.threads;
     } else {
         // one wavefront per species, two children per lane and trip at pop=128: every wavefront is busy in every phase; with
         // children evaluated in pairs this is also as fast per query as one lane per child (measured: 165 vs 161 us per
@@ -296,9 +354,9 @@ struct DevBuf {
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3  // register budget of k_solve: wavefronts per SIMD (its __launch_bounds__)
 #endif
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets).total * 8;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0).total * 8;
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
@@ -306,6 +364,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (n == 0) return;
     DevSolveParams sp = sp_in;
     const DevProblem& dp = p->host.dev;
+    const SolveSwitches sw = switches();  // (the diagnostic switches as last parsed: no environment access on the launch path)
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
@@ -357,14 +416,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
     // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
     // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
-    int nth = solve_threads(sp, units);
+    int nth = solve_threads(sp, units, sw);
     const bool exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
-    if (!std::getenv("BIOIK_SOLVE_THREADS") && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
+    if (sw.threads <= 0 && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
     const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
-    const bool manual = std::getenv("BIOIK_SOLVE_THREADS") || std::getenv("BIOIK_SOLVE_STORE_CHILDREN") || std::getenv("BIOIK_SOLVE_CHILD_PAIRS") ||
-                        std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL") || std::getenv("BIOIK_SOLVE_COLUMNLESS");
+    const bool manual = sw.manual();
     // children computed where they are read (no genotype columns in LDS): the lean flavour can, whenever it is chosen below
-    const bool can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !std::getenv("BIOIK_SOLVE_GENERAL");
+    const bool can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !sw.general_set;
     sp.columnless = 0;
     if (!manual && nth == 128) {
         struct Cand {
@@ -384,7 +442,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             if (c.pairs && !c.columnless && cols < 2) continue;
             // (computed children in pairs: measured +1.5 % with eight children per lane and generation (C4), -4 % with two (C3))
             if (c.pairs && c.columnless && sp.lambda < 4 * G_c) continue;
-            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact);
+            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact, c.columnless && exact);
             if (bytes > 160 * 1024) continue;
             int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
             if (waves > kCuWaves) waves = kCuWaves;
@@ -402,7 +460,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // pre-selection itself, selection, the memetic phase) weigh more; with both species of a query on the halves of ONE wavefront those
         // run once for the two.  Measured: C3 (128 children per species) +14 %, C4 (512: sixteen children per lane) -22 % (tools/c34_mapping_probe.sh).
         if (sp.columnless && dp.n_secondary > 0 && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
-            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact) * kCuWaves <= 160 * 1024) {
+            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact) * kCuWaves <= 160 * 1024) {
             nth = 64, sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1;
         }
     } else {
@@ -411,21 +469,20 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // (small populations, <= 32 children per species: +65..80 % measured, tools/halfwave_sweep.sh; at 64 and more children
         // per species the sequential single wavefront or the two-wavefront mapping is as good or better)
         sp.species_parallel = (nth % 128 == 0 || (nth == 64 && sp.lambda <= 32 && dp.D < 32)) ? 1 : 0;  // (the memetic phase wants lane D of a group)
-        if (const char* e = std::getenv("BIOIK_SOLVE_SPECIES_PARALLEL")) sp.species_parallel = (std::atoi(e) != 0 && (nth % 128 == 0 || (nth == 64 && dp.D < 32))) ? 1 : 0;
+        if (sw.species_parallel >= 0) sp.species_parallel = (sw.species_parallel != 0 && (nth % 128 == 0 || (nth == 64 && dp.D < 32))) ? 1 : 0;
         const int groups_m = sp.species_parallel ? 2 : 1, G_m = nth / groups_m;
         sp.child_cols = (sp.lambda + G_m - 1) / G_m;
         if (quat) {
             sp.child_cols = 1;
-        } else if (const char* e = std::getenv("BIOIK_SOLVE_STORE_CHILDREN")) {
-            if (std::atoi(e) == 0) sp.child_cols = 1;
+        } else if (sw.store_children >= 0) {
+            if (sw.store_children == 0) sp.child_cols = 1;
         } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 1, exact) > 48 * 1024) {
             sp.child_cols = 1;
         }
         // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
         // trees, a second set of parked frames
         sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2, exact) <= 64 * 1024) ? 1 : 0;
-        if (const char* e = std::getenv("BIOIK_SOLVE_CHILD_PAIRS"))
-            if (std::atoi(e) == 0) sp.child_pairs = 0;
+        if (sw.child_pairs == 0) sp.child_pairs = 0;
     }
     // BIOIK_SCHEDULE_THROUGHPUT: the whole solve under the mapping that retires most steps per ms on a full chip -- both species of a query on the
     // halves of one wavefront, children computed where they are read and scored in pairs (the first launch's mapping of the two-launch solve
@@ -433,15 +490,16 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const bool throughput = sp.schedule == BIOIK_SCHEDULE_THROUGHPUT && !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
                             dp.n_secondary == 0;
     if (throughput) nth = 64, sp.species_parallel = 1, sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 1;
-    if (const char* e = std::getenv("BIOIK_SOLVE_COLUMNLESS"))
-        if (std::atoi(e) != 0 && can_columnless) {
-            sp.columnless = 1, sp.child_cols = 1;
-            sp.child_pairs = (std::atoi(e) == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
-        }
+    // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
+    const bool dense = throughput && !sw.three_waves && dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
+    if (sw.columnless > 0 && can_columnless) {
+        sp.columnless = 1, sp.child_cols = 1;
+        sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
+    }
     const int groups = sp.species_parallel ? 2 : 1;
-    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact);
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
-    if (std::getenv("BIOIK_SOLVE_REPORT")) {  // diagnostics: the lane mapping and the residency it gives
+    if (sw.report) {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
                                         groups, sp.child_pairs ? 2 : 1);
         int n_rev = 0, n_pos = 0, n_rot = 0;  // revolute ops and how many of them the walk takes through a sparse form
@@ -455,8 +513,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     }
     if (lds > 64 * 1024) be_allow_lds(lds);
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
-    if (const char* e = std::getenv("BIOIK_SOLVE_GENERAL"))
-        if (std::atoi(e) != 0) lean = false;
+    if (sw.general_set && sw.general) lean = false;
     SolveArgs a;
     a.pb = p->pb();
     a.sp = sp;
@@ -470,7 +527,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     }
 #if defined(BIOIK_PHASE_TIMING)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
-    const char* phase_path = std::getenv("BIOIK_PHASE_DUMP");
+    const char* phase_path = sw.phase_dump.empty() ? nullptr : sw.phase_dump.c_str();
     if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
 #endif
     result_arrays(a);
@@ -478,22 +535,28 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
-        const bool four_waves = ((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !std::getenv("BIOIK_SOLVE_THREE_WAVES")) ||
-                                std::getenv("BIOIK_SOLVE_FOUR_WAVES");  // (diagnostic: the 128-register build wherever children are computed)
+        // (k_solve_lean_cl4 is compiled for exactly this mapping -- solve_body<.., FIXED = 2> --: 128 lanes, a wavefront per species, exact FK, children in pairs)
+        const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT;
+        const bool four_waves = cl4_mapping && (((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !sw.three_waves) ||
+                                                sw.four_waves);  // (diagnostic: the 128-register build wherever its mapping is the one in use)
         // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
         // (with a wavefront per species -- 128 lanes, C4 -- the same walk gains nothing: a wavefront that waits at a barrier costs no issue slots,
         // profiles/r03_ab_joint_walk.log)
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
-                           !std::getenv("BIOIK_SOLVE_NO_JOINT");
+                           !sw.no_joint;
+        if (sw.report)
+            std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
+                         !lean ? "k_solve" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : (lanes == 64 && dense) ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
         if (lean && args.sp.columnless && joint)
             LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
-        else if (lean && args.sp.columnless && lanes == 64 && ((throughput && !std::getenv("BIOIK_SOLVE_THREE_WAVES")) || std::getenv("BIOIK_SOLVE_CL64W4")))
+        else if (lean && args.sp.columnless && lanes == 64 && dense)
             // the whole solve of a stream of batches under the dense mapping: sixteen queries per CU instead of twelve (+11 % with six solves in flight;
             // 30 values -- the lane's best two across the chain walk, a few kernel-lifetime ones -- then live in scratch memory;
             // profiles/r03_ab_dense_four_waves.log)
-            LAUNCH(k_solve_lean_cl64w4, (solve_body<true, true, false, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+            LAUNCH(k_solve_lean_cl64w4, (solve_body<true, true, false, true, 1>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && four_waves)
-            LAUNCH(k_solve_lean_cl4, (solve_body<true, true, false, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
+            LAUNCH(k_solve_lean_cl4, (solve_body<true, true, false, true, 2>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless)
             LAUNCH(k_solve_lean_cl, (solve_body<true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean)
@@ -511,16 +574,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // mapping through it.
     std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
     const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
-    if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
-        const bool init_only = std::strcmp(e, "init") == 0;  // (experiment: the first launch only initialises)
-        if (init_only) handovers.push_back(0);
-        for (const char* c = e; *c && !init_only;) {
-            char* end = nullptr;
-            const long k = std::strtol(c, &end, 10);
-            if (end == c) break;
+    if (sw.two_phase_set) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
+        if (sw.two_phase_init) handovers.push_back(0);  // (experiment: the first launch only initialises)
+        for (const long k : sw.two_phase)
             if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
-            c = *end == ',' ? end + 1 : end;
-        }
     } else if (halves_ok && !manual && !throughput && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
         handovers.push_back(1);
     }
@@ -544,7 +601,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             if (j == 0 && halves_ok && !manual) {
                 lanes = 64;
                 aj.sp.species_parallel = 1, aj.sp.columnless = 1, aj.sp.child_cols = 1, aj.sp.child_pairs = 1;
-                lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact);
+                lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact);
                 if (lds_j > 64 * 1024) be_allow_lds(lds_j);
             }
             aj.carry = (double*)ws;
@@ -584,6 +641,12 @@ const char* bioik_last_error(void) { return g_err.c_str(); }
 int bioik_abi_version(void) { return BIOIK_ABI_VERSION; }
 int bioik_device_count(void) { return be_device_count(); }
 int bioik_goal_param_count(int goal_type) { return bioik::goal_param_count(goal_type); }
+int bioik_debug_reload_switches(void) {  // diagnostics only: the BIOIK_SOLVE_* switches are otherwise read once, when the library is loaded
+    SolveSwitches w = parse_switches();
+    std::lock_guard<std::mutex> lock(g_switch_mtx);
+    g_switches = std::move(w);
+    return BIOIK_OK;
+}
 
 void bioik_default_solve_params(bioik_solve_params* p) {
     if (!p) return;

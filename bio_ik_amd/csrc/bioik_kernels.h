@@ -25,9 +25,10 @@ struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species g
     int seed, par, pop, sol, prefix, state, clip, xcol, slots, g_first, g_stride, total;
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
     int xm, xp, dv, fc;  // memetic phase (per group): support points x -+ g, gene displacements [4][m], tip-frame components [4][T*8]
+    int fitp;            // fit_park: the children's fitness values of one generation [lambda], on the space of the memetic phase's vectors
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
-                               int groups = 1, int slot_sets = 1) {
+                               int groups = 1, int slot_sets = 1, int fit_park = 0) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -62,6 +63,10 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
         L.sec = 0, L.order = n_sec;
         if (n_sec + n_order > g) g = n_sec + n_order;
     }
+    // fit_park (exact-FK generations only, like has_secondary == 2): the fitness of every child of the running generation, written by the lane
+    // that scored it and read back by the same lane when the generation's walks are over -- so that no lane carries a best-two across them
+    L.fitp = 0;
+    if (fit_park && g < lambda) g = lambda;
     L.red = g, g += 4 * (nthreads / 64) + 4;
     L.bc = g, g += 4;  // values broadcast from the group's leading wavefront
     if (has_secondary != 2) {
@@ -224,13 +229,13 @@ BIOIK_NOINLINE void build_approximator(PB pb, XV x, double* slots, double* s_fra
     }
     for (int k = gtid; k < n_ops; k += G) s_base[k] = x(k);
     group_sync(G);
-    for (int idx = gtid; idx < T * n_ops; idx += G) {
-        int t = idx / n_ops, k = idx - t * n_ops;
-        double o[7];
-        approximator_entry(pb, t, k, s_frames, s_tips, o, s_base, prefix);
-        double* d = s_delta + ((size_t)t * n_ops + k) * 7;
-        for (int c = 0; c < 7; c++) d[c] = o[c];
-    }
+    for (int t = 0; t < T; t++)  // (no idx / n_ops: the reciprocal of a division by a uniform would be set up in front of the step loop and kept)
+        for (int k = gtid; k < n_ops; k += G) {
+            double o[7];
+            approximator_entry(pb, t, k, s_frames, s_tips, o, s_base, prefix);
+            double* d = s_delta + ((size_t)t * n_ops + k) * 7;
+            for (int c = 0; c < 7; c++) d[c] = o[c];
+        }
     group_sync(G);
 }
 
@@ -272,7 +277,7 @@ struct SpeciesState {
 // computes its LDS addresses where it uses them instead of inheriting them from in front of the step loop, where the compiler had
 // parked them in scratch memory (r02: 36 spilled VGPRs, every one of them an address of this kind).
 #define BIOIK_LANE_SCOPE                                                                                                            \
-    const int tid = p_fresh(tid0); /* (the one lane number kept across the phases; group and index inside it follow from it) */     \
+    const int tid = SLIM ? p_tid_fresh() : p_fresh(tid0); /* (the lane number, from a copy kept across the phases or (SLIM) computed afresh; group and index inside it follow from it) */ \
     const int grp = g_shift >= 0 ? tid >> g_shift : tid / G, gtid = tid - grp * G;                                                  \
     double* const gbase = lds + L.g_first + grp * L.g_stride; /* this group's scratch */                                            \
     double* const s_xn = gbase + L.xn;                                                                                              \
@@ -309,8 +314,14 @@ struct SpeciesState {
 // and filed where it ends, so that nothing of it lives in registers -- or, under that budget, in scratch memory -- across the chain walks (the
 // record's reads are then LDS reads; a species group is one wavefront or half of one in the mappings that run under this budget, so the
 // hand-over is a wavefront-level rendezvous, not a barrier)
-template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false>
+// FIXED: what the launcher guarantees for the two kernels under the 128-register budget is known at compile time (the runtime switches of the other
+// instantiations cost them registers and code):  1 = 64 lanes, the species on the halves of ONE wavefront, exact FK, children computed where they are
+// read and walked in pairs, no secondary goal (k_solve_lean_cl64w4);  2 = 128 lanes, a wavefront per species, exact FK, computed children in pairs,
+// secondary goals allowed (k_solve_lean_cl4)
+template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
+    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2;
+    static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
     static_assert(CL || !JOINT, "the joint walk of both species' children exists for computed children only");
@@ -322,22 +333,23 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
-    const int tid0 = p_tid(), nth = p_nthreads();
+    const int tid0 = p_tid(), nth = DENSE ? 64 : (WAVE2 ? 128 : p_nthreads());
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
-    const bool has_sec = pb->n_secondary > 0;
-    const bool exact = sp.fk_mode == FK_EXACT;
+    const bool has_sec = DENSE ? false : pb->n_secondary > 0;
+    const bool exact = FIXED ? true : sp.fk_mode == FK_EXACT;
+    const bool child_pairs = FIXED ? true : sp.child_pairs != 0;
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
     constexpr bool columnless = CL;
     // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
-    const int groups = sp.species_parallel ? 2 : 1;
-    const int G = nth / groups;        // lanes per species group (a multiple of 64)
-    const int g_shift = (G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1;  // the group sizes the launcher produces are powers of two: no integer division
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, sp.child_pairs ? 2 : 1);
+    const int groups = FIXED ? 2 : (sp.species_parallel ? 2 : 1);
+    const int G = DENSE ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
+    const int g_shift = DENSE ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -477,9 +489,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double final_fit = BIOIK_DBL_MAX;
     const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
     for (int step = a.step_begin; step < step_end; step++) {
-        const int rank_begin = groups == 2 ? (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
-        for (int rank = rank_begin; rank < rank_end; rank++) {
-            SpeciesState S = species_load(rank);
+        const int rank_begin = groups == 2 ? (SLIM ? 0 : (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G)) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
+        for (int rank_it = rank_begin; rank_it < rank_end; rank_it++) {
+            // (DENSE: a half-wavefront runs the species of its own number, read off the lane number wherever it is needed: no register carries it)
+            auto rank_now = [&]() { return (SLIM && groups == 2) ? (DENSE ? p_lane_fresh() >> 5 : (WAVE2 ? p_wave_index() : (g_shift >= 0 ? p_tid_fresh() >> g_shift : p_tid_fresh() / G))) : rank_it; };
+            SpeciesState S = species_load(rank_now());
             double* popS = s_pop + S.slot * SP;
             if (!exact) {
                 // :341-346 linearise at the elite; both elites are re-scored under the new linear model
@@ -491,12 +505,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             }
             if constexpr (SLIM) {
                 BIOIK_LANE_SCOPE;
-                if (gtid == 0) species_store(rank, S);
+                if (gtid == 0) species_store(rank_now(), S);
                 group_sync(G);
             }
             for (int gen = 0; gen < sp.generations; gen++) {
                 BIOIK_LANE_SCOPE;
-                if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP;
+                if constexpr (SLIM) S = species_load(rank_now()), popS = s_pop + S.slot * SP;
                 const double* cb = popS + S.cur * BF;
                 const double *p0g = cb, *p0d = cb + M, *p1d = cb + 3 * M;  // (pointers to const: re-derived after the walks under SLIM)
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
@@ -558,6 +572,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     uint32_t o0, o1;
                     philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
                     n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
+                    if constexpr (WAVE2) n_eval = p_uniform(n_eval);  // (a group is a whole wavefront: the count is the same in all its lanes, so it can live in a scalar register)
                     PHASE_MARK(PH_PRESELECT);
                 }
                 // genotype -> phenotype -> fitness (:391-407): lane r of the group scores the child at sorted position r
@@ -567,7 +582,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = !columnless && n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
-                if (!JOINT && stored && sp.child_pairs && exact) {
+                if (!JOINT && stored && child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
                     for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
                         const int r1 = r + G;
@@ -621,8 +636,51 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         top2_wave64_minima(t1f[1], t1p[1], t2f[1], t2p[1]);
                         b1f = grp ? t1f[1] : t1f[0], b1p = grp ? t1p[1] : t1p[0], b2f = grp ? t2f[1] : t2f[0], b2p = grp ? t2p[1] : t2p[0];
                     }
-                } else if (!JOINT && columnless && sp.child_pairs && exact) {
+                } else if (!JOINT && columnless && child_pairs && exact) {
                     // two children per trip, both computed where they are read: two independent dependency chains per lane
+                    if constexpr (SLIM) {
+                        // the fitness values go to LDS (fit_park) and come back when the walks are over: nothing but the lane number lives across a walk
+                        // (so the trip counter is uniform, and what follows a walk -- the goals that read no link, rarely present -- starts from the lane number again)
+                        for (int r0 = 0; r0 < n_eval; r0 += 2 * G) {
+                            double f[2];
+                            {
+                                BIOIK_LANE_SCOPE;
+                                const int r = r0 + gtid, r1 = r + G;
+                                const bool two = r1 < n_eval;
+                                const int ra = r < n_eval ? r : 0, rb = two ? r1 : ra;  // (a lane without a child in this trip walks a copy and drops it)
+                                const int c0 = has_sec ? s_order[ra] : ra, c1 = has_sec ? s_order[rb] : rb;
+                                const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);  // (= ctr1, from the record: the stream's hash is not carried over the walks)
+                                const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
+                                PHASE_MARK(PH_REPRODUCE);
+                                eval_exact_primary_n<2, true>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                            }
+                            BIOIK_LANE_SCOPE;
+                            const int r = r0 + gtid, r1 = r + G;
+                            const bool two = r1 < n_eval;
+                            if (pb->n_link_primary < pb->n_primary) {  // (primary goals over the joint values: the accessors are built again, nothing of them crossed the walk)
+                                const SpeciesState S2 = species_load(rank_now());
+                                const double* cb2 = s_pop + S2.slot * SP + S2.cur * BF;
+                                const uint32_t ctr2 = rng_ctr1(gctr, (uint32_t)S2.id, RNG_REPRODUCE);
+                                const int ra = r < n_eval ? r : 0, rb = two ? r1 : ra;
+                                const int c0 = has_sec ? s_order[ra] : ra, c1 = has_sec ? s_order[rb] : rb;
+                                const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr2, (uint32_t)c0 + 2u, cb2, cb2 + M, cb2 + 3 * M),
+                                                          make_child_x(pb, key, ctr2, (uint32_t)c1 + 2u, cb2, cb2 + M, cb2 + 3 * M)};
+                                f[0] += nonlink_primary(pb, cx[0], qc), f[1] += nonlink_primary(pb, cx[1], qc);
+                            } else {
+                                f[0] += 0.0, f[1] += 0.0;  // (nonlink_primary of no goal: the sum it returns)
+                            }
+                            f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc), f[1] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
+                            PHASE_MARK(PH_FITNESS);
+                            double* const s_fit = gbase + L.fitp;
+                            if (r < n_eval) s_fit[r] = f[0];
+                            if (two) s_fit[r1] = f[1];
+                        }
+                        {
+                            BIOIK_LANE_SCOPE;
+                            const double* const s_fit2 = gbase + L.fitp;
+                            for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);  // (its own entries: a lane's LDS accesses stay in program order)
+                        }
+                    } else
                     for (int r = gtid; r < n_eval; r += 2 * G) {
                         const int r1 = r + G;
                         const bool two = r1 < n_eval;
@@ -659,7 +717,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     }
                 }
                 // elitist top-2 selection (:410-431), including the tie order of the reference's selection sort
-                if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP, cb = popS + S.cur * BF, p0g = cb, p0d = cb + M, p1d = cb + 3 * M;
+                {  // (a lane scope of its own: nothing of the lane numbers in front of the walks is used behind them)
+                BIOIK_LANE_SCOPE;
+                if constexpr (SLIM) S = species_load(rank_now()), popS = s_pop + S.slot * SP, cb = popS + S.cur * BF, p0g = cb, p0d = cb + M, p1d = cb + 3 * M;
+                const uint32_t ctr1w = SLIM ? rng_ctr1((uint32_t)step * 16u + (uint32_t)gen, (uint32_t)S.id, RNG_REPRODUCE) : ctr1;  // (the winners' stream: not carried through the walks under SLIM)
                 if (!JOINT) top2_wave(b1f, b1p, b2f, b2p, G);  // (the joint walk has reduced over the whole wavefront already)
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
@@ -712,7 +773,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         // one lane doing all of them was 7 % of a C3 step)
                         BIOIK_FP_STRICT
                         const int c = has_sec ? s_order[id - 2] : id - 2;
-                        const ChildX<PB> cx = make_child_x(pb, key, ctr1, (uint32_t)c + 2u, p0g, p0d, p1d);
+                        const ChildX<PB> cx = make_child_x(pb, key, ctr1w, (uint32_t)c + 2u, p0g, p0d, p1d);
                         auto derive = [&](int k) {
                             const double gene = cx(k);
                             double mom = 0.0;
@@ -733,10 +794,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 S.pf0 = first.f;
                 S.pf1 = second.f;
                 if constexpr (SLIM)
-                    if (gtid == 0) species_store(rank, S);
+                    if (gtid == 0) species_store(rank_now(), S);
                 PHASE_MARK(PH_SEL_COPY);
                 group_sync(G);
                 PHASE_MARK(PH_SEL_BAR);
+                }
             }
 
             // memetic phase on the elite (:436-570): finite-difference gradient of the linearised fitness, L1 normalisation, three-point
@@ -752,7 +814,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             //                    lanes; the candidate on all lanes alike (scalars of the line search are carried redundantly)
             // Hand-overs are LDS writes and reads of one wavefront in program order (p_wave_sync): no s_barrier inside the phase, so a
             // species stops as soon as a candidate is rejected, whatever the other species' wavefront is doing.
-            if constexpr (SLIM) S = species_load(rank), popS = s_pop + S.slot * SP;
+            if constexpr (SLIM) S = species_load(rank_now()), popS = s_pop + S.slot * SP;
             if (sp.memetic) {
                 BIOIK_LANE_SCOPE;
                 double* el = popS + S.cur * BF;  // the elite's genes, edited in place
@@ -946,7 +1008,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             }
             {
                 BIOIK_LANE_SCOPE;
-                if (gtid == 0) species_store(rank, S);
+                if (gtid == 0) species_store(rank_now(), S);
             }
         }
         p_barrier();  // both species are ranked and their bookkeeping is in LDS

@@ -75,6 +75,21 @@ BIOIK_DEV int p_fresh(int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+BIOIK_DEV double p_fresh(double v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// The lane's number inside its wavefront, computed where it is asked for (v_mbcnt, two instructions) and never kept: for a workgroup that IS one
+// wavefront this is p_tid() without a register that lives as long as the kernel.
+BIOIK_DEV int p_lane_fresh() {
+    int v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v));
+    return v;
+}
+// p_tid() the same way: the wavefront's number inside the workgroup is uniform (a scalar register from the kernel's first instructions on), the lane's
+// number comes from v_mbcnt where it is needed -- the kernel then has no use for the vector register it received the thread index in.
+BIOIK_DEV int p_wave_index() { return p_uniform(p_tid() >> 6); }  // this wavefront's number inside its workgroup (a scalar register)
+BIOIK_DEV int p_tid_fresh() { return p_lane_fresh() + (p_wave_index() << 6); }
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock

@@ -27,7 +27,7 @@ EXPORTS = [
     "bioik_problem_active_variable_count", "bioik_problem_active_variables", "bioik_problem_tip_count", "bioik_problem_tip_links",
     "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch", "bioik_solve_batch_multi",
     "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
-    "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait",
+    "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait", "bioik_debug_reload_switches",
 ]
 
 
@@ -109,6 +109,20 @@ def load_library(path=None):
     return _lib
 
 
+_switch_snapshot = {}
+
+
+def sync_debug_switches(L):
+    """The library parses its BIOIK_SOLVE_* diagnostic switches once, when it is loaded.  Tests and probes that change them inside a
+    process (monkeypatch.setenv) get them re-read here, before a solve, when the environment differs from what library `L` last saw."""
+    snap = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("BIOIK_SOLVE_") or k == "BIOIK_PHASE_DUMP"))
+    key = id(L)
+    if _switch_snapshot.get(key, ()) != snap:
+        if hasattr(L, "bioik_debug_reload_switches"):
+            L.bioik_debug_reload_switches()
+        _switch_snapshot[key] = snap
+
+
 def device_count():
     return int(load_library().bioik_device_count())
 
@@ -183,6 +197,7 @@ class HipSolver:
     # ---- the hot path -------------------------------------------------------------------------------------
     def solve_batch(self, params, seeds, goal_params):
         """n independent queries: seeds [n][V], goal_params [n][P] -> (solutions [n][V], fitness, success, steps)."""
+        sync_debug_switches(self.L)
         s = _f64(seeds).reshape(-1, self.V)
         n = s.shape[0]
         gp = self._gp(goal_params, n)
@@ -196,6 +211,7 @@ class HipSolver:
     def submit_batch(self, params, seeds, goal_params):
         """bioik_solve_batch_submit: the same solve without waiting.  Returns a ticket object; `wait_batch(ticket)` returns what solve_batch
         returns.  Up to three batches of this handle are in flight together (the library rotates over three internal streams)."""
+        sync_debug_switches(self.L)
         s = _f64(seeds).reshape(-1, self.V)
         n = s.shape[0]
         gp = self._gp(goal_params, n)
@@ -211,6 +227,7 @@ class HipSolver:
     def solve_batch_multi(self, others, params, seeds, goal_params):
         """One batch over this handle and `others` (HipSolver objects of the same template, e.g. one per GPU): contiguous shards, one host
         thread and stream per handle inside the library (bioik_solve_batch_multi); equals solve_batch on one handle bit for bit."""
+        sync_debug_switches(self.L)
         s = _f64(seeds).reshape(-1, self.V)
         n = s.shape[0]
         gp = self._gp(goal_params, n)
@@ -224,6 +241,7 @@ class HipSolver:
 
     def solve_batch_device(self, params, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, stream=0):
         """All arguments are device pointers (ints) of arrays resident in HBM; enqueues on `stream`, does not synchronise."""
+        sync_debug_switches(self.L)
         self._chk(self.L.bioik_solve_batch_device(self.problem, C.byref(params), int(n), d_seeds, d_goal_params, d_solutions, d_fitness,
                                                   d_success, d_steps, stream))
 

@@ -209,6 +209,10 @@ const char* bioik_last_error(void);
 int bioik_abi_version(void);
 /* number of usable HIP devices (0 when none); never fails */
 int bioik_device_count(void);
+/* Diagnostics (no reference counterpart): the library reads its BIOIK_SOLVE_* / BIOIK_PHASE_DUMP switches (tools/README.md: forced lane mappings,
+ * hand-overs, the mapping report) from the environment ONCE, when it is loaded; this call reads them again.  The test-suite uses it to run every
+ * lane mapping in one process; nothing on the solve path touches the environment. */
+int bioik_debug_reload_switches(void);
 
 /* replaces RobotFK/RobotInfo construction from a RobotModel (ik_base.h:144-151) */
 int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out);

@@ -73,6 +73,10 @@ BIOIK_DEV int p_uniform(int v) { return v; }
 template <class T>
 BIOIK_DEV T p_read_lane(T v, int lane) { return p_shfl(v, lane); }
 BIOIK_DEV int p_fresh(int v) { return v; }
+BIOIK_DEV double p_fresh(double v) { return v; }
+BIOIK_DEV int p_lane_fresh() { return sim::tid & 63; }
+BIOIK_DEV int p_tid_fresh() { return sim::tid; }
+BIOIK_DEV int p_wave_index() { return sim::tid >> 6; }
 BIOIK_DEV unsigned long long p_ballot(bool pred) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)
     const int w = sim::tid >> 6, l = sim::tid & 63;
     uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;

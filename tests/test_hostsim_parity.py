@@ -348,6 +348,22 @@ def test_throughput_schedule_changes_no_result(sims, oracles, templates):
         assert all(np.array_equal(a, b) for a, b in zip(want, got))
 
 
+def test_kernels_compiled_for_one_mapping(sims, oracles, templates, monkeypatch):
+    """The two builds of the computed-children kernel for the 128-register budget know their lane mapping at compile time (solve_body<.., FIXED>):
+    k_solve_lean_cl4 = 128 lanes, a wavefront per species, children in pairs -- what the launcher picks for the 31-joint chain at 512 children, and,
+    forced (BIOIK_SOLVE_FOUR_WAVES), for any problem under that mapping, with and without a secondary goal, odd populations included;
+    k_solve_lean_cl64w4 = the throughput schedule's kernel (its own test above).  The oracle's trajectories bit for bit."""
+    pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=512, steps_list=(1, 2))  # (the launcher's own choice)
+    for k, v in {"BIOIK_SOLVE_THREADS": "128", "BIOIK_SOLVE_COLUMNLESS": "2", "BIOIK_SOLVE_FOUR_WAVES": "1"}.items():
+        monkeypatch.setenv(k, v)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(1, 3))
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=70, steps_list=(2,))
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=200, steps_list=(2,))
+    pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=33, steps_list=(2,), islands=2)
+    monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "1")  # ... and resumed from a hand-over
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
+
+
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):
     """joints without any range: every child of a generation is the same genotype, so every fitness of a generation is the same number and
     the elitist selection is decided by position alone (ik_evolution_2.cpp:410-431) -- the tie path of the wavefront-minimum top-2
