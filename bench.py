@@ -242,6 +242,18 @@ def main():
                          "flight), latency = the mapping for isolated calls (three in flight fill the chip); the one-at-a-time leg always runs under latency")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` by itself (no launcher around it): re-execute under torch.distributed.run, one rank per GPU of this node.  On a box
+    # with fewer GPUs than ranks the ranks share the devices over gloo (RCCL refuses two ranks on one device): a dry run of the N > 1 control flow,
+    # flagged as such on the JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     import numpy as np
     import torch
 
@@ -260,7 +272,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: bio_ik_amd has no CPU compute path")
     # one rank per GPU; BIOIK_BENCH_BACKEND=gloo lets several ranks share the GPUs of a smaller box (RCCL refuses two ranks on one
     # device): a dry run of the N>1 control flow, not a measurement
-    backend = os.environ.get("BIOIK_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("BIOIK_BENCH_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
     gpu = local_rank % torch.cuda.device_count()
     if world > 1:
         torch.cuda.set_device(gpu)
@@ -270,6 +282,7 @@ def main():
             dist.init_process_group(backend=backend)
     dev = torch.device("cuda", gpu)
     torch.cuda.set_device(dev)
+    group_world = dist.get_world_size() if world > 1 else 1  # read back from the process group (what RCCL / gloo actually formed)
 
     if args.config == "c5":
         return bench_c5(args, rank, world, gpu, dev)
@@ -398,10 +411,21 @@ def main():
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         total_success = float(ts.item())
 
-    # result-level check of what was timed: every success reproduces its goal pose under the device's own exact FK
+    # result-level check of what was timed: every success reproduces its goal pose -- under the ORACLE's exact FK in its reference-pinned arithmetic
+    # (mode 0: the reference's own unfused expressions + libm; the checker, outside every timed region), the device's own FK only where the oracle's
+    # library is not on the box
     sol = d_sol.cpu().numpy()
     ok_idx = np.nonzero(suc)[0][:256]
-    tips = np.stack([h.fk_genes(sol[i], sol[i][h.active_variables][None, :])[0] for i in ok_idx]) if len(ok_idx) else np.zeros((0, T, 7))
+    pose_check_by = "oracle FK, reference-pinned arithmetic (mode 0)"
+    try:
+        from oracle import orc as _orc
+        _o = _orc.Oracle(template)
+        if int(_orc.lib().orc_get_trig_mode()) != 0:
+            _orc.set_trig_mode(0)
+        tips = _o.fk(sol[ok_idx]) if len(ok_idx) else np.zeros((0, T, 7))
+    except Exception as e:
+        pose_check_by = "device FK (oracle unavailable: %r)" % e
+        tips = np.stack([h.fk_genes(sol[i], sol[i][h.active_variables][None, :])[0] for i in ok_idx]) if len(ok_idx) else np.zeros((0, T, 7))
     pos_err = float(np.linalg.norm(tips[:, 0, :3] - params[ok_idx, :3], axis=1).max()) if len(ok_idx) else 0.0
     rot_err = float((2.0 * np.arccos(np.minimum(1.0, np.abs(np.einsum("ij,ij->i", tips[:, 0, 3:], params[ok_idx, 3:7]))))).max()) if len(ok_idx) else 0.0
 
@@ -441,6 +465,8 @@ def main():
         "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        "process_group": {"backend": backend if world > 1 else None, "world_size": group_world, "devices_visible": torch.cuda.device_count(),
+                          "note": None if world <= 1 or torch.cuda.device_count() >= world else "fewer devices than ranks: the ranks share them (dry run of the N > 1 control flow, not a scaling figure)"},
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (one batch of queries per stream in flight: same recipe, different draws)",
@@ -453,6 +479,7 @@ def main():
         "child_evaluations_per_s": generations * POP * args.steps * world / elapsed if elapsed > 0 else 0.0,  # fitness evaluations of children (rank 0's count x ranks)
         "max_pos_err_m_of_successes": pos_err,
         "max_rot_err_rad_of_successes": rot_err,
+        "pose_check": pose_check_by,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
                      "kernel": "k_solve_lean_cl64w4" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
@@ -631,30 +658,53 @@ def main():
                   "port_same_parameters": port}
             # the reference's default of four island threads per query (ik_evolution_2.cpp:649) runs four CLONES of this island -- same
             # seed, same random tables, same trajectory (src/ik_parallel.h:141-145) -- so its solves/s per query stream is this one-thread
-            # figure; what more host cores buy is more queries at once: the same code, one solver object per thread, queries split over them
-            try:
+            # figure; what more host cores buy is more queries at once: the same code, one solver object per thread, the queries split over ALL
+            # host threads, every thread repeating its share until about two seconds of work are done
+            def query_parallel(flavour, nt, seconds=2.0):
                 import threading
-                nt = min(ncpu, 32)
-                refs = [r] + [ref.Reference(template, pr, release=True) for _ in range(nt - 1)]
+                refs = [ref.Reference(template, pr, release=flavour) for _ in range(nt)]
                 bounds = [(i * BATCH) // nt for i in range(nt + 1)]
-                got = [None] * nt
+                reps = max(1, int(seconds * cb["value"] * nt / BATCH * 0.6))  # (passes over the batch: the one-thread rate x threads, derated for shared caches)
+                got = [0.0] * nt
 
                 def work(i):
-                    got[i] = refs[i].solve_batch(seeds[bounds[i]:bounds[i + 1]], params[bounds[i]:bounds[i + 1]], 512)
+                    lo, hi = bounds[i], bounds[i + 1]
+                    if hi <= lo:
+                        return
+                    for _ in range(reps):
+                        got[i] += float(refs[i].solve_batch(seeds[lo:hi], params[lo:hi], 512)[2].sum())
                 for i in range(nt):
-                    refs[i].solve_batch(seeds[:2], params[:2], 512)
+                    refs[i].solve_batch(seeds[:1], params[:1], 8)
                 t1 = time.perf_counter()
                 th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
                 [t.start() for t in th]
                 [t.join() for t in th]
                 dtp = time.perf_counter() - t1
-                cb["query_parallel"] = {"value": float(sum(g[2].sum() for g in got)) / dtp, "cores": nt, "seconds": dtp,
-                                        "sample": "the same 4096 queries split over %d host threads, one reference solver object each" % nt}
+                return {"value": sum(got) / dtp, "cores": nt, "seconds": dtp, "passes_over_the_batch": reps,
+                        "sample": "the same 4096 queries split over %d host threads (all of them), one reference solver object each, %d passes" % (nt, reps)}
+            try:
+                cb["query_parallel"] = query_parallel(True, ncpu)
             except Exception as e:  # (the headline line must not depend on this leg)
                 cb["query_parallel"] = {"error": repr(e)}
+            # -march: the prebuilt reference library travels from the container that holds the reference tree to the box that times it, so
+            # "-march=native" is not available to it; its build for AVX2 + FMA hosts (-march=x86-64-v3, oracle/Makefile) is, where the host has them
+            try:
+                if ref.v3_available():
+                    r3 = ref.Reference(template, pr, release="v3")
+                    r3.solve_batch(seeds[:4], params[:4], 512)
+                    dts3 = []
+                    for _ in range(3):
+                        t1 = time.perf_counter()
+                        _, _, rsuc3, _ = r3.solve_batch(seeds, params, 512)
+                        dts3.append(time.perf_counter() - t1)
+                    cb["march_x86_64_v3"] = {"value": float(rsuc3.sum()) / float(np.median(dts3)), "cores": 1, "success_rate": float(rsuc3.mean()),
+                                             "flags": "the reference's Release flags + -march=x86-64-v3", "query_parallel": query_parallel("v3", ncpu)}
+                else:
+                    cb["march_x86_64_v3"] = {"note": "no AVX2 + FMA build of the reference library on this box, or the host lacks the flags"}
+            except Exception as e:
+                cb["march_x86_64_v3"] = {"error": repr(e)}
             cb["four_island_threads_note"] = ("reference default concurrency() = 4 island threads are identical clones (same RNG state): per-query "
-                                              "rate = the 1-thread figure; -march=native is not reported because the prebuilt reference library travels "
-                                              "between hosts of different micro-architectures")
+                                              "rate = the 1-thread figure")
         else:
             cb = dict(port)
             cb["host_cpus"] = ncpu

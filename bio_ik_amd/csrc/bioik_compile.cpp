@@ -523,6 +523,10 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         n_prefix++;
     if (n_prefix == n_chain) n_prefix = 0;  // nothing left to walk: no point
     dev.n_prefix = n_prefix;
+    dev.serial_chain = n_chain > 0 ? 1 : 0;
+    for (int k = 0; k < n_chain; k++)
+        if (ops[k].src != k - 1 || ops[k].load_slot >= 0 || ops[k].save_slot >= 0 || ops[k].mimic_src >= 0 || ops[k].type >= BIOIK_OP_FLOATING) dev.serial_chain = 0;
+    dev.reserved0 = 0;
     dev.genes_follow_ops = 1;
     for (int i = 1; i < D; i++)
         if (dev.op_of_gene[i] <= dev.op_of_gene[i - 1]) dev.genes_follow_ops = 0;

@@ -740,7 +740,10 @@ BIOIK_DEV double eval_exact_primary(PB pb, const XA& x, const QueryCtx& qc, doub
 // dependency chains, so that the scalar loads of a joint's constants, the LDS reads of the gene values and the latency of the
 // polynomial chains are paid once per joint instead of once per joint and child.  Arithmetic per individual is identical
 // to fk_walk.  Parked branch frames: child j uses the slot set at slots + j * slot_set_stride.
-template <int N, class PB, class XA, class TipFn>
+// SERIAL (DevProblem::serial_chain, the caller's promise): no op fetches or parks a branch frame, restarts at the root or mimics another joint -- the
+// loop body then has ONE definition of the running frames, and the compiler keeps them in the same registers from joint to joint (with the branch
+// paths in the body it copies all 14 N numbers between two sets of registers in every trip)
+template <int N, bool SERIAL = false, class PB, class XA, class TipFn>
 BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_stride, TipFn&& tip_fn, const double* prefix = nullptr) {
     const int nth = p_nthreads();
     const int n_chain = pb->n_chain_ops;
@@ -774,11 +777,11 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
     for (int k = k_begin; k < n_chain; k++) {
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
-        const int type = pb->ops[k].type, src = pb->ops[k].src, ls = pb->ops[k].load_slot, ss = pb->ops[k].save_slot;
+        const int type = pb->ops[k].type, src = SERIAL ? k - 1 : pb->ops[k].src, ls = SERIAL ? -1 : pb->ops[k].load_slot, ss = SERIAL ? -1 : pb->ops[k].save_slot;
         const int pk = pb->ops[k].pos_kind, rk = pb->ops[k].rot_kind;
         const int t0 = pb->ops[k].tip_first, t1 = t0 + pb->ops[k].tip_count;
-        const int msrc = pb->ops[k].mimic_src;
-        const double mf = pb->ops[k].mimic_factor, mo = pb->ops[k].mimic_offset;
+        const int msrc = SERIAL ? -1 : pb->ops[k].mimic_src;
+        const double mf = SERIAL ? 1.0 : pb->ops[k].mimic_factor, mo = SERIAL ? 0.0 : pb->ops[k].mimic_offset;
         const double ca0 = pb->ops[k].ca[0], ca1 = pb->ops[k].ca[1], ca2 = pb->ops[k].ca[2], ca3 = pb->ops[k].ca[3];
         const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
         const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
@@ -844,13 +847,13 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
 }
 // LINKS_ONLY: the walk and the goals that read a tip; the caller adds nonlink_primary and balance_cost itself (the dense kernel: it re-derives
 // the children's accessors behind the walk instead of carrying them through it)
-template <int N, bool LINKS_ONLY = false, class PB, class XA>
+template <int N, bool LINKS_ONLY = false, bool SERIAL = false, class PB, class XA>
 BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc, double* slots, int slot_set_stride, double (&out)[N],
                                     const double* prefix = nullptr) {
     V3 bal[N];
 #pragma unroll
     for (int j = 0; j < N; j++) out[j] = 0.0, bal[j] = v3(0.0, 0.0, 0.0);
-    fk_walk_n<N>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
+    fk_walk_n<N, SERIAL>(pb, x, slots, slot_set_stride, [&](int t, const F7 (&f)[N]) {
 #pragma unroll
         for (int j = 0; j < N; j++) balance_tip(pb, t, f[j], bal[j]);
         // the goals of the tip, each evaluated for the N individuals (per individual: the summation order of tip_goals).  (No one-PoseGoal
@@ -1225,7 +1228,11 @@ struct ChildX {
         double parent_gradient = d0 * (1.0 - fmix) + d1 * fmix;
         double g2 = parent_gradient * gradient_factor;
         gn += g2;
+#if defined(BIOIK_CLAMP_LIBRARY)
         gn = fmin(fmax(gn, cmin), cmax);
+#else
+        gn = p_clamp_uniform(gn, cmin, cmax);
+#endif
         return gn;
     }
 };

@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(256) k_eval_check(EvalArgs a) {
     extern __shared__ double lds[];
     eval_check_body(a, blockIdx.x, lds);
 }
+__global__ void __launch_bounds__(256) k_eval_arith(ArithArgs a) { arith_body(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void __launch_bounds__(256) k_stream_fitness(StreamArgs a) {
     extern __shared__ double lds[];
     stream_fitness_body(a, blockIdx.x, lds);
@@ -259,6 +260,7 @@ struct SolveSwitches {
     bool general = false, general_set = false;  // BIOIK_SOLVE_GENERAL
     bool report = false;        // BIOIK_SOLVE_REPORT
     bool three_waves = false, four_waves = false, no_joint = false;
+    int dense_handover = 0;     // BIOIK_SOLVE_DENSE_HANDOVER=K: a throughput solve hands the queries that pass K steps over to the latency mapping (0: never)
     bool two_phase_set = false, two_phase_init = false;
     std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
     std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
@@ -281,6 +283,7 @@ static SolveSwitches parse_switches() {
     w.three_waves = std::getenv("BIOIK_SOLVE_THREE_WAVES") != nullptr;
     w.four_waves = std::getenv("BIOIK_SOLVE_FOUR_WAVES") != nullptr;
     w.no_joint = std::getenv("BIOIK_SOLVE_NO_JOINT") != nullptr;
+    w.dense_handover = geti("BIOIK_SOLVE_DENSE_HANDOVER", 0);
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
         w.two_phase_init = std::strcmp(e, "init") == 0;
@@ -489,9 +492,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // below) -- for callers that keep six or more batches in flight (include/bioik_hip.h; profiles/r03_inflight_and_schedule.log)
     const bool throughput = sp.schedule == BIOIK_SCHEDULE_THROUGHPUT && !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
                             dp.n_secondary == 0;
-    if (throughput) nth = 64, sp.species_parallel = 1, sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 1;
+    // (nth / sp keep the LATENCY mapping: a throughput solve may hand its stragglers over to it, sw.dense_handover; its own launch takes the
+    // dense mapping where it is made, `halves` below)
     // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
-    const bool dense = throughput && !sw.three_waves && dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
+    const bool dense = throughput && !sw.three_waves && dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
     if (sw.columnless > 0 && can_columnless) {
         sp.columnless = 1, sp.child_cols = 1;
         sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
@@ -536,7 +540,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
         // (k_solve_lean_cl4 is compiled for exactly this mapping -- solve_body<.., FIXED = 2> --: 128 lanes, a wavefront per species, exact FK, children in pairs)
-        const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT;
+        const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT && dp.serial_chain != 0;
         const bool four_waves = cl4_mapping && (((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !sw.three_waves) ||
                                                 sw.four_waves);  // (diagnostic: the 128-register build wherever its mapping is the one in use)
         // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
@@ -544,13 +548,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // profiles/r03_ab_joint_walk.log)
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
                            !sw.no_joint;
+        const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
-                         !lean ? "k_solve" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : (lanes == 64 && dense) ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         !lean ? "k_solve" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
                          lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
         if (lean && args.sp.columnless && joint)
             LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
-        else if (lean && args.sp.columnless && lanes == 64 && dense)
+        else if (lean && args.sp.columnless && dense_launch)
             // the whole solve of a stream of batches under the dense mapping: sixteen queries per CU instead of twelve (+11 % with six solves in flight;
             // 30 values -- the lane's best two across the chain walk, a few kernel-lifetime ones -- then live in scratch memory;
             // profiles/r03_ab_dense_four_waves.log)
@@ -578,13 +583,30 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         if (sw.two_phase_init) handovers.push_back(0);  // (experiment: the first launch only initialises)
         for (const long k : sw.two_phase)
             if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
-    } else if (halves_ok && !manual && !throughput && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+    } else if (throughput) {
+        // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
+        if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
+    } else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
         handovers.push_back(1);
     }
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) handovers.clear();
 #endif
-    if (handovers.empty()) {
+    // the mapping with both species of a query on the halves of ONE wavefront, children computed where they are read and walked in pairs: the
+    // first launch of a solve in several launches, and the whole of a throughput solve
+    auto halves = [&](SolveArgs& aj, int& lanes, size_t& lds_j) {
+        lanes = 64;
+        aj.sp.species_parallel = 1, aj.sp.columnless = 1, aj.sp.child_cols = 1, aj.sp.child_pairs = 1;
+        lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact);
+        if (lds_j > 64 * 1024) be_allow_lds(lds_j);
+    };
+    if (handovers.empty() && throughput) {
+        SolveArgs a0 = a;
+        int lanes = nth;
+        size_t lds_0 = lds;
+        halves(a0, lanes, lds_0);
+        launch(a0, lanes, lds_0);
+    } else if (handovers.empty()) {
         launch(a, nth, lds);
     } else {
         const size_t nh = handovers.size();
@@ -598,12 +620,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             SolveArgs aj = a;
             int lanes = nth;
             size_t lds_j = lds;
-            if (j == 0 && halves_ok && !manual) {
-                lanes = 64;
-                aj.sp.species_parallel = 1, aj.sp.columnless = 1, aj.sp.child_cols = 1, aj.sp.child_pairs = 1;
-                lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact);
-                if (lds_j > 64 * 1024) be_allow_lds(lds_j);
-            }
+            if (j == 0 && halves_ok && !manual) halves(aj, lanes, lds_j);
             aj.carry = (double*)ws;
             if (j > 0) {
                 aj.step_begin = handovers[j - 1];
@@ -1014,6 +1031,28 @@ int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t 
     const int nth = 64;
     LAUNCH(k_eval_check, eval_check_body(a, b_, l_), (n + nth - 1) / nth, nth, lds_bytes(p, nth, 0), 0, a);
     be_d2h(ok, dok.p, n * 4, 0);
+    be_sync(0);
+    API_END
+}
+
+int bioik_eval_arith(int device, int op, size_t n, const double* in, double* out) {
+    API_BEGIN
+    const int ni = arith_in(op), no = arith_out(op);
+    if (ni == 0) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_eval_arith: unknown op");
+    if (n && (!in || !out)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
+    if (n == 0) return BIOIK_OK;
+    const int nd = be_device_count();
+    if (nd <= 0) throw Error(BIOIK_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
+    if (device < 0 || device >= nd) throw Error(BIOIK_ERR_NO_DEVICE, "HIP device index out of range");
+    DeviceGuard on_device(device);
+    DevBuf din(n * ni * 8), dout(n * no * 8);
+    be_h2d(din.p, in, n * ni * 8, 0);
+    ArithArgs a;
+    a.op = op, a.pad = 0, a.n = n, a.in = din.as<double>(), a.out = dout.as<double>();
+    const uint64_t grid = (n + 255) / 256;
+    if (grid > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many elements for one launch");
+    LAUNCH(k_eval_arith, arith_body(a, b_ * 256 + (uint64_t)p_tid()), grid, 256, 0, 0, a);
+    be_d2h(out, dout.p, n * no * 8, 0);
     be_sync(0);
     API_END
 }

@@ -652,7 +652,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);  // (= ctr1, from the record: the stream's hash is not carried over the walks)
                                 const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
                                 PHASE_MARK(PH_REPRODUCE);
-                                eval_exact_primary_n<2, true>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                                // (FIXED: the launcher hands these kernels serial chains only, DevProblem::serial_chain -- the usual robot arm: one chain, nothing parked)
+                                eval_exact_primary_n<2, true, FIXED != 0>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
                             }
                             BIOIK_LANE_SCOPE;
                             const int r = r0 + gtid, r1 = r + G;
@@ -737,10 +738,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // the winners become the elites (written to the species' other buffer)
                 // lanes 0..31 of the group write the first winner, lanes 32..63 the second, lane k its ops k, k + 32
                 double* nb = popS + (S.cur ^ 1) * BF;
-                for (int pass = 0; pass < (G >= 64 ? 1 : 2); pass++) {  // a half-wave group has 32 lanes: one winner per pass
+                // (a half-wave group has 32 lanes: sixteen per winner where the ops are no more than that, else one winner per pass)
+                const bool both_at_once = G >= 64 || M <= 16;
+                for (int pass = 0; pass < (both_at_once ? 1 : 2); pass++) {
                     BIOIK_LANE_SCOPE;
                     if (gtid >= 64) break;
-                    const int i = G >= 64 ? gtid >> 5 : pass, k0 = gtid & 31;
+                    const int i = G >= 64 ? gtid >> 5 : (both_at_once ? gtid >> 4 : pass), k0 = G >= 64 || !both_at_once ? gtid & 31 : gtid & 15;
                     const int id = i == 0 ? first.id : second.id;
                     double* dst = nb + i * 2 * M;
                     if (id < 2) {
@@ -1267,6 +1270,51 @@ BIOIK_DEV void eval_check_body(const EvalArgs& a, uint64_t block, double* lds) {
     FitCheck fc = exact_fitness_check(pb, XV{xcol, nth}, qc, lds + L.slots, a.dpos, a.drot, a.dtwist, 1);
     a.outi[i] = fc.ok;
     if (a.out0) a.out0[i] = fc.fitness;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The shared arithmetic headers one function at a time (bioik_sincos.h, bioik_fused.h): what the kernels AND the CPU checker's "device arithmetic"
+// mode both include is evaluated here on the device for arbitrary arguments, so that a test can hold it against an independent high-precision
+// reference (tests/test_arith_headers.py) -- bit parity between two users of one header cannot show a defect of the header itself.
+// ---------------------------------------------------------------------------------------------------------
+enum { ARITH_SINCOS = 0, ARITH_QROT = 1, ARITH_QMUL = 2, ARITH_DOT3 = 3, ARITH_DOT4 = 4, ARITH_REVOLUTE = 5 };
+struct ArithArgs {
+    int32_t op, pad;
+    uint64_t n;
+    const double* in;  // [n][arith_in(op)]
+    double* out;       // [n][arith_out(op)]
+};
+BIOIK_HD int arith_in(int op) { return op == ARITH_SINCOS ? 1 : op == ARITH_QROT ? 7 : op == ARITH_QMUL ? 8 : op == ARITH_DOT3 ? 6 : op == ARITH_DOT4 ? 8 : op == ARITH_REVOLUTE ? 22 : 0; }
+BIOIK_HD int arith_out(int op) { return op == ARITH_SINCOS ? 2 : op == ARITH_QROT ? 3 : op == ARITH_QMUL ? 4 : op == ARITH_DOT3 ? 1 : op == ARITH_DOT4 ? 1 : op == ARITH_REVOLUTE ? 14 : 0; }
+BIOIK_DEV void arith_body(const ArithArgs& a, uint64_t i) {
+    if (i >= a.n) return;
+    const double* x = a.in + i * (uint64_t)arith_in(a.op);
+    double* o = a.out + i * (uint64_t)arith_out(a.op);
+    if (a.op == ARITH_SINCOS) {
+        p_sincos(x[0], &o[0], &o[1]);
+    } else if (a.op == ARITH_QROT) {
+        const V3 r = qrot(Q4{x[0], x[1], x[2], x[3]}, v3(x[4], x[5], x[6]));
+        o[0] = r.x, o[1] = r.y, o[2] = r.z;
+    } else if (a.op == ARITH_QMUL) {
+        const Q4 r = qmul(Q4{x[0], x[1], x[2], x[3]}, Q4{x[4], x[5], x[6], x[7]});
+        o[0] = r.x, o[1] = r.y, o[2] = r.z, o[3] = r.w;
+    } else if (a.op == ARITH_DOT3) {
+        o[0] = dot3(v3(x[0], x[1], x[2]), v3(x[3], x[4], x[5]));
+    } else if (a.op == ARITH_DOT4) {
+        o[0] = qdot(Q4{x[0], x[1], x[2], x[3]}, Q4{x[4], x[5], x[6], x[7]});
+    } else if (a.op == ARITH_REVOLUTE) {
+        // one revolute joint applied to a frame: in = frame[7], half angle, cpos[3], ca[4], cb[4], pos_kind, rot_kind, (pad); out = the general form's
+        // frame [7], then the frame of the sparse form named by (pos_kind, rot_kind) [7] -- equal wherever the struck-out constants are exact zeros
+        F7 g[1] = {f7_load(x)}, sp[1] = {f7_load(x)};
+        double sn[1], cs[1];
+        p_sincos(x[7], &sn[0], &cs[0]);
+        const RevConst kg{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15], x[16], x[17], x[18], BIOIK_POS_GENERAL, BIOIK_ROT_GENERAL};
+        const RevConst ks{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15], x[16], x[17], x[18], (int)x[19], (int)x[20]};
+        revolute_apply<1>(g, sn, cs, kg);
+        revolute_apply<1>(sp, sn, cs, ks);
+        f7_store(o, g[0]);
+        f7_store(o + 7, sp[0]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -90,6 +90,15 @@ BIOIK_DEV int p_lane_fresh() {
 // number comes from v_mbcnt where it is needed -- the kernel then has no use for the vector register it received the thread index in.
 BIOIK_DEV int p_wave_index() { return p_uniform(p_tid() >> 6); }  // this wavefront's number inside its workgroup (a scalar register)
 BIOIK_DEV int p_tid_fresh() { return p_lane_fresh() + (p_wave_index() << 6); }
+// fmin(fmax(x, lo), hi) for wavefront-uniform bounds: the two instructions themselves.  Written with the library functions, the compiler first
+// passes each bound through a v_max_f64 of its own (it cannot know that a number loaded from memory is no signalling NaN): four instructions per
+// clipped gene instead of two.  Same instruction, same operands: the same bits for every x and every pair of bounds that are numbers.
+BIOIK_DEV double p_clamp_uniform(double x, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "s"(hi));
+    return r;
+}
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock

@@ -101,6 +101,9 @@ struct DevProblem {
     int32_t pose_only;       // 1: the primary fitness is primary[0].weight_sq * PoseGoal cost of tip 0, and there is no secondary / balance goal
     int32_t pose_param_off;  // primary[0].param_off
     double pose_weight_sq;   // primary[0].weight_sq
+    int32_t serial_chain;    // 1: ops[0..n_chain_ops) are ONE serial chain -- every op continues the frame of the op in front of it, none fetches or parks
+                             //    a branch frame, none is a mimic joint: the walk of the dense kernels then carries its frames in place
+    int32_t reserved0;
     uint64_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
     double multi_c[7];     // constant frame in front of the floating / planar joint
     int32_t quat_op[4];    // op index of the first of the four orientation value ops

@@ -27,7 +27,7 @@ EXPORTS = [
     "bioik_problem_active_variable_count", "bioik_problem_active_variables", "bioik_problem_tip_count", "bioik_problem_tip_links",
     "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch", "bioik_solve_batch_multi",
     "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
-    "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait", "bioik_debug_reload_switches",
+    "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait", "bioik_debug_reload_switches", "bioik_eval_arith",
 ]
 
 
@@ -63,6 +63,8 @@ def _declare(L):
     L.bioik_eval_approximator.argtypes = [C.c_void_p, _pd, _pd, _pd, _pd]
     L.bioik_eval_reproduce.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, _pd, _pd, _pd]
     L.bioik_eval_check.argtypes = [C.c_void_p, C.POINTER(abi.SolveParams), C.c_size_t, _pd, _pd, _pd, _pi]
+    if hasattr(L, "bioik_eval_arith"):
+        L.bioik_eval_arith.argtypes = [C.c_int, C.c_int, C.c_size_t, _pd, _pd]
     L.bioik_stream_fitness_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
@@ -121,6 +123,21 @@ def sync_debug_switches(L):
         if hasattr(L, "bioik_debug_reload_switches"):
             L.bioik_debug_reload_switches()
         _switch_snapshot[key] = snap
+
+
+ARITH_IN = {0: 1, 1: 7, 2: 8, 3: 6, 4: 8, 5: 22}
+ARITH_OUT = {0: 2, 1: 3, 2: 4, 3: 1, 4: 1, 5: 14}
+
+
+def eval_arith(op, x, device=0, lib=None):
+    """bioik_eval_arith: the shared arithmetic headers on the device, one function at a time (include/bioik_hip.h)"""
+    L = lib if lib is not None else load_library()
+    a = _f64(x).reshape(-1, ARITH_IN[op])
+    out = np.zeros((a.shape[0], ARITH_OUT[op]))
+    rc = L.bioik_eval_arith(int(device), int(op), a.shape[0], _d(a), _d(out))
+    if rc != abi.OK:
+        raise BioIKError(rc, L.bioik_last_error().decode())
+    return out
 
 
 def device_count():

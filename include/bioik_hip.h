@@ -315,6 +315,17 @@ int bioik_eval_reproduce(bioik_problem* p, int population, uint32_t rng_key, int
 int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seed,
                      const double* goal_params, const double* genes, int32_t* ok);
 
+/* The shared arithmetic of both sides of the boundary, one function at a time on the device (bio_ik_amd/csrc/bioik_sincos.h, bioik_fused.h -- the
+ * headers the kernels and the test-suite's CPU checker both include): so that a test can hold them against an INDEPENDENT high-precision
+ * reference (tests/test_arith_headers.py).  op / doubles in / doubles out per element:
+ *   0 sincos        x                                      -> sin x, cos x           (reference: libm, src/forward_kinematics.h:89-112)
+ *   1 qrot          q[4] v[3]                              -> q v q^-1                (frame.h:108-149)
+ *   2 qmul          p[4] q[4]                              -> p (x) q                 (frame.h:151-172)
+ *   3 dot3          a[3] b[3]   4 dot4  a[4] b[4]          -> a . b
+ *   5 revolute      frame[7] half_angle cpos[3] ca[4] cb[4] pos_kind rot_kind pad  -> frame'[7] by the general form, frame'[7] by the sparse form
+ * Host pointers. */
+int bioik_eval_arith(int device, int op, size_t n, const double* in, double* out);
+
 /* streamed (unfused) generation: n_units (query,species) populations resident in HBM, layout
  * genes [n_units][D][population] (individual index fastest — coalesced), fitness [n_units][population].
  * One launch evaluates exact-FK fitness of every individual.  Used for the HBM-streamed measurement of

@@ -14,6 +14,7 @@ from bio_ik_amd import abi
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "_ref", "libbioik_ref.so")
 PATH_RELEASE = os.path.join(HERE, "_ref", "libbioik_ref_release.so")  # reference Release flags: timing baseline
+PATH_RELEASE_V3 = os.path.join(HERE, "_ref", "libbioik_ref_release_v3.so")  # ... + -march=x86-64-v3 (AVX2, FMA): hosts that have them
 _lib = None
 _libs = {}
 _pd = C.POINTER(C.c_double)
@@ -28,8 +29,23 @@ def release_available():
     return os.path.exists(PATH_RELEASE) or os.path.isdir("/root/reference/src")
 
 
+def v3_available():
+    """the -march=x86-64-v3 build exists and this host can execute it"""
+    if not os.path.exists(PATH_RELEASE_V3):
+        return False
+    try:
+        flags = set(next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split())
+    except Exception:
+        return False
+    return {"avx2", "fma", "bmi2", "movbe", "f16c"} <= flags and ("abm" in flags or "lzcnt" in flags)
+
+
 def lib(release=False):
     global _lib
+    if release == "v3":
+        if "v3" not in _libs:
+            _libs["v3"] = _declare(C.CDLL(PATH_RELEASE_V3))
+        return _libs["v3"]
     if release:
         if "release" not in _libs:
             if not os.path.exists(PATH_RELEASE):
