@@ -4,7 +4,8 @@
 // The MI355X solver evaluates the built-in goals inside its kernels; this class is what runs every goal through its virtual
 // `evaluate()` — built-in or user-defined — at ONE configuration: to score or filter returned solutions with goals that have no
 // device opcode (JointFunctionGoal, LinkFunctionGoal, a user's subclass), and for the tests that hold the kernels' goal costs against
-// the closed forms of bio_ik/goal_types.h.  It is not a solver and sits on no solve path.
+// the closed forms of bio_ik/goal_types.h.  It is not a solver; the plugin core (bio_ik/plugin_core.h) uses it to re-score the candidates of a
+// device search with the goals the device cannot evaluate (the hybrid path for callback goals).
 #pragma once
 #include <functional>
 #include <stdexcept>
@@ -74,6 +75,13 @@ public:
         frames_.resize(tip_names_.size());
     }
     const std::vector<std::string>& getTipNames() const { return tip_names_; }
+    // another query of the same goal structure: what goals read of variables that are not active comes from its seed (goal.h:70-77)
+    void setInitialGuess(const std::vector<double>& initial_guess) {
+        for (auto& e : entries_) e.context.initial_guess_ = initial_guess;
+    }
+    size_t goalCount() const { return entries_.size(); }
+    bool isSecondary(size_t i) const { return entries_[i].context.goal_secondary_; }
+    double weightSq(size_t i) const { return entries_[i].weight_sq; }
 
     // the goals' unweighted costs at `positions` (a full variable vector), in goal order
     std::vector<double> evaluateGoals(const std::vector<double>& positions) const {

@@ -67,6 +67,14 @@ public:
             mv.has_mimic = mv.has_mimic || rm.joint_mimic[l] >= 0;
         }
         mv.var_bounded = rm.var_bounded, mv.var_min = rm.var_min, mv.var_max = rm.var_max;
+        mv.var_max_velocity = rm.var_max_velocity;
+        mv.var_prismatic.assign(mv.n_variables, 0);
+        for (size_t l = 0; l < rm.joint_type.size(); l++)
+            if (rm.joint_type[l] == BIOIK_JOINT_PRISMATIC) mv.var_prismatic[rm.joint_first_variable[l]] = 1;
+        // (goals evaluated on the host -- JointFunctionGoal, LinkFunctionGoal, user subclasses: plugin_core.h, the hybrid path -- read link frames from here)
+        mv.link_frame = [&rm](const std::string& link, const double* positions, double* frame7) {
+            rm.linkTransform(rm.linkIndex(link), std::vector<double>(positions, positions + rm.variable_names.size()), frame7);
+        };
         joint_names.clear();
         for (int j : jmg.active_joints) {
             joint_names.push_back(rm.joint_names[j]);
@@ -96,7 +104,7 @@ public:
 
     // The batched entry point without waiting: n independent queries sharing one goal structure are marshalled and enqueued; finish
     // with searchPositionIKBatchWait.  ik_poses [n][tips] (ignored with options.replace), ik_seed_states [n][group variables]
-    // (referenced until the wait).  Up to three batches per device may be in flight.
+    // (referenced until the wait, like `options`, whose solution_fitness the wait writes).  Up to six batches per device may be in flight.
     Pending searchPositionIKBatchAsync(const std::vector<std::vector<geometry_msgs::Pose>>& ik_poses, const std::vector<std::vector<double>>& ik_seed_states,
                                        const bio_ik::KinematicsQueryOptions& options = bio_ik::KinematicsQueryOptions(),
                                        const std::vector<double>* context_state = nullptr, double timeout = 0.0) const {

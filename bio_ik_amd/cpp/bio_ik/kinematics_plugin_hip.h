@@ -21,11 +21,13 @@ bool searchPositionIKBatch(const kinematics::KinematicsBase& solver, const std::
                            const kinematics::KinematicsQueryOptions& options = kinematics::KinematicsQueryOptions(),
                            const moveit::core::RobotState* context_state = nullptr);
 
-// The same without waiting: the batch is marshalled and enqueued (transfers and kernels on one of the plugin's three streams per
+// The same without waiting: the batch is marshalled and enqueued (transfers and kernels on one of the solver handle's SIX streams per
 // device), and the call returns a ticket; searchPositionIKBatchWait blocks until that batch is complete and post-processed.  A caller
-// with a stream of batches keeps up to three in flight and gets the throughput the device reaches on a stream of batches -- the slow
-// tail of one batch runs behind the bulk of the next.  `ik_seed_states` must stay alive until the wait; the
-// timeout is counted from the submitting call.
+// with a stream of batches keeps up to six in flight and gets the throughput the device reaches on a stream of batches -- the slow
+// tail of one batch runs behind the bulk of the next.  `ik_seed_states` and `options` must stay alive until the wait
+// (the wait writes BioIKKinematicsQueryOptions::solution_fitness).  The marshalling time is taken off `timeout`; the device counts what is
+// left from the moment the batch's first workgroup runs, so a batch that queues behind others of the pipeline is NOT cut short by its wait.
+// A ticket that is destroyed without having been waited for lets its solves finish first (its arrays are what they write into).
 struct BatchTicket {
     struct Impl;
     std::unique_ptr<Impl> impl;

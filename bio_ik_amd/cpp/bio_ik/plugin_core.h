@@ -12,7 +12,7 @@
 //   solution_fitness, approximate solutions (:632-641)                 -> Engine::wait
 //
 // A batch is SUBMITTED (inputs marshalled, transfers and kernels enqueued, nothing waited for) and later WAITED for: a caller with a
-// stream of batches keeps up to three in flight per device and reaches the throughput of DESIGN.md section 6 through this boundary;
+// stream of batches keeps up to six in flight per device and reaches the throughput of DESIGN.md section 6 through this boundary;
 // the synchronous calls are submit + wait.  Robot-model access goes through `ModelView`, a handful of arrays and name look-ups that
 // each face fills from its own model type.  Header-only; link with libbioik_hip.so.
 #pragma once
@@ -27,6 +27,7 @@
 #include <stdexcept>
 
 #include "goal.h"
+#include "goal_eval.h"
 #include "goal_types.h"
 
 namespace bio_ik {
@@ -42,6 +43,10 @@ struct ModelView {
     std::vector<int32_t> group_joints;  // link index (= its parent joint) per JointModelGroup::getActiveJointModels()
     std::function<int(const std::string&)> link_index, variable_index, joint_link_index;  // by name; negative: unknown
     std::function<void(double*)> enforce_bounds;  // RobotModel::enforcePositionBounds where the face has MoveIt's; else the generic form below
+    // For goals WITHOUT a device implementation (JointFunctionGoal, LinkFunctionGoal, a user's Goal subclass: evaluated on the host, see Engine::wait):
+    std::vector<double> var_max_velocity;  // VariableBounds::max_velocity_ (RobotInfo, include/bio_ik/robot_info.h:70-106)
+    std::vector<uint8_t> var_prismatic;
+    std::function<void(const std::string& link, const double* positions, double* frame7)> link_frame;  // global frame of a link at a full variable vector
 };
 
 struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path reads them, + the additive gpu_* keys
@@ -58,6 +63,8 @@ struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path rea
                                           // call returns the same answer; false (default): the streams advance from call to call like the
                                           // reference's generator state, and a retry of a failed query explores differently
     std::vector<int> devices = {0};  // a batch is sharded over them (contiguous shards, no exchange)
+    int gpu_host_goal_candidates = 4;  // solves whose goal list holds goals without a device implementation: candidates per query (independent random
+                                       // streams of the device search over the device-capable goals) that the host then scores with ALL goals
 };
 
 // IKFactory names with a device implementation (src/ik_evolution_2.cpp:652-654, src/ik_gradient.cpp:254-292): the bio2 family, and gd /
@@ -157,9 +164,7 @@ class Engine {
             }
         std::vector<bioik_goal_desc> gd;
         for (auto* g : goals) {
-            if (g->gpuOpcode() < 0)
-                throw std::runtime_error("bio_ik (MI355X): a goal without a device implementation (JointFunctionGoal, LinkFunctionGoal or a user-defined Goal) cannot be part "
-                                         "of a device solve; evaluate it on the host (bio_ik/goal_eval.h) on the returned solutions instead");
+            if (g->gpuOpcode() < 0) throw std::logic_error("bio_ik (MI355X): a goal without a device implementation reached the problem compiler");  // (submit() splits them off)
             bioik_goal_desc d{g->gpuOpcode(), -1, -1, g->isSecondary() ? 1 : 0, g->getWeight()};
             if (!g->gpuLinkName().empty()) {
                 d.link = mv_.link_index(g->gpuLinkName());
@@ -202,8 +207,23 @@ public:
         std::vector<uint64_t> tickets;   // one per device shard (0: an empty shard)
         std::vector<double> seeds, params, sol, fit;
         std::vector<int32_t> suc, steps, active;
-        bool approximate = false, failed = false;
-        const BioIKKinematicsQueryOptions* bio = nullptr;
+        bool approximate = false, failed = false, waited = false;
+        const BioIKKinematicsQueryOptions* bio = nullptr;  // receives solution_fitness in wait(): the caller's options object must outlive the wait
+        // goals without a device implementation (the hybrid path): every query was searched `replicas` times with independent random streams over
+        // the device-capable goals; wait() scores the candidates with the host goals added and keeps the best
+        size_t replicas = 1;
+        std::vector<const Goal*> host_goals;
+        double dmax_sq = 0.0;  // min(dpos, dtwist)^2: what a primary goal of a class the success test does not know must stay below (problem.cpp:327-334)
+        Ticket() {}
+        Ticket(const Ticket&) = delete;
+        Ticket& operator=(const Ticket&) = delete;
+        // A ticket that is dropped -- forgotten, or unwound by an exception -- while its solves are in flight: the device still writes into the
+        // arrays above (through the handle's staging arena at completion), so they must not go before the solves are over.
+        ~Ticket() {
+            if (!waited)
+                for (size_t r = 0; r < handles.size() && r < tickets.size(); r++)
+                    if (tickets[r]) (void)bioik_solve_batch_wait(handles[r], tickets[r]);
+        }
     };
 
     Engine() {}
@@ -243,27 +263,48 @@ public:
         auto tk = std::make_shared<Ticket>();
         const size_t n = rq.seed_states ? rq.seed_states->size() : 0, V = mv_.n_variables;
         tk->n = n, tk->approximate = rq.return_approximate_solution, tk->bio = rq.bio;
-        std::shared_ptr<ProblemSet> set = problemFor(rq.goals, rq.fixed_joints);
+        // Goals without a device implementation (std::function callbacks, user subclasses: the reference calls them through Goal::evaluate inside its
+        // solver loop, src/problem.cpp:244-257) cannot steer a device search.  The hybrid path: the device searches over the goals it CAN evaluate,
+        // `gpu_host_goal_candidates` times per query with independent random streams; wait() scores every candidate with the remaining goals on the host
+        // (bio_ik/goal_eval.h) and returns the best.  A weaker coupling than the reference's -- the callbacks choose among candidates instead of
+        // shaping them -- documented in DESIGN.md section 7.
+        std::vector<const Goal*> device_goals;
+        for (const Goal* g : rq.goals) (g->gpuOpcode() >= 0 ? device_goals : tk->host_goals).push_back(g);
+        if (!tk->host_goals.empty()) {
+            if (device_goals.empty())
+                throw std::runtime_error("bio_ik (MI355X): every goal of this request is a host callback (JointFunctionGoal, LinkFunctionGoal or a user-defined Goal): the "
+                                         "device search needs at least one goal with a device implementation to steer it");
+            if (!mv_.link_frame || mv_.var_max_velocity.size() != mv_.n_variables)
+                throw std::runtime_error("bio_ik (MI355X): this build of the plugin cannot evaluate goals on the host (no link_frame in its ModelView)");
+            tk->replicas = (size_t)std::max(1, settings_.gpu_host_goal_candidates);
+            const double dmax = std::min(settings_.dpos, settings_.dtwist);
+            tk->dmax_sq = dmax >= 1e150 ? DBL_MAX : dmax * dmax;
+        }
+        const size_t K = tk->replicas;
+        std::shared_ptr<ProblemSet> set = problemFor(device_goals, rq.fixed_joints);
         tk->problems = set, tk->handles = set->per_device;
         bioik_problem* problem = tk->handles.front();
         const size_t P = (size_t)bioik_problem_param_count(problem);
         tk->active.resize((size_t)bioik_problem_active_variable_count(problem));
         bioik_problem_active_variables(problem, tk->active.data());
         // the seed states over the context / default state (:465-485)
-        tk->seeds.resize(n * V);
+        // (row k K + j: candidate j of query k; K = 1 unless host goals are present)
+        tk->seeds.resize(n * K * V);
         for (size_t k = 0; k < n; k++) {
-            double* row = &tk->seeds[k * V];
+            double* row = &tk->seeds[k * K * V];
             for (size_t v = 0; v < V; v++) row[v] = rq.context[v];
             const std::vector<double>& seed = (*rq.seed_states)[k];
             for (size_t i = 0; i < mv_.group_vars.size(); i++) row[mv_.group_vars[i]] = seed.at(i);
+            for (size_t j = 1; j < K; j++) std::copy(row, row + V, row + j * V);
         }
         // per-query goal numbers: the default pose goals move into the model frame (:487-502, :540-546), then every goal writes its own
-        tk->params.resize(n * P);
+        tk->params.resize(n * K * P);
         std::vector<double> row;
+        if (rq.n_pose_goals > device_goals.size()) throw std::logic_error("bio_ik (MI355X): the default pose goals must lead the goal list");
         for (size_t k = 0; k < n; k++) {
             row.clear();
-            for (size_t gi = 0; gi < rq.goals.size(); gi++) {
-                const Goal* g = rq.goals[gi];
+            for (size_t gi = 0; gi < device_goals.size(); gi++) {
+                const Goal* g = device_goals[gi];
                 if (gi < rq.n_pose_goals) {
                     double m[7];
                     concat7(rq.base_frame, &rq.tip_poses.at((k * rq.n_pose_goals + gi) * 7), m);
@@ -273,7 +314,8 @@ public:
                 }
                 g->gpuParams(row);
             }
-            for (size_t i = 0; i < P; i++) tk->params[k * P + i] = row.at(i);
+            for (size_t j = 0; j < K; j++)
+                for (size_t i = 0; i < P; i++) tk->params[(k * K + j) * P + i] = row.at(i);
         }
         bioik_solve_params sp;
         bioik_default_solve_params(&sp);
@@ -285,7 +327,8 @@ public:
         sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
         sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;
         sp.no_wipeout = settings_.no_wipeout ? 1 : 0;
-        tk->sol.resize(n * V), tk->fit.resize(n), tk->suc.resize(n), tk->steps.resize(n);
+        const size_t rows = n * K;
+        tk->sol.resize(rows * V), tk->fit.resize(rows), tk->suc.resize(rows), tk->steps.resize(rows);
         // problem.timeout = t0 + timeout with t0 taken at entry (:448, :504): what the marshalling above has used is off the budget (one
         // step always runs, ik_parallel.h:160)
         if (rq.timeout > 0.0) {
@@ -297,9 +340,9 @@ public:
         const size_t W = tk->handles.size();
         tk->tickets.assign(W, 0);
         const uint64_t first = settings_.gpu_reproducible_calls ? 0 : next_query_;
-        next_query_ += n;
+        next_query_ += rows;
         for (size_t r = 0; r < W; r++) {
-            const size_t a = r * n / W, b = (r + 1) * n / W;
+            const size_t a = r * rows / W, b = (r + 1) * rows / W;
             if (a == b) continue;
             bioik_problem_set_first_query(tk->handles[r], first + a);
             if (bioik_solve_batch_submit(tk->handles[r], &sp, b - a, &tk->seeds[a * V], P ? &tk->params[a * P] : nullptr, &tk->sol[a * V], &tk->fit[a], &tk->suc[a],
@@ -312,21 +355,71 @@ public:
     // Waits for the batch; solutions [n][group variables], ok[k] = accurate solution or an approximate one was asked for (:638-641).
     // Returns true iff every query is ok.
     bool wait(Ticket& tk, std::vector<std::vector<double>>& solutions, std::vector<uint8_t>& ok) {
-        const size_t n = tk.n, V = mv_.n_variables;
+        const size_t n = tk.n, V = mv_.n_variables, K = tk.replicas;
         for (size_t r = 0; r < tk.handles.size(); r++)
             if (tk.tickets[r] && bioik_solve_batch_wait(tk.handles[r], tk.tickets[r]) != BIOIK_OK) tk.failed = true;
+        tk.waited = true;
         solutions.assign(n, std::vector<double>());
         ok.assign(n, 0);
         if (tk.failed) return false;
         bool all_ok = true;
-        for (size_t k = 0; k < n; k++) {
-            double* st = &tk.sol[k * V];
-            postprocess(st, &tk.seeds[k * V], tk.active);
-            for (int gv : mv_.group_vars) solutions[k].push_back(st[gv]);  // map the result to the group's variables (:619-629)
-            ok[k] = (tk.suc[k] || tk.approximate) ? 1 : 0;
-            all_ok = all_ok && ok[k];
+        std::unique_ptr<HostGoalProblem> host;  // the goals the device did not see, evaluated through their own describe() / evaluate()
+        std::vector<double> positions(V);
+        if (!tk.host_goals.empty() && n) {
+            HostGoalProblem::Model hm;
+            for (size_t v = 0; v < V; v++)
+                hm.info.addVariable(mv_.var_min[v], mv_.var_max[v], mv_.var_bounded[v] != 0, mv_.var_max_velocity[v], mv_.var_revolute[v] != 0,
+                                    v < mv_.var_prismatic.size() && mv_.var_prismatic[v] != 0);
+            hm.variable_index = mv_.variable_index;
+            const ModelView* mv = &mv_;
+            hm.link_frame = [mv](const std::string& name, const std::vector<double>& p) {
+                double f[7];
+                mv->link_frame(name, p.data(), f);
+                return Frame(Vector3(f[0], f[1], f[2]), Quaternion(f[3], f[4], f[5], f[6]));
+            };
+            host.reset(new HostGoalProblem(hm, tk.host_goals, std::vector<int>(tk.active.begin(), tk.active.end()), std::vector<double>(&tk.seeds[0], &tk.seeds[0] + V)));
         }
-        if (tk.bio && n) tk.bio->solution_fitness = tk.fit[n - 1];  // :632-634
+        for (size_t k = 0; k < n; k++) {
+            size_t best = k * K;
+            if (host) {
+                // ik_parallel.h:220-269 over the candidates: the accepted ones ranked by primary + secondary fitness, else the least primary fitness --
+                // with the host goals' weighted costs added to the device's figures, and a candidate accepted only if every PRIMARY host goal also
+                // passes the success rule for goal classes the test does not know: weight^2 cost < min(dpos, dtwist)^2 (problem.cpp:327-334)
+                host->setInitialGuess(std::vector<double>(&tk.seeds[k * K * V], &tk.seeds[k * K * V] + V));
+                double best_fit = DBL_MAX;
+                bool best_ok = false;
+                for (size_t j = 0; j < K; j++) {
+                    const size_t r = k * K + j;
+                    double* st = &tk.sol[r * V];
+                    postprocess(st, &tk.seeds[r * V], tk.active);
+                    positions.assign(st, st + V);
+                    const std::vector<double> e = host->evaluateGoals(positions);
+                    double prim = 0.0, sec = 0.0;
+                    bool pass = tk.suc[r] != 0;
+                    for (size_t g = 0; g < e.size(); g++) {
+                        const double d = e[g] * host->weightSq(g);
+                        if (host->isSecondary(g)) {
+                            sec += d;
+                        } else {
+                            prim += d;
+                            if (!(d < tk.dmax_sq)) pass = false;
+                        }
+                    }
+                    // (the device's fitness of an accepted candidate already holds its secondary goals, of a rejected one the primary goals only;
+                    // a candidate the host rejects is compared on primary fitness, like one the device rejected)
+                    const double total = tk.fit[r] + prim + (pass ? sec : 0.0);
+                    tk.suc[r] = pass ? 1 : 0, tk.fit[r] = total;
+                    if ((pass && !best_ok) || (pass == best_ok && total < best_fit)) best = r, best_fit = total, best_ok = pass;
+                }
+            } else {
+                postprocess(&tk.sol[best * V], &tk.seeds[best * V], tk.active);
+            }
+            const double* st = &tk.sol[best * V];
+            for (int gv : mv_.group_vars) solutions[k].push_back(st[gv]);  // map the result to the group's variables (:619-629)
+            ok[k] = (tk.suc[best] || tk.approximate) ? 1 : 0;
+            all_ok = all_ok && ok[k];
+            if (tk.bio && k == n - 1) tk.bio->solution_fitness = tk.fit[best];  // :632-634
+        }
         return all_ok;
     }
 

@@ -137,7 +137,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
     moveit::core::RobotModelConstPtr robot_model;
     const moveit::core::JointModelGroup* joint_model_group = nullptr;
     mutable std::vector<double> state;
-    mutable std::unique_ptr<moveit::core::RobotState> temp_state;
+    mutable std::unique_ptr<moveit::core::RobotState> temp_state, host_state;
     mutable std::vector<std::unique_ptr<bio_ik::Goal>> default_goals;
     mutable std::mutex mutex;  // the reference's instance is not re-entrant either (mutable members, :121-124); here calls serialise
 
@@ -207,6 +207,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         lookupParam("no_wipeout", p.no_wipeout, false);
         lookupParam("gpu_population", p.gpu_population, 128);   // children per species and generation (reference: 16, ik_evolution_2.cpp:138)
         lookupParam("gpu_islands", p.gpu_islands, 1);
+        lookupParam("gpu_host_goal_candidates", p.gpu_host_goal_candidates, 4);  // candidates per query that the host scores when the goal list holds callback goals
         lookupParam("gpu_max_steps", p.gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query
         lookupParam("gpu_fk", p.gpu_fk, std::string("exact"));  // "exact" | "linear" (the reference's linearised phenotypes)
         lookupParam("gpu_schedule", p.gpu_schedule, std::string("auto"));  // "auto" | "latency" | "throughput" (plugin_core.h: Settings)
@@ -236,7 +237,20 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
             const moveit::core::VariableBounds& b = jm->getVariableBounds()[v - (size_t)jm->getFirstVariableIndex()];
             mv.var_bounded.push_back(b.position_bounded_ ? 1 : 0);
             mv.var_min.push_back(b.min_position_), mv.var_max.push_back(b.max_position_);
+            mv.var_max_velocity.push_back(b.max_velocity_);
+            mv.var_prismatic.push_back(jm->getType() == moveit::core::JointModel::PRISMATIC ? 1 : 0);
         }
+        // goals that are evaluated on the host (JointFunctionGoal, LinkFunctionGoal, user subclasses: bio_ik/plugin_core.h, the hybrid path) read link
+        // frames through MoveIt's own forward kinematics
+        host_state.reset(new moveit::core::RobotState(robot_model));
+        moveit::core::RobotState* hs = host_state.get();
+        const size_t n_var = mv.n_variables;
+        mv.link_frame = [hs, n_var](const std::string& link, const double* positions, double* frame7) {
+            hs->setVariablePositions(std::vector<double>(positions, positions + n_var));
+            hs->update();
+            const Frame7 f = toFrame(hs->getGlobalLinkTransform(link));
+            for (int c = 0; c < 7; c++) frame7[c] = f.v[c];
+        };
         mv.has_mimic = !rm->getMimicJointModels().empty();
         for (auto& joint_name : joint_names) {  // seed / solution vectors: the variables of the group's joints in this order (:473-484, :619-629)
             auto* joint_model = rm->getJointModel(joint_name);

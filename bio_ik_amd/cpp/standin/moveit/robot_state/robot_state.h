@@ -22,6 +22,7 @@ public:
     const double* getVariablePositions() const { return position_.data(); }
     double* getVariablePositions() { return position_.data(); }
     void setVariablePositions(const std::vector<double>& p) { position_ = p; }
+    void update(bool /*force*/ = false) {}  // (MoveIt: refresh the cached link transforms; here they are computed where they are asked for)
     void setVariablePosition(const std::string& name, double v) { position_[(size_t)model_->getVariableIndex(name)] = v; }
     double getVariablePosition(const std::string& name) const { return position_[(size_t)model_->getVariableIndex(name)]; }
     // RobotState::setFromIK, the multi-tip overload with explicit options (defined with the KinematicsBase stand-in, kinematics_base.h):

@@ -216,6 +216,10 @@ struct bioik_problem {
         size_t n = 0, o_sol = 0, o_fit = 0, o_suc = 0, o_steps = 0;
         double *solutions = nullptr, *fitness = nullptr;
         int32_t *success = nullptr, *steps = nullptr;
+        // a solve of this slot that ended in a device error: remembered for ITS ticket's wait (the slot itself is free again)
+        uint64_t failed_ticket = 0;
+        int failed_code = 0;
+        std::string failed_message;
     } io[kIoSlots];
     uint64_t next_ticket = 1;  // ticket t runs on slot t % kIoSlots
     uint64_t first_query = 0;
@@ -765,9 +769,17 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
 // io_finish: the slot's solve is complete and its results are in the caller's arrays (no-op for an idle slot).  Called with p->mtx held.
 static void io_finish(bioik_problem* p, bioik_problem::IoSlot& sl) {
     if (!sl.pending) return;
-    sl.pending = false;  // (whatever happens below, the slot is free again)
     DeviceGuard on_device(p->model->device);
-    be_sync(sl.stream);
+    try {
+        be_sync(sl.stream);
+    } catch (const Error& e) {
+        // the device failed under THIS slot's solve: its ticket's wait reports it (not whichever call came by to reuse the slot), its result arrays
+        // stay untouched, and the slot is free again
+        sl.failed_ticket = sl.ticket, sl.failed_code = e.code, sl.failed_message = e.what();
+        sl.pending = false;
+        return;
+    }
+    sl.pending = false;
     const size_t V = p->host.dev.V;
     const char* hd = (const char*)sl.host;
     std::memcpy(sl.solutions, hd + sl.o_sol, sl.n * V * 8);
@@ -833,7 +845,7 @@ int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t
     API_END
 }
 
-// Asynchronous host-pointer solve: a caller with a stream of batches keeps up to three of them in flight on ONE handle.
+// Asynchronous host-pointer solve: a caller with a stream of batches keeps up to kIoSlots (six) of them in flight on ONE handle.
 int bioik_solve_batch_submit(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,
                              double* fitness, int32_t* success, int32_t* steps, uint64_t* ticket) {
     API_BEGIN
@@ -861,15 +873,20 @@ int bioik_solve_batch_wait(bioik_problem* p, uint64_t ticket) {
     {
         std::lock_guard<std::mutex> lock(p->mtx);
         if (ticket == 0 || ticket >= p->next_ticket) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_batch_wait: unknown ticket");
+        if (sl.failed_ticket == ticket) throw Error(sl.failed_code, "the solve of this ticket failed on the device: " + sl.failed_message);
         if (!sl.pending || sl.ticket != ticket) return BIOIK_OK;  // completed when its slot was taken again, or an empty batch
         st = sl.stream;
     }
     {  // the wait itself happens outside the handle's lock: another thread may submit the next batch meanwhile
         DeviceGuard on_device(p->model->device);
-        be_sync(st);
+        try {
+            be_sync(st);
+        } catch (const Error&) {  // (io_finish below meets the same error under the lock and files it with the ticket)
+        }
     }
     std::lock_guard<std::mutex> lock(p->mtx);
     if (sl.pending && sl.ticket == ticket) io_finish(p, sl);
+    if (sl.failed_ticket == ticket) throw Error(sl.failed_code, "the solve of this ticket failed on the device: " + sl.failed_message);
     API_END
 }
 

@@ -227,7 +227,7 @@ class HipSolver:
 
     def submit_batch(self, params, seeds, goal_params):
         """bioik_solve_batch_submit: the same solve without waiting.  Returns a ticket object; `wait_batch(ticket)` returns what solve_batch
-        returns.  Up to three batches of this handle are in flight together (the library rotates over three internal streams)."""
+        returns.  Up to six batches of this handle are in flight together (the library rotates over six internal streams)."""
         sync_debug_switches(self.L)
         s = _f64(seeds).reshape(-1, self.V)
         n = s.shape[0]

@@ -183,7 +183,9 @@ typedef struct bioik_solve_params {
     int32_t population;      /* children per species per generation (reference hard-codes 16,
                                 ik_evolution_2.cpp:138); new key "gpu_population"                        */
     int32_t islands;         /* independent islands per query (reference concurrency()==4 identical
-                                clones, ik_evolution_2.cpp:649 + utils.h:423); new key "gpu_islands"     */
+                                clones, ik_evolution_2.cpp:649 + utils.h:423); new key "gpu_islands".  Applies to
+                                every mode: for gd / gd_r / gd_c / jac, islands = N > 1 is the reference's "gd_N" ...
+                                (islands 1 ... N - 1 start at random configurations)                       */
     int32_t max_steps;       /* budget in IKEvolution2::step() calls per island (deterministic; checked after
                                 every step like the success test of ik_parallel.h:173-181)               */
     uint64_t random_seed;    /* yaml "random_seed" (kinematics_plugin.cpp:256)                           */
@@ -194,7 +196,11 @@ typedef struct bioik_solve_params {
     double timeout;          /* the caller's `timeout` of searchPositionIK [s] (kinematics_plugin.cpp:504, 574;
                                 ik_parallel.h:160 `ros::WallTime::now() < timeout`): wall-clock budget of ONE
                                 bioik_solve_batch* call, measured on the device from the moment the launch's first
-                                workgroup starts.  Every query runs at least one step (ik_parallel.h:160
+                                workgroup starts -- NOT from the submitting call: a solve that waits behind other
+                                solves of the caller's pipeline (bioik_solve_batch_submit with several in flight, or
+                                several device-pointer solves on busy streams) starts its clock when it reaches the
+                                chip, so its wall time from submission exceeds `timeout` by the time it queued.  An
+                                isolated call (the plugin's searchPositionIK) has no such wait.  Every query runs at least one step (ik_parallel.h:160
                                 `iteration != 0`), then stops at the first of: success, max_steps, timeout.
                                 <= 0: no wall-clock limit (results are then independent of timing).          */
 } bioik_solve_params;

@@ -24,6 +24,10 @@ using namespace bio_ik_kinematics_plugin;
         }                                                               \
     } while (0)
 
+struct SecondaryLinkFunctionGoal : bio_ik::LinkFunctionGoal {  // (a callback goal made secondary the way a user of the reference would: in a subclass)
+    SecondaryLinkFunctionGoal(const std::string& link, const std::function<double(const bio_ik::Vector3&, const bio_ik::Quaternion&)>& f) : LinkFunctionGoal(link, f) { secondary_ = true; }
+};
+
 int main() {
     bio_ik::RobotModel rm = pr2Arm();
     BioIKKinematicsPlugin plugin;
@@ -104,6 +108,69 @@ int main() {
     opts.goals.emplace_back(new bio_ik::MinimalDisplacementGoal(0.1));
     CHECK(quick.searchPositionIK(std::vector<geometry_msgs::Pose>(), seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, opts));
     CHECK(opts.solution_fitness >= 0.0);
+
+    // Goals without a device implementation (LinkFunctionGoal, JointFunctionGoal, a user's subclass: the reference calls them inside its solver loop,
+    // problem.cpp:244-257): the hybrid path of plugin_core.h -- the device searches over the goals it can evaluate, gpu_host_goal_candidates times per
+    // query with independent random streams, and the host scores the candidates with the callback goals added.
+    {
+        BioIKKinematicsPlugin hybrid;
+        BioIKParams hp = params;
+        hp.gpu_max_steps = 60, hp.gpu_host_goal_candidates = 4, hp.gpu_reproducible_calls = true;
+        CHECK(hybrid.initialize(rm, "right_arm", "torso_lift_link", {"r_wrist_roll_link"}, 0.0, hp));
+        // the candidates themselves: with reproducible calls, candidate j of query 0 draws from stream j -- as query j of a plain batch of four copies does
+        std::vector<std::vector<geometry_msgs::Pose>> p4(4, poses[0]);
+        std::vector<std::vector<double>> s4(4, seeds[0]), cand;
+        std::vector<moveit_msgs::MoveItErrorCodes> c4;
+        CHECK(hybrid.searchPositionIKBatch(p4, s4, cand, c4));
+        auto elbow_z = [&](const std::vector<double>& sol) {
+            std::vector<double> st = rm.defaultPositions();
+            for (size_t i = 0; i < gv.size(); i++) st[gv[i]] = sol[i];
+            double f[7];
+            rm.linkTransform(rm.linkIndex("r_elbow_flex_link"), st, f);
+            return f[2];
+        };
+        size_t lowest = 0, highest = 0;
+        for (size_t j = 1; j < 4; j++) {
+            if (elbow_z(cand[j]) < elbow_z(cand[lowest])) lowest = j;
+            if (elbow_z(cand[j]) > elbow_z(cand[highest])) highest = j;
+        }
+        CHECK(elbow_z(cand[highest]) - elbow_z(cand[lowest]) > 1e-6);  // (a 7-joint arm reaches a pose along a one-parameter family: the streams find different members)
+        for (int sign : {+1, -1}) {  // a SECONDARY callback goal that wants the elbow low (+1) or high (-1): it decides which candidate is returned
+            bio_ik::BioIKKinematicsQueryOptions o;
+            o.goals.emplace_back(new SecondaryLinkFunctionGoal("r_elbow_flex_link", [sign](const bio_ik::Vector3& p, const bio_ik::Quaternion&) { return (sign * p.z() + 3.0) * (sign * p.z() + 3.0); }));
+            CHECK(hybrid.searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, o) && code.val == moveit_msgs::MoveItErrorCodes::SUCCESS);
+            CHECK(solution == cand[sign > 0 ? lowest : highest]);
+            CHECK(o.solution_fitness > 0.0);
+        }
+        {  // a PRIMARY callback goal gates success by the rule for goal classes the success test does not know: weight^2 cost < min(dpos, dtwist)^2 (problem.cpp:327-334)
+            bio_ik::BioIKKinematicsQueryOptions o;
+            o.goals.emplace_back(new bio_ik::JointFunctionGoal({"r_elbow_flex_joint"}, [](std::vector<double>& v) { v[0] = v[0] + 1.0; }));  // cost 1: never met
+            CHECK(!hybrid.searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, o) && code.val == moveit_msgs::MoveItErrorCodes::NO_IK_SOLUTION);
+            o.return_approximate_solution = true;
+            CHECK(hybrid.searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, o) && solution.size() == 7);
+            bio_ik::BioIKKinematicsQueryOptions met;
+            met.goals.emplace_back(new bio_ik::JointFunctionGoal({"r_elbow_flex_joint"}, [](std::vector<double>&) {}));  // cost 0: always met
+            CHECK(hybrid.searchPositionIK(poses[0], seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, met) && code.val == moveit_msgs::MoveItErrorCodes::SUCCESS);
+        }
+        {  // nothing but callbacks: there is no goal the device search could follow -- a configuration error with a message
+            bio_ik::BioIKKinematicsQueryOptions o;
+            o.replace = true;
+            o.goals.emplace_back(new bio_ik::LinkFunctionGoal("r_wrist_roll_link", [](const bio_ik::Vector3& p, const bio_ik::Quaternion&) { return p.z(); }));
+            bool threw = false;
+            try {
+                hybrid.searchPositionIK(std::vector<geometry_msgs::Pose>(), seeds[0], TEST_TIMEOUT, std::vector<double>(), solution, IKCallbackFn(), code, o);
+            } catch (const std::runtime_error& e) {
+                threw = std::string(e.what()).find("at least one goal with a device implementation") != std::string::npos;
+            }
+            CHECK(threw);
+        }
+        {  // a batch that is submitted and never waited for: the ticket's destructor lets the solves finish before their arrays go (no use after free)
+            std::vector<std::vector<geometry_msgs::Pose>> pp(2, poses[0]);
+            std::vector<std::vector<double>> ss(2, seeds[0]);
+            { auto pending = hybrid.searchPositionIKBatchAsync(pp, ss); }
+            CHECK(hybrid.searchPositionIKBatch(pp, ss, cand, c4));
+        }
+    }
     std::printf("ok\n");
     return 0;
 }
