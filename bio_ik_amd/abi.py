@@ -61,7 +61,8 @@ class ProblemDesc(C.Structure):
 class SolveParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_int32), ("fk_mode", C.c_int32), ("population", C.c_int32),
                 ("islands", C.c_int32), ("max_steps", C.c_int32), ("random_seed", C.c_uint64), ("dpos", C.c_double),
-                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("schedule", C.c_int32), ("timeout", C.c_double)]
+                ("drot", C.c_double), ("dtwist", C.c_double), ("no_wipeout", C.c_int32), ("schedule", C.c_int32), ("timeout", C.c_double),
+                ("island_sync", C.c_int32), ("reserved0", C.c_int32)]
 
 
 def default_solve_params(**kw):
@@ -80,6 +81,8 @@ def default_solve_params(**kw):
     p.no_wipeout = 0
     p.schedule = SCHEDULE_LATENCY
     p.timeout = 0.0
+    p.island_sync = 0
+    p.reserved0 = 0
     for k, v in kw.items():
         if k == "mode" and isinstance(v, str):
             v = MODE_BY_NAME[v]

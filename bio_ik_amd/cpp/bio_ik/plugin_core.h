@@ -55,6 +55,8 @@ struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path rea
     double dpos = DBL_MAX, drot = DBL_MAX, dtwist = 1e-5;
     bool no_wipeout = false;
     int gpu_population = 128, gpu_islands = 1, gpu_max_steps = 4096;
+    bool gpu_island_sync = true;  // gpu_islands > 1 (and the _2 / _4 / _8 solver names): "any island succeeds => all stop", the reference's island loop
+                                  // (ik_parallel.h:102, 160-178) in its deterministic form (bioik_solve_params::island_sync); false: every island to its own end
     std::string gpu_fk = "exact";
     std::string gpu_schedule = "auto";     // "latency": every call as fast as it can be; "throughput": for callers that keep six or more batches in
                                            // flight (searchPositionIKBatchAsync): +30 % solves per second, an isolated call a quarter slower; "auto":
@@ -327,6 +329,7 @@ public:
         sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
         sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;
         sp.no_wipeout = settings_.no_wipeout ? 1 : 0;
+        sp.island_sync = (settings_.gpu_island_sync && sp.islands > 1) ? 1 : 0;
         const size_t rows = n * K;
         tk->sol.resize(rows * V), tk->fit.resize(rows), tk->suc.resize(rows), tk->steps.resize(rows);
         // problem.timeout = t0 + timeout with t0 taken at entry (:448, :504): what the marshalling above has used is off the budget (one

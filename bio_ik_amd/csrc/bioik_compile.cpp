@@ -584,6 +584,8 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "unknown schedule");
     o.schedule = p.schedule;
     o.generations = o.memetic ? 8 : 16;  // ik_evolution_2.cpp:349-351
+    if (p.island_sync != 0 && p.island_sync != 1) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "island_sync must be 0 or 1");
+    o.island_sync = (p.island_sync && o.islands > 1) ? 1 : 0;
     return o;
 }
 

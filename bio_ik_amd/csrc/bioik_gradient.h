@@ -284,13 +284,20 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
         const FitCheck fc = exact_fitness_check(pb, XV{s_best, 1}, qc, s_slots, sp.dpos, sp.drot, sp.dtwist, 1, s_prefix);
         final_fit = fc.fitness;
         success = fc.ok != 0;
-        if (success) break;
-        if (sp.timeout_ticks != 0ull) {
-            if (tid == 0) s_ex[6] = p_wall_clock() >= deadline ? 1.0 : 0.0;
+        if (success) {
+            if (a.first_success && tid == 0) p_atomic_min(a.first_success + q, (unsigned int)steps);  // ik_parallel.h:176-177 `finished = 1`
+            break;
+        }
+        if (sp.timeout_ticks != 0ull || a.first_success) {
+            if (tid == 0) {
+                const bool expired_now = sp.timeout_ticks != 0ull && p_wall_clock() >= deadline;
+                const bool overtaken = a.first_success && p_atomic_load(a.first_success + q) <= (unsigned int)steps;  // (see solve_body)
+                s_ex[6] = (expired_now || overtaken) ? 1.0 : 0.0;
+            }
             p_wave_sync();
-            const bool expired = s_ex[6] != 0.0;
+            const bool stop = s_ex[6] != 0.0;
             p_wave_sync();
-            if (expired) break;
+            if (stop) break;
         }
     }
     double rank_fit = final_fit;

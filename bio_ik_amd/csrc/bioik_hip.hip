@@ -85,6 +85,7 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
 }
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
 static void be_zero_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
+static void be_fill_ff_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0xff, bytes, s)); }
 static stream_t be_stream_create() {
     hipStream_t s = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -388,17 +389,22 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             return;
         }
         const size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
-        island_ws = be_alloc_async(units * per + 64, stream);
+        island_ws = be_alloc_async(units * per + 64 + n * 4, stream);
         char* w = (char*)island_ws;
         args.solutions = (double*)w, w += units * dp.V * 8;
         args.fitness = (double*)w, w += units * 8;
         args.success = (int32_t*)w, w += units * 4;
-        args.steps = (int32_t*)w;
+        args.steps = (int32_t*)w, w += units * 4;
+        if (sp.island_sync) {  // "any island succeeds => all stop": the least step count of a passing island, per query (0xffffffff: none yet)
+            args.first_success = (unsigned int*)w;
+            be_fill_ff_async(args.first_success, n * 4, stream);
+        }
     };
     auto select_islands = [&](const SolveArgs& args) {  // ik_parallel.h:220-269: the best island of every query
         if (sp.islands == 1) return;
         SelectArgs s;
         s.islands = sp.islands, s.V = dp.V, s.n = n;
+        s.sync = sp.island_sync, s.pad = 0;
         s.isl_solutions = args.solutions, s.isl_fitness = args.fitness, s.isl_success = args.success, s.isl_steps = args.steps;
         s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
         LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
@@ -684,6 +690,7 @@ void bioik_default_solve_params(bioik_solve_params* p) {
     p->dtwist = 1e-5;
     p->no_wipeout = 0;
     p->timeout = 0.0;
+    p->island_sync = 0;
 }
 
 int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out) {

@@ -260,6 +260,10 @@ struct SolveArgs {
     unsigned int* carry_count = nullptr;      // ... and how many (zeroed by the host)
     const int32_t* unit_list = nullptr;       // second launch: workgroup b continues unit_list[b] ...
     const unsigned int* unit_count = nullptr; // ... for b < *unit_count (the grid is an upper bound)
+    // sp.island_sync ("any island succeeds => all stop", ik_parallel.h:102, 160-178): one word per query, the least number of steps after which
+    // an island of the query has passed the success test (the host fills it with 0xffffffff).  An island that passes files its step count (atomic
+    // minimum); an island that finds a count <= its own leaves, because k_select only considers the islands that passed at the least count.
+    unsigned int* first_success = nullptr;    // [n]
 };
 
 struct SpeciesState {
@@ -485,7 +489,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
     }
     int steps = a.step_begin;
-    bool success = false, expired = false;
+    bool success = false, expired = false, overtaken_out = false;
     double final_fit = BIOIK_DBL_MAX;
     const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
     for (int step = a.step_begin; step < step_end; step++) {
@@ -1067,21 +1071,34 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         final_fit = s_solst[0];
         success = s_solst[1] != 0.0;
         PHASE_MARK(PH_CHECK);
-        if (success) break;
-        if (sp.timeout_ticks != 0ull) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
+        if (success) {
+            if (a.first_success && tid == 0) p_atomic_min(a.first_success + q, (unsigned int)steps);  // ik_parallel.h:176-177 `finished = 1`
+            break;
+        }
+        if (sp.timeout_ticks != 0ull || a.first_success) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
             if (tid == 0) {
-                const unsigned long long deadline = ((unsigned long long)s_deadline[0] << 32) | (unsigned long long)s_deadline[1];
-                s_wbc[2] = p_wall_clock() >= deadline ? 1.0 : 0.0;
+                bool stop = false;
+                if (sp.timeout_ticks != 0ull) {
+                    const unsigned long long deadline = ((unsigned long long)s_deadline[0] << 32) | (unsigned long long)s_deadline[1];
+                    stop = p_wall_clock() >= deadline;
+                }
+                // ik_parallel.h:160 `!finished`: another island of the query has passed after no more steps than this one has run -- whatever this
+                // island finds from here on, the selection will not look at it (lane 0 reads the word, the verdict crosses LDS like the clock's)
+                const bool overtaken = a.first_success && p_atomic_load(a.first_success + q) <= (unsigned int)steps;
+                s_wbc[2] = stop ? 1.0 : 0.0;
+                s_wbc[3] = overtaken ? 1.0 : 0.0;
             }
             p_barrier();
             expired = s_wbc[2] != 0.0;
+            const bool overtaken = s_wbc[3] != 0.0;
             p_barrier();
-            if (expired) break;
+            if (overtaken) overtaken_out = true;
+            if (expired || overtaken) break;
         }
     }
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
-    const bool handed_over = a.carry_list && !success && !expired && step_end < sp.max_steps;  // neither solved nor out of time: the next launch goes on
+    const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && step_end < sp.max_steps;  // neither solved nor out of time: the next launch goes on
     if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < 2 * BF; i += nth) {
@@ -1113,6 +1130,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
 // best island per query (ik_parallel.h:220-269); one lane per query
 struct SelectArgs {
     int islands, V;
+    int sync, pad;  // sync: only the islands that passed after the LEAST number of steps are candidates (bioik_solve_params::island_sync)
     uint64_t n;
     const double* isl_solutions;
     const double* isl_fitness;
@@ -1127,9 +1145,15 @@ BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
     if (q >= a.n) return;
     int best = 0;
     double best_fit = BIOIK_DBL_MAX;
+    int least_steps = 0x7fffffff;
+    if (a.sync)
+        for (int i = 0; i < a.islands; i++) {
+            uint64_t u = q * (uint64_t)a.islands + i;
+            if (a.isl_success[u] && a.isl_steps[u] < least_steps) least_steps = a.isl_steps[u];
+        }
     for (int i = 0; i < a.islands; i++) {
         uint64_t u = q * (uint64_t)a.islands + i;
-        if (a.isl_success[u] && a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
+        if (a.isl_success[u] && (!a.sync || a.isl_steps[u] == least_steps) && a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
     }
     if (best_fit == BIOIK_DBL_MAX) {
         for (int i = 0; i < a.islands; i++) {

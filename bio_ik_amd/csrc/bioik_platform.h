@@ -107,6 +107,8 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     return old ? old : value;
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return atomicAdd(counter, 1u); }  // returns the value before
+BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) { (void)atomicMin(word, value); }
+BIOIK_DEV unsigned int p_atomic_load(const unsigned int* word) { return __atomic_load_n(word, __ATOMIC_RELAXED); }  // (a word other workgroups write: read from memory every time)
 #define P_INF (__builtin_inf())
 #define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
 #define BIOIK_HD __host__ __device__ inline

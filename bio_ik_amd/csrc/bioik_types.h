@@ -141,4 +141,5 @@ struct DevSolveParams {
     int32_t species_parallel;   // 1: the workgroup splits into two lane groups, one species each, running concurrently
     int32_t schedule;           // BIOIK_SCHEDULE_* (host side only: what the launcher optimises for)
     int32_t child_pairs;        // 1: a lane reproduces and scores its children two at a time (two independent dependency chains per lane)
+    int32_t island_sync;        // 1: the islands of a query stop once one of them has passed the success test (bioik_solve_params::island_sync)
 };

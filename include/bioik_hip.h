@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BIOIK_ABI_VERSION 3
+#define BIOIK_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -203,6 +203,14 @@ typedef struct bioik_solve_params {
                                 isolated call (the plugin's searchPositionIK) has no such wait.  Every query runs at least one step (ik_parallel.h:160
                                 `iteration != 0`), then stops at the first of: success, max_steps, timeout.
                                 <= 0: no wall-clock limit (results are then independent of timing).          */
+    int32_t island_sync;     /* islands > 1: 0 = every island runs to its own success or budget and the best one is returned (ik_parallel.h:220-269
+                                over independent islands); 1 = "any island succeeds => all stop" (the reference's `finished` flag, ik_parallel.h:102,
+                                160-178) in its deterministic form: the islands of a query advance step by step together and all stop at the end of the
+                                FIRST step in which any of them passes the success test; the result is the best of the islands that passed in that
+                                step, `steps` is that step's number.  (On the device an island leaves as soon as it sees that another one has passed at
+                                an earlier or the same step -- its own result can no longer be chosen -- so WHEN it leaves depends on timing, WHAT is
+                                returned does not.)  New key "gpu_island_sync". */
+    int32_t reserved0;
 } bioik_solve_params;
 
 /* defaults: bio2_memetic, exact FK, population 128, 1 island, 64 steps, no timeout, seed 0, dpos=drot=off, dtwist=1e-5 */

@@ -4,6 +4,7 @@
 #include "bioik_oracle.h"
 
 #include <atomic>
+#include <climits>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -522,8 +523,14 @@ int orc_solve_batch(void* problem, const bioik_solve_params* params, int rng_mod
                         }
                     }
                     size_t best_index = 0;
+                    // bioik_solve_params::island_sync ("any island succeeds => all stop", ik_parallel.h:102, 160-178, in lock step): the islands that
+                    // passed after the least number of steps are the candidates; the others would have been stopped at that step without having passed
+                    int least_steps = INT_MAX;
+                    if (params->island_sync)
+                        for (size_t i = 0; i < rs.size(); i++)
+                            if (rs[i].success && rs[i].steps < least_steps) least_steps = rs[i].steps;
                     for (size_t i = 0; i < rs.size(); i++) {
-                        if (rs[i].success) {
+                        if (rs[i].success && (!params->island_sync || rs[i].steps == least_steps)) {
                             double f = rs[i].fitness;
                             if (!local.secondary_goals.empty()) {
                                 std::vector<Frame> nullf(local.tip_link_indices.size(), Frame{{0, 0, 0}, {0, 0, 0, 0}});

@@ -13,6 +13,7 @@ unsigned long long sim_wall_clock() {
     return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }
 static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, bytes); }
+static void be_fill_ff_async(void* p, size_t bytes, void*) { std::memset(p, 0xff, bytes); }
 typedef void* stream_t;
 static int be_device_count() { return 1; }
 static void be_set_device(int) {}

@@ -491,6 +491,27 @@ def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeyp
     assert all(np.array_equal(x, y) for x, y in zip(a, c))
 
 
+def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
+    """bioik_solve_params::island_sync = 1 on the device: islands of a query that run in different workgroups at different times, the answer still the
+    oracle's lock-step answer bit for bit (an island leaves early only when its result can no longer be chosen)"""
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=64, pop=128, steps_list=(24,), islands=4, island_sync=1, seed=3)
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=40, pop=16, steps_list=(40,), islands=3, island_sync=1, fk_mode=abi.FK_LINEAR, seed=4)
+    pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=16, pop=128, steps_list=(8,), islands=2, island_sync=1)
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=16, pop=8, steps_list=(40,), islands=8, island_sync=1, mode="gd_c")
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=32, pop=128, steps_list=(24,), islands=2, island_sync=1, schedule="throughput")
+    monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "2,5")
+    pc.trajectory(gpus["c2"], oracles["c2"], templates["c2"], n=64, pop=128, steps_list=(24,), islands=4, island_sync=1, seed=3)
+    monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE")
+    # a full-size batch: fewer steps than with independent islands, the same successes, and the same answer twice
+    h, t = gpus["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 2048, seed=37)
+    a = h.solve_batch(abi.default_solve_params(population=128, max_steps=48, random_seed=2, islands=4), seeds, params)
+    b = h.solve_batch(abi.default_solve_params(population=128, max_steps=48, random_seed=2, islands=4, island_sync=1), seeds, params)
+    c = h.solve_batch(abi.default_solve_params(population=128, max_steps=48, random_seed=2, islands=4, island_sync=1), seeds, params)
+    assert np.array_equal(a[2], b[2]) and np.all(b[3] <= a[3]) and b[3].mean() < a[3].mean()
+    assert all(np.array_equal(x, y) for x, y in zip(b, c))
+
+
 def test_sharded_batch_equals_whole_batch(gpus, templates):
     """the multi-GPU split: shards solved separately with their query offsets reproduce the unsharded batch"""
     h, t = gpus["c2"], templates["c2"]

@@ -364,6 +364,27 @@ def test_kernels_compiled_for_one_mapping(sims, oracles, templates, monkeypatch)
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
 
 
+def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
+    """bioik_solve_params::island_sync = 1: "any island succeeds => all stop" (ik_parallel.h:102, 160-178) in lock step -- the answer is the best of the
+    islands that passed after the LEAST number of steps, whatever the other islands went on to find; bit for bit the oracle's, under one launch and under
+    hand-overs, for the evolution and for the gradient family (the reference's gd_4: four solver threads)"""
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=6, pop=32, steps_list=(12,), islands=3, island_sync=1, seed=3)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=3, pop=16, steps_list=(30,), islands=4, island_sync=1, fk_mode=abi.FK_LINEAR, seed=4)
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=24, steps_list=(6,), islands=2, island_sync=1)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=3, pop=8, steps_list=(25,), islands=4, island_sync=1, mode="gd_c")
+    monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "2,5")
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=6, pop=32, steps_list=(12,), islands=3, island_sync=1, seed=3)
+    # the two selection rules do differ: somewhere an island that passes later has the better fitness
+    from bio_ik_amd.workload import make_queries
+    h, t = sims["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 24, seed=3)
+    a = h.solve_batch(abi.default_solve_params(population=32, max_steps=16, random_seed=5, islands=3, island_sync=0), seeds, params)
+    b = h.solve_batch(abi.default_solve_params(population=32, max_steps=16, random_seed=5, islands=3, island_sync=1), seeds, params)
+    assert np.array_equal(a[2], b[2]) and np.all(b[3] <= a[3]) and np.any(b[3] < a[3])
+    with pytest.raises(Exception):
+        h.solve_batch(abi.default_solve_params(islands=2, island_sync=2), seeds[:1], params[:1])
+
+
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):
     """joints without any range: every child of a generation is the same genotype, so every fitness of a generation is the same number and
     the elitist selection is decided by position alone (ik_evolution_2.cpp:410-431) -- the tie path of the wavefront-minimum top-2

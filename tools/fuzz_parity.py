@@ -79,6 +79,8 @@ def main():
         if rng.random() < 0.3:  # the solve split over two or more launches (round 2), under whatever mapping was drawn above
             env["BIOIK_SOLVE_TWO_PHASE"] = str(rng.choice(["1", "2", "3", "1,2", "2,4,6", "init"]))
         kw = {"no_wipeout": int(rng.random() < 0.2), "schedule": int(rng.random() < 0.25)}  # (schedule: BIOIK_SCHEDULE_THROUGHPUT where its mapping exists)
+        if islands > 1 and rng.random() < 0.5:
+            kw["island_sync"] = 1  # (round 4: the islands of a query stop once one of them has passed)
         seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=int(rng.integers(1 << 30)), kind=str(rng.choice(["global", "tracking"])))
         p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=int(rng.integers(1 << 30)), mode=mode, fk_mode=fk, islands=islands, **kw)
         old = {k: os.environ.get(k) for k in env}
@@ -95,7 +97,7 @@ def main():
         ok = np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1]) and np.array_equal(sa[2], sb[2]) and np.array_equal(sa[3], sb[3])
         bad += 0 if ok else 1
         print("%-3d %-9s pop=%-3d %-15s fk=%d islands=%d steps=%d n=%-2d sched=%d %-60s %s" %
-              (case, name, pop, mode, fk, islands, steps, n, kw["schedule"], str(env), "ok" if ok else "MISMATCH max|dx|=%g" % np.abs(sa[0] - sb[0]).max()), flush=True)
+              (case, name, pop, mode, fk, islands + 10 * kw.get("island_sync", 0), steps, n, kw["schedule"], str(env), "ok" if ok else "MISMATCH max|dx|=%g" % np.abs(sa[0] - sb[0]).max()), flush=True)
     print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
     sys.exit(1 if bad else 0)
 
