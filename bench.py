@@ -664,22 +664,24 @@ def main():
                 import threading
                 refs = [ref.Reference(template, pr, release=flavour) for _ in range(nt)]
                 bounds = [(i * BATCH) // nt for i in range(nt + 1)]
-                reps = max(1, int(seconds * cb["value"] * nt / BATCH * 0.6))  # (passes over the batch: the one-thread rate x threads, derated for shared caches)
                 got = [0.0] * nt
 
-                def work(i):
-                    lo, hi = bounds[i], bounds[i + 1]
-                    if hi <= lo:
-                        return
-                    for _ in range(reps):
-                        got[i] += float(refs[i].solve_batch(seeds[lo:hi], params[lo:hi], 512)[2].sum())
+                def run(reps):
+                    def work(i):
+                        lo, hi = bounds[i], bounds[i + 1]
+                        for _ in range(reps if hi > lo else 0):
+                            got[i] += float(refs[i].solve_batch(seeds[lo:hi], params[lo:hi], 512)[2].sum())
+                    t1 = time.perf_counter()
+                    th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+                    [t.start() for t in th]
+                    [t.join() for t in th]
+                    return time.perf_counter() - t1
                 for i in range(nt):
                     refs[i].solve_batch(seeds[:1], params[:1], 8)
-                t1 = time.perf_counter()
-                th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
-                [t.start() for t in th]
-                [t.join() for t in th]
-                dtp = time.perf_counter() - t1
+                reps = max(1, min(2000, int(seconds / max(run(2) / 2.0, 1e-4))))  # (two untimed passes set the number of timed ones: the cores share caches and memory)
+                for i in range(nt):
+                    got[i] = 0.0
+                dtp = run(reps)
                 return {"value": sum(got) / dtp, "cores": nt, "seconds": dtp, "passes_over_the_batch": reps,
                         "sample": "the same 4096 queries split over %d host threads (all of them), one reference solver object each, %d passes" % (nt, reps)}
             try:

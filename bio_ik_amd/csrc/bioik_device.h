@@ -1246,6 +1246,50 @@ BIOIK_DEV ChildX<PB> make_child_x(PB pb, uint32_t key, uint32_t ctr1, uint32_t c
     c.gradient_factor = (double)(child_index % 3u);
     return c;
 }
+// The same child with the mix of the parents' momentum read from a table: `parent_gradient = d0 * (1 - fmix) + d1 * fmix` has TWO forms per op in a
+// generation (child index even: fmix = 0.2, odd: 0), built once per species and generation by the very operations ChildX performs per gene and
+// child (child_parent_gradient).  A lane that walks several children of a generation then reads one number instead of two and spends one FP64
+// instruction (x gradient_factor) instead of four per gene and child; the child's accessor shrinks by five registers.  The table takes 2 M doubles
+// of the species' OTHER elite buffer, which nobody reads or writes between the start of a generation and its winner copy.
+BIOIK_DEV double child_parent_gradient(double d0, double d1, int parity) {  // parity: child_index % 2
+    BIOIK_FP_STRICT
+    const double fmix = parity == 0 ? 0.2 : 0.0;
+    return d0 * (1.0 - fmix) + d1 * fmix;
+}
+template <class PB>
+struct ChildT {
+    PB pb;
+    const double *p0g, *pgrow;  // LDS, op-indexed: genes of parent 0; the row of the table for this child's parity
+    uint32_t base;
+    double mutation_rate, gradient_factor;
+    BIOIK_DEV double operator()(int k) const {
+        BIOIK_FP_STRICT
+        const int g = pb->ops[k].gene;
+        const double parent_gene = p0g[k];
+        if (g < 0) return parent_gene;
+        const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
+        const uint32_t word = rng_mix32(base + (uint32_t)(g + 1) * 0x9E3779B1u);
+        double r = rng_gauss32(word);
+        double f = mutation_rate * span;
+        double gn = parent_gene;
+        gn += r * f;
+        double g2 = pgrow[k] * gradient_factor;
+        gn += g2;
+        gn = p_clamp_uniform(gn, cmin, cmax);
+        return gn;
+    }
+};
+// pgtable: LDS, [2][M] (row = child_index % 2)
+template <class PB>
+BIOIK_DEV ChildT<PB> make_child_t(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* pgtable, int M) {
+    ChildT<PB> c;
+    c.pb = pb, c.p0g = p0g;
+    c.pgrow = pgtable + (int)(child_index % 2u) * M;
+    c.base = (child_index << 8) * 0x9E3779B1u + rng_child_stream(key, ctr1);
+    c.mutation_rate = (double)(1u << (rng_mix32(c.base) & 15u)) * (1.0 / (double)(1 << 23));
+    c.gradient_factor = (double)(child_index % 3u);
+    return c;
+}
 // the elite with ONE gene advanced by a step (the memetic phase's finite differences), read where it is needed
 struct PerturbX {
     const double* el;

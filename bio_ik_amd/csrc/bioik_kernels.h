@@ -520,6 +520,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
+                if constexpr (FIXED != 0) {
+                    // the two forms of the parents' mixed momentum (ChildT), lane k the column of op k, into the species' other elite buffer
+                    double* const pgt = popS + (S.cur ^ 1) * BF;
+                    for (int k = gtid; k < n_ops; k += G) {
+                        const double d0 = p0d[k], d1 = p1d[k];
+                        pgt[k] = child_parent_gradient(d0, d1, 0), pgt[M + k] = child_parent_gradient(d0, d1, 1);
+                    }
+                    group_sync(G);
+                }
                 if (has_sec) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
                     if (columnless && lambda >= 4 * G) {  // four children per lane and trip: four independent hash -> Gaussian -> clip -> cost chains
@@ -527,10 +536,17 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             int cj[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) cj[j] = c + j * G < lambda ? c + j * G : c;  // (a tail repeats the first child and drops it)
-                            const ChildX<PB> cx[4] = {make_child_x(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, p0d, p1d),
-                                                      make_child_x(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, p0d, p1d)};
                             double e[4];
-                            secondary_fitness_n<4>(pb, cx, qc, e);
+                            if constexpr (FIXED != 0) {
+                                const double* const pgt = popS + (S.cur ^ 1) * BF;
+                                const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
+                                                          make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
+                                secondary_fitness_n<4>(pb, cx, qc, e);
+                            } else {
+                                const ChildX<PB> cx[4] = {make_child_x(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, p0d, p1d),
+                                                          make_child_x(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, p0d, p1d)};
+                                secondary_fitness_n<4>(pb, cx, qc, e);
+                            }
 #pragma unroll
                             for (int j = 0; j < 4; j++)
                                 if (c + j * G < lambda) s_sec[c + j * G] = e[j];
@@ -654,10 +670,17 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const int ra = r < n_eval ? r : 0, rb = two ? r1 : ra;  // (a lane without a child in this trip walks a copy and drops it)
                                 const int c0 = has_sec ? s_order[ra] : ra, c1 = has_sec ? s_order[rb] : rb;
                                 const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);  // (= ctr1, from the record: the stream's hash is not carried over the walks)
-                                const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
-                                PHASE_MARK(PH_REPRODUCE);
                                 // (FIXED: the launcher hands these kernels serial chains only, DevProblem::serial_chain -- the usual robot arm: one chain, nothing parked)
-                                eval_exact_primary_n<2, true, FIXED != 0>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                                if constexpr (FIXED != 0) {
+                                    const double* const pgt = popS + (S.cur ^ 1) * BF;  // (the table of the parents' mixed momentum, built where the generation begins)
+                                    const ChildT<PB> cx[2] = {make_child_t(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, pgt, M)};
+                                    PHASE_MARK(PH_REPRODUCE);
+                                    eval_exact_primary_n<2, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
+                                } else {
+                                    const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, p0d, p1d)};
+                                    PHASE_MARK(PH_REPRODUCE);
+                                    eval_exact_primary_n<2, true, FIXED != 0>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                                }
                             }
                             BIOIK_LANE_SCOPE;
                             const int r = r0 + gtid, r1 = r + G;
