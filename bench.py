@@ -583,7 +583,7 @@ def main():
         for i in range(nfl):
             rstep(i)
         torch.cuda.synchronize(dev)
-        kr = 9
+        kr = max(3 * nfl, args.steps)  # (as many timed launches as the headline: a 512-step budget makes the last stragglers of every launch a 40 ms tail that few launches cannot amortise)
         t1 = time.perf_counter()
         for i in range(kr):
             rstep(i)
@@ -592,7 +592,7 @@ def main():
         rsuc = bufs[0][2].cpu().numpy()
         out["reference_parameters"] = {"value": float(rsuc.sum()) / dtr, "unit": "solves/s", "ms_per_step": dtr * 1e3, "success_rate": float(rsuc.mean()),
                                        "mean_steps_per_solve": float(bufs[0][3].cpu().numpy().mean()), "population": 16, "fk": "linear", "max_steps": 512,
-                                       "batches_in_flight": nfl}
+                                       "batches_in_flight": nfl, "batches_timed": kr}
 
     if rank == 0 and world == 1 and not args.timed_only:
         # The "tracking" workload of SURVEY.md section 8(d) (seed = target + N(0, 0.1 rad), as the reference's ik_test does): same

@@ -138,6 +138,14 @@ __global__ void __launch_bounds__(64, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_c
     extern __shared__ double lds[];
     solve_body<true, true, true>(a, blockIdx.x, lds);
 }
+// Populations of up to 32 children per species with LINEARISED phenotypes (the reference's own parameters: 16 children, RobotFK_Mutator): both species on
+// the halves of one wavefront, children computed where they are read, under the register budget of four wavefronts per SIMD (solve_body<.., FIXED = 3>).
+// Such solves are bound by the latency of their single-individual phases (linearisation, line search, ranking), not by arithmetic: sixteen queries
+// per CU instead of twelve (profiles/r04_ab_small_population_kernel.log)
+__global__ void __launch_bounds__(64, 4) k_solve_lean_lin(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true, false, true, 3>(a, blockIdx.x, lds);
+}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -184,6 +192,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_lin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -497,6 +506,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2, exact) <= 64 * 1024) ? 1 : 0;
         if (sw.child_pairs == 0) sp.child_pairs = 0;
     }
+    // small populations, linearised phenotypes (the reference's own parameters), both species on the halves of one wavefront: children computed where
+    // they are read, and the kernel compiled for exactly that (k_solve_lean_lin: sixteen queries per CU)
+    const bool small_linear = !manual && !sw.three_waves && can_columnless && !exact && nth == 64 && sp.species_parallel && sp.lambda <= 32 && sp.solver == 0;
+    if (small_linear) sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 0;
     // BIOIK_SCHEDULE_THROUGHPUT: the whole solve under the mapping that retires most steps per ms on a full chip -- both species of a query on the
     // halves of one wavefront, children computed where they are read and scored in pairs (the first launch's mapping of the two-launch solve
     // below) -- for callers that keep six or more batches in flight (include/bioik_hip.h; profiles/r03_inflight_and_schedule.log)
@@ -559,11 +572,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
                            !sw.no_joint;
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
+        const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
-                         !lean ? "k_solve" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
                          lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
-        if (lean && args.sp.columnless && joint)
+        if (lean && lin_launch)
+            LAUNCH(k_solve_lean_lin, (solve_body<true, true, false, true, 3>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean && args.sp.columnless && joint)
             LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && dense_launch)
             // the whole solve of a stream of batches under the dense mapping: sixteen queries per CU instead of twelve (+11 % with six solves in flight;

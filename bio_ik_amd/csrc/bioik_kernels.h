@@ -318,13 +318,14 @@ struct SpeciesState {
 // and filed where it ends, so that nothing of it lives in registers -- or, under that budget, in scratch memory -- across the chain walks (the
 // record's reads are then LDS reads; a species group is one wavefront or half of one in the mappings that run under this budget, so the
 // hand-over is a wavefront-level rendezvous, not a barrier)
-// FIXED: what the launcher guarantees for the two kernels under the 128-register budget is known at compile time (the runtime switches of the other
+// FIXED: what the launcher guarantees for the kernels under the smaller register budgets is known at compile time (the runtime switches of the other
 // instantiations cost them registers and code):  1 = 64 lanes, the species on the halves of ONE wavefront, exact FK, children computed where they are
 // read and walked in pairs, no secondary goal (k_solve_lean_cl64w4);  2 = 128 lanes, a wavefront per species, exact FK, computed children in pairs,
-// secondary goals allowed (k_solve_lean_cl4)
+// secondary goals allowed (k_solve_lean_cl4);  3 = 64 lanes, the species on the halves of one wavefront, LINEARISED phenotypes, one computed child per
+// lane and trip (k_solve_lean_lin: populations of up to 32 children per species -- the reference's own parameters)
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
-    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2;
+    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, HALVES = DENSE || LIN;
     static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
@@ -337,22 +338,22 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
-    const int tid0 = p_tid(), nth = DENSE ? 64 : (WAVE2 ? 128 : p_nthreads());
+    const int tid0 = p_tid(), nth = HALVES ? 64 : (WAVE2 ? 128 : p_nthreads());
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
     const bool has_sec = DENSE ? false : pb->n_secondary > 0;
-    const bool exact = FIXED ? true : sp.fk_mode == FK_EXACT;
-    const bool child_pairs = FIXED ? true : sp.child_pairs != 0;
+    const bool exact = LIN ? false : (FIXED ? true : sp.fk_mode == FK_EXACT);
+    const bool child_pairs = LIN ? false : (FIXED ? true : sp.child_pairs != 0);
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
     constexpr bool columnless = CL;
     // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
     // workgroup splits into two lane groups that run one species each, concurrently (on different SIMDs of the CU).
     const int groups = FIXED ? 2 : (sp.species_parallel ? 2 : 1);
-    const int G = DENSE ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
-    const int g_shift = DENSE ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
+    const int G = HALVES ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
+    const int g_shift = HALVES ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
     const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
@@ -496,7 +497,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         const int rank_begin = groups == 2 ? (SLIM ? 0 : (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G)) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
         for (int rank_it = rank_begin; rank_it < rank_end; rank_it++) {
             // (DENSE: a half-wavefront runs the species of its own number, read off the lane number wherever it is needed: no register carries it)
-            auto rank_now = [&]() { return (SLIM && groups == 2) ? (DENSE ? p_lane_fresh() >> 5 : (WAVE2 ? p_wave_index() : (g_shift >= 0 ? p_tid_fresh() >> g_shift : p_tid_fresh() / G))) : rank_it; };
+            auto rank_now = [&]() { return (SLIM && groups == 2) ? (HALVES ? p_lane_fresh() >> 5 : (WAVE2 ? p_wave_index() : (g_shift >= 0 ? p_tid_fresh() >> g_shift : p_tid_fresh() / G))) : rank_it; };
             SpeciesState S = species_load(rank_now());
             double* popS = s_pop + S.slot * SP;
             if (!exact) {
@@ -520,7 +521,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
-                if constexpr (FIXED != 0) {
+                if constexpr (DENSE || WAVE2) {
                     // the two forms of the parents' mixed momentum (ChildT), lane k the column of op k, into the species' other elite buffer
                     double* const pgt = popS + (S.cur ^ 1) * BF;
                     for (int k = gtid; k < n_ops; k += G) {
@@ -537,7 +538,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
 #pragma unroll
                             for (int j = 0; j < 4; j++) cj[j] = c + j * G < lambda ? c + j * G : c;  // (a tail repeats the first child and drops it)
                             double e[4];
-                            if constexpr (FIXED != 0) {
+                            if constexpr (DENSE || WAVE2) {
                                 const double* const pgt = popS + (S.cur ^ 1) * BF;
                                 const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
                                                           make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
@@ -671,7 +672,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const int c0 = has_sec ? s_order[ra] : ra, c1 = has_sec ? s_order[rb] : rb;
                                 const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);  // (= ctr1, from the record: the stream's hash is not carried over the walks)
                                 // (FIXED: the launcher hands these kernels serial chains only, DevProblem::serial_chain -- the usual robot arm: one chain, nothing parked)
-                                if constexpr (FIXED != 0) {
+                                if constexpr (DENSE || WAVE2) {
                                     const double* const pgt = popS + (S.cur ^ 1) * BF;  // (the table of the parents' mixed momentum, built where the generation begins)
                                     const ChildT<PB> cx[2] = {make_child_t(pb, key, ctr1t, (uint32_t)c0 + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1t, (uint32_t)c1 + 2u, p0g, pgt, M)};
                                     PHASE_MARK(PH_REPRODUCE);

@@ -1,5 +1,5 @@
 """Per-phase shader cycles of a solve of C3 / C4 (profiling build: hipcc ... -DBIOIK_PHASE_TIMING -o build/libphase.so).
-usage: BIOIK_HIP_LIBRARY=build/libphase.so python tools/phase_probe_config.py [c2|ref|c3|c4] [queries]"""
+usage: BIOIK_HIP_LIBRARY=build/libphase.so python tools/phase_probe_config.py [c2|ref|c3|c4] [queries] [latency|throughput]"""
 import os
 import sys
 
@@ -28,7 +28,8 @@ def main():
         t, pop, steps = ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]), 512, 8
     h = HipSolver(t, device=0)
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=5)
-    p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=1, fk_mode=abi.FK_LINEAR if cfg == "ref" else abi.FK_EXACT)
+    p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=1, fk_mode=abi.FK_LINEAR if cfg == "ref" else abi.FK_EXACT,
+                                 schedule=sys.argv[3] if len(sys.argv) > 3 else "latency")
     p.dtwist = 1e-300  # no query may succeed: every workgroup runs the whole budget
     path = "/tmp/phase_%s.bin" % cfg
     os.environ["BIOIK_PHASE_DUMP"] = path
