@@ -446,7 +446,16 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // children computed where they are read (no genotype columns in LDS): the lean flavour can, whenever it is chosen below
     const bool can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !sw.general_set;
     sp.columnless = 0;
-    if (!manual && nth == 128) {
+    // k_solve_lean_cl4's mapping first -- 128 lanes, a wavefront per species, children computed where they are read and walked in pairs, the kernel compiled
+    // for exactly that under the budget of four wavefronts per SIMD (no register spills since round 4): for problems without a secondary goal whose
+    // lanes get at least one pair of children per generation and whose LDS footprint lets sixteen wavefronts share a CU it beats the kernel with the
+    // children kept in columns on every count (C2: lone step 94 -> 91 us, fixed work at 4096 queries +30 %, three solves in flight +26 %, an isolated
+    // call +16 %: profiles/r04_ab_latency_schedule_kernel.log)
+    const bool prefer_cl4 = !manual && nth == 128 && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
+                            sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= 160 * 1024;
+    if (prefer_cl4) {
+        sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
+    } else if (!manual && nth == 128) {
         struct Cand {
             int nth, store, pairs, columnless;
         };
@@ -564,7 +573,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
         // (k_solve_lean_cl4 is compiled for exactly this mapping -- solve_body<.., FIXED = 2> --: 128 lanes, a wavefront per species, exact FK, children in pairs)
         const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT && dp.serial_chain != 0;
-        const bool four_waves = cl4_mapping && (((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && args.sp.lambda >= 8 * group_lanes && !sw.three_waves) ||
+        const bool four_waves = cl4_mapping && (((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && (args.sp.lambda >= 8 * group_lanes || prefer_cl4) && !sw.three_waves) ||
                                                 sw.four_waves);  // (diagnostic: the 128-register build wherever its mapping is the one in use)
         // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
         // (with a wavefront per species -- 128 lanes, C4 -- the same walk gains nothing: a wavefront that waits at a barrier costs no issue slots,
@@ -612,7 +621,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     } else if (throughput) {
         // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
         if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
-    } else if (halves_ok && !manual && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+        // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
+        // profiles/r04_ab_latency_schedule_kernel.log)
         handovers.push_back(1);
     }
 #if defined(BIOIK_PHASE_TIMING)
