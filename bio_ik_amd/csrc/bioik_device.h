@@ -339,8 +339,12 @@ BIOIK_DEV double goal_eval_joint_set_x(ProbPtr pb, int type, int var_op, int var
 // the same goals for N individuals at once (N independent dependency chains; per individual the operations and their order are those of
 // goal_eval_joint_set_x): the pre-selection scores every child of a generation on its secondary goals, and with the children computed
 // where they are read a gene is a hash, a Gaussian and a clip -- a long chain per gene that one individual at a time leaves exposed
+// inside_mask (wavefront-uniform; AvoidJointLimitsGoal only): bit k = op k of EVERY individual in x lies strictly inside the half of its range that
+// costs nothing (avoid_limits_surely_free) -- its term is `sum += 0`, which leaves a non-negative sum as it is, so the op is passed over without its
+// value being computed at all
 template <int N, class XA>
-BIOIK_DEV void goal_eval_joint_set_xn(ProbPtr pb, int type, int var_op, int var_seed, double p0, const XA (&x)[N], const lds_f64* seed, double (&out)[N]) {
+BIOIK_DEV void goal_eval_joint_set_xn(ProbPtr pb, int type, int var_op, int var_seed, double p0, const XA (&x)[N], const lds_f64* seed, double (&out)[N],
+                                      uint64_t inside_mask = 0ull) {
     const int n_ops = pb->n_ops;
     double sum[N];
 #pragma unroll
@@ -348,7 +352,7 @@ BIOIK_DEV void goal_eval_joint_set_xn(ProbPtr pb, int type, int var_op, int var_
     switch (type) {
         case G_AVOID_JOINT_LIMITS:
             for (int k = 0; k < n_ops; k++)
-                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
+                if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded && !((inside_mask >> k) & 1ull)) {
                     const double mid = (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5, half_span = pb->ops[k].span * 0.5, vw = pb->ops[k].vw;
 #pragma unroll
                     for (int j = 0; j < N; j++) {
@@ -524,8 +528,18 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XA& x, const QueryCtx& qc) 
     return sum;
 }
 // the same for N individuals at once (see goal_eval_joint_set_xn); per individual: the goals in their order, each weighted as above
+// AvoidJointLimitsGoal (goal_types.h:387-401) costs a variable nothing while it stays in the middle half of its range: |x - mid| * 2 <= span / 2.  A child's
+// gene is parent_gene + gauss * rate * span + parent_gradient * factor with |gauss| <= 4.41 (rng_gauss32: 2304 lattice steps of 0.4899 / 256), rate <= 2^-8
+// (ChildX: 2^(15 - 23)) and factor <= 2, clipped towards the inside afterwards: whenever the parent's gene is further inside the free zone than
+// 0.0173 span + 2 |parent_gradient| (+ a margin far above any rounding), EVERY child of the generation has that gene in the free zone.  True for about half
+// the genes of a typical elite -- and for those the pre-selection need not generate the children's values at all.
+BIOIK_DEV bool avoid_limits_surely_free(double parent_gene, double pg_even, double pg_odd, double vmin, double vmax, double span) {
+    const double mid = (vmin + vmax) * 0.5;
+    const double reach = 0.0173 * span + 2.0 * fmax(fabs(pg_even), fabs(pg_odd));
+    return fabs(parent_gene - mid) + reach < 0.25 * span * (1.0 - 1e-9);
+}
 template <int N, class XA>
-BIOIK_DEV void secondary_fitness_n(ProbPtr pb, const XA (&x)[N], const QueryCtx& qc, double (&out)[N]) {
+BIOIK_DEV void secondary_fitness_n(ProbPtr pb, const XA (&x)[N], const QueryCtx& qc, double (&out)[N], uint64_t inside_mask = 0ull) {
     const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
     for (int j = 0; j < N; j++) out[j] = 0.0;
@@ -535,7 +549,7 @@ BIOIK_DEV void secondary_fitness_n(ProbPtr pb, const XA (&x)[N], const QueryCtx&
         double e[N];
         if (type == G_AVOID_JOINT_LIMITS || type == G_CENTER_JOINTS || type == G_REGULARIZATION || type == G_MINIMAL_DISPLACEMENT || type == G_JOINT_VARIABLE) {
             const double* P = qc.par + pb->secondary[g].param_off;
-            goal_eval_joint_set_xn<N>(pb, type, pb->secondary[g].var_op, pb->secondary[g].var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, x, (const lds_f64*)qc.seed, e);
+            goal_eval_joint_set_xn<N>(pb, type, pb->secondary[g].var_op, pb->secondary[g].var_seed, type == G_JOINT_VARIABLE ? P[0] : 0.0, x, (const lds_f64*)qc.seed, e, inside_mask);
         } else {
 #pragma unroll
             for (int j = 0; j < N; j++)

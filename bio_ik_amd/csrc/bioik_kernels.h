@@ -521,13 +521,19 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t gctr = (uint32_t)step * 16u + (uint32_t)gen;
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
+                uint64_t inside_mask = 0ull;  // (WAVE2: the ops no child of this generation can take out of AvoidJointLimitsGoal's free zone)
                 if constexpr (DENSE || WAVE2) {
                     // the two forms of the parents' mixed momentum (ChildT), lane k the column of op k, into the species' other elite buffer
                     double* const pgt = popS + (S.cur ^ 1) * BF;
+                    bool inside = false;
                     for (int k = gtid; k < n_ops; k += G) {
                         const double d0 = p0d[k], d1 = p1d[k];
-                        pgt[k] = child_parent_gradient(d0, d1, 0), pgt[M + k] = child_parent_gradient(d0, d1, 1);
+                        const double pg0 = child_parent_gradient(d0, d1, 0), pg1 = child_parent_gradient(d0, d1, 1);
+                        pgt[k] = pg0, pgt[M + k] = pg1;
+                        if constexpr (WAVE2)
+                            inside = pb->ops[k].gene >= 0 && !pb->ops[k].unbounded && avoid_limits_surely_free(p0g[k], pg0, pg1, pb->ops[k].vmin, pb->ops[k].vmax, pb->ops[k].span);
                     }
+                    if constexpr (WAVE2) inside_mask = has_sec ? p_ballot(inside) : 0ull;  // (a group is one wavefront and an op a lane: at most 64 ops)
                     group_sync(G);
                 }
                 if (has_sec) {
@@ -542,7 +548,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const double* const pgt = popS + (S.cur ^ 1) * BF;
                                 const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
                                                           make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
-                                secondary_fitness_n<4>(pb, cx, qc, e);
+                                secondary_fitness_n<4>(pb, cx, qc, e, inside_mask);
                             } else {
                                 const ChildX<PB> cx[4] = {make_child_x(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, p0d, p1d),
                                                           make_child_x(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, p0d, p1d)};

@@ -23,12 +23,19 @@ for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_col
         steps = names[(closing, k)]
         out[k] = {"steps": steps, "mean_per_launch": v / steps, "per_kernel_mean": {kn: sum(c[k]) / len(c[k]) for kn, c in per_kernel.items() if k in c}}
 fk, wk = out["FETCH_SIZE"]["mean_per_launch"], out["WRITE_SIZE"]["mean_per_launch"]
-summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --timed-only --steps 5 --warmup 1 "
-                      "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*)", "kernel": "k_solve_lean_cl(SolveArgs) + k_solve_lean(SolveArgs): the two launches of one solve, counters summed per solve (`mean_per_launch`)", "counters": out,
+kernels_seen = sorted({kn for kn, _ in names})
+out.pop("dispatch", None)  # (rocprofv3's per-dispatch VGPR / LDS columns are allocation granules of the launch, not the code object's figures: those are in profiles/rNN_kernel_metadata.txt)
+summary = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --timed-only --steps 5 --warmup 1 --in-flight 1 "
+                      "(separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* ...; one solve at a time, so a dispatch's counters hold no neighbour's traffic)",
+           "kernel": " + ".join(kernels_seen) + ": the launch(es) of one solve, counters summed per solve (`mean_per_launch`)",
+           "kernel_metadata": "profiles/%s_kernel_metadata.txt (llvm-readelf --notes of the code object: registers, spilled registers, scratch bytes)" % rnd,
+           "counters": out,
            "hbm_bytes_per_launch": {"fetch_bytes_raw": fk * 1024, "fetch_bytes_corrected_x2_gfx950": 2 * fk * 1024, "write_bytes": wk * 1024,
                                     "total_corrected": 2 * fk * 1024 + wk * 1024,
                                     "note": "FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM) -> doubled; "
-                                            "WRITE_SIZE uncalibrated.  The query data are 1.4 MB; under BIOIK_SCHEDULE_THROUGHPUT the rest is the scratch traffic of the dense kernel's 128-register build (30 spilled values, written through to HBM and read back from L2; its 168-register build moves 3.9 MB), under BIOIK_SCHEDULE_LATENCY the hand-over state of the two-launch solve (13 MB in all)."}}
+                                            "WRITE_SIZE uncalibrated.  The query data of a 4096-query solve are 1.4 MB in and out; since round 4 no solve kernel of the "
+                                            "bench workload uses scratch memory (k_solve_lean_cl64w4 / k_solve_lean_cl4: 0 spilled registers), so what is measured beyond "
+                                            "the query data is the problem block and instruction / constant fetches."}}
 json.dump(summary, open(os.path.join(p, rnd + "_pmc_k_solve.json"), "w"), indent=1)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_sources_hash: the figure is valid for the kernel sources it was measured on, and bench.py checks that)
@@ -45,7 +52,7 @@ if isinstance(b.get("roofline"), dict):
     json.dump(b, open(os.path.join(p, rnd + "_bench.json"), "w"))
 for k in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES"):
     print(k, "%.4g" % out[k]["mean_per_launch"])
-print("hbm bytes/launch %.4g" % summary["hbm_bytes_per_launch"]["total_corrected"], out["dispatch"])
+print("hbm bytes/launch %.4g" % summary["hbm_bytes_per_launch"]["total_corrected"], kernels_seen)
 
 # k_stream_fitness: measured HBM bytes per launch (same unit corrections) next to the algorithmic bytes of the bench line
 sf = {}
