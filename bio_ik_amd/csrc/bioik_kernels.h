@@ -42,18 +42,21 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.xcol = o, o += m * nthreads * (child_cols >= 0 ? child_cols : 1);  // genotype columns: [col][op][lane]; none when children are computed where they are read
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
     int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
+    // The per-joint frame chain [m][7] is read by the Jacobian columns right after the walk that publishes it and never again (build_approximator);
+    // the line-search vectors (9 m doubles) are written after that: the chain lies on top of them (round 4: 7 m doubles per group less, which is
+    // what lets a CU hold 15 instead of 13 queries of the two-armed problem)
+    L.frames = g;
     L.xn = g, g += m;
     L.gv = g, g += m;
-    L.frames = g, g += m * 7;
-    L.tips = g, g += T * 7;
-    L.delta = g, g += T * m * 7;
-    L.base = g, g += m;
     L.grad = g, g += m;
     L.xm = g, g += m;
     L.xp = g, g += m;
     L.dv = g, g += 4 * m;
     g += g & 1;  // (two-double alignment of the component blocks)
     L.fc = g, g += 4 * 8 * (T > 0 ? T : 1);
+    L.tips = g, g += T * 7;
+    L.delta = g, g += T * m * 7;
+    L.base = g, g += m;
     // has_secondary == 2: the pre-selection scratch of the generation loop shares the space of the memetic phase's vectors and
     // linear model (exact-FK generations never read the linear model, and both are rebuilt before every use)
     int n_sort = 2;  // the pre-selection sorts its lambda children in a power-of-two array (solve_body)
@@ -1251,9 +1254,10 @@ BIOIK_DEV void eval_fitness_body(const EvalArgs& a, uint64_t block, double* lds)
     load_query(a, lds + L.seed, lds + L.par);
     const QueryCtx qc{lds + L.seed, lds + L.par};
     if (a.fk_mode == FK_LINEAR) {
-        if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.g_first + L.xn, 1);
+        // (the base configuration sits in the solution's slot: the line-search vectors lie under the frame chain, make_layout)
+        if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.sol, 1);
         p_barrier();
-        build_approximator(pb, XV{lds + L.g_first + L.xn, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
+        build_approximator(pb, XV{lds + L.sol, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
                            lds + L.g_first + L.base, tid, nth);
     }
     const LinModel lm{lds + L.g_first + L.tips, lds + L.g_first + L.delta, lds + L.g_first + L.base};
@@ -1272,9 +1276,9 @@ BIOIK_DEV void eval_approximator_body(const EvalArgs& a, double* lds) {
     const int tid = p_tid(), nth = p_nthreads();
     const LdsLayout L = make_layout(pb->n_ops, pb->V, pb->P, pb->T, pb->n_slots, nth, 0, 0);
     load_query(a, lds + L.seed, lds + L.par);
-    if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.g_first + L.xn, 1);
+    if (tid == 0) load_genotype(pb, lds + L.seed, a.base, lds + L.sol, 1);
     p_barrier();
-    build_approximator(pb, XV{lds + L.g_first + L.xn, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
+    build_approximator(pb, XV{lds + L.sol, 1}, lds + L.slots, lds + L.g_first + L.frames, lds + L.g_first + L.tips, lds + L.g_first + L.delta,
                            lds + L.g_first + L.base, tid, nth);
     const int T = pb->T, D = pb->D, n_ops = pb->n_ops;
     for (int idx = tid; idx < T * 7; idx += nth) {
