@@ -146,6 +146,12 @@ __global__ void __launch_bounds__(64, 4) k_solve_lean_lin(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, false, true, 3>(a, blockIdx.x, lds);
 }
+// The joint walk under the register budget of four wavefronts per SIMD (solve_body<.., FIXED = 4>: fitness values parked in LDS, accessors rebuilt behind
+// the walks): picked where a CU's LDS holds more than the twelve queries k_solve_lean_clj's 135 ... 168 registers allow
+__global__ void __launch_bounds__(64, 4) k_solve_lean_clj4(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true, true, true, 4>(a, blockIdx.x, lds);
+}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -193,6 +199,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_lin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -580,14 +587,17 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // profiles/r03_ab_joint_walk.log)
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
                            !sw.no_joint;
+        const bool joint4 = joint && !sw.three_waves && (160 * 1024 / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
-                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj" : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? (joint4 ? "k_solve_lean_clj4" : "k_solve_lean_clj") : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
                          lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
         if (lean && lin_launch)
             LAUNCH(k_solve_lean_lin, (solve_body<true, true, false, true, 3>(args, b_, l_)), units, lanes, lds_b, stream, args);
+        else if (lean && args.sp.columnless && joint && joint4)
+            LAUNCH(k_solve_lean_clj4, (solve_body<true, true, true, true, 4>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && joint)
             LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && dense_launch)

@@ -284,7 +284,7 @@ struct SpeciesState {
 // computes its LDS addresses where it uses them instead of inheriting them from in front of the step loop, where the compiler had
 // parked them in scratch memory (r02: 36 spilled VGPRs, every one of them an address of this kind).
 #define BIOIK_LANE_SCOPE                                                                                                            \
-    const int tid = SLIM ? p_tid_fresh() : p_fresh(tid0); /* (the lane number, from a copy kept across the phases or (SLIM) computed afresh; group and index inside it follow from it) */ \
+    const int tid = HALVES ? p_lane_fresh() : (SLIM ? p_tid_fresh() : p_fresh(tid0)); /* (the lane number, from a copy kept across the phases or (SLIM) computed afresh -- HALVES: the workgroup is one wavefront; group and index inside it follow from it) */ \
     const int grp = g_shift >= 0 ? tid >> g_shift : tid / G, gtid = tid - grp * G;                                                  \
     double* const gbase = lds + L.g_first + grp * L.g_stride; /* this group's scratch */                                            \
     double* const s_xn = gbase + L.xn;                                                                                              \
@@ -325,10 +325,12 @@ struct SpeciesState {
 // instantiations cost them registers and code):  1 = 64 lanes, the species on the halves of ONE wavefront, exact FK, children computed where they are
 // read and walked in pairs, no secondary goal (k_solve_lean_cl64w4);  2 = 128 lanes, a wavefront per species, exact FK, computed children in pairs,
 // secondary goals allowed (k_solve_lean_cl4);  3 = 64 lanes, the species on the halves of one wavefront, LINEARISED phenotypes, one computed child per
-// lane and trip (k_solve_lean_lin: populations of up to 32 children per species -- the reference's own parameters)
+// lane and trip (k_solve_lean_lin: populations of up to 32 children per species -- the reference's own parameters);  4 = 64 lanes, halves, exact FK,
+// secondary goals, the pre-selected children of both species walked as one list (JOINT; k_solve_lean_clj4)
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
-    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, HALVES = DENSE || LIN;
+    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, JH = FIXED == 4, HALVES = DENSE || LIN || JH;
+    static_assert(FIXED != 4 || JOINT, "FIXED = 4 is the joint walk of both species' children (64 lanes, halves, exact FK, secondary goals: k_solve_lean_clj4)");
     static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
     static_assert(LEAN || !CL, "computed children: lean flavour only (quaternion genes are renormalised in place)");
@@ -347,7 +349,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
-    const bool has_sec = DENSE ? false : pb->n_secondary > 0;
+    const bool has_sec = DENSE ? false : (JH ? true : pb->n_secondary > 0);
     const bool exact = LIN ? false : (FIXED ? true : sp.fk_mode == FK_EXACT);
     const bool child_pairs = LIN ? false : (FIXED ? true : sp.child_pairs != 0);
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
@@ -642,6 +644,53 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         const int32_t* const ord[2] = {(const int32_t*)(lds + L.g_first + L.order), (const int32_t*)(lds + L.g_first + L.g_stride + L.order)};
                         double t1f[2] = {P_INF, P_INF}, t2f[2] = {P_INF, P_INF};  // the lane's best two per species
                         int t1p[2] = {0x7fffffff, 0x7fffffff}, t2p[2] = {0x7fffffff, 0x7fffffff};
+                        if constexpr (SLIM) {
+                            // (fit_park, as in the other kernels of the 128-register budget: every item's fitness goes to ITS species' array in LDS; when the
+                            // walks are over a half reads its own species' entries back and reduces them inside the half)
+                            for (int t0 = 0; t0 < total; t0 += 128) {
+                                double f[2];
+                                {
+                                    BIOIK_LANE_SCOPE;
+                                    const int i0r = t0 + tid, i0 = i0r < total ? i0r : 0, i1 = i0r + 64 < total ? i0r + 64 : i0;
+                                    const int sp0 = i0 >= ne0 ? 1 : 0, sp1 = i1 >= ne0 ? 1 : 0;
+                                    const int r0 = i0 - (sp0 ? ne0 : 0), r1 = i1 - (sp1 ? ne0 : 0);
+                                    // (the other species' order array: base + species x stride, not a select between two addresses -- those would be two
+                                    // registers that live as long as the kernel)
+                                    const int32_t* const ord0 = (const int32_t*)(lds + L.g_first + L.order);
+                                    const int c0 = ord0[sp0 * 2 * L.g_stride + r0], c1 = ord0[sp1 * 2 * L.g_stride + r1];
+                                    const double *pa = lds + (sp0 ? cbo[1] : cbo[0]), *pc = lds + (sp1 ? cbo[1] : cbo[0]);
+                                    const ChildX<PB> cx[2] = {make_child_x(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, pa + M, pa + 3 * M),
+                                                              make_child_x(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, pc + M, pc + 3 * M)};
+                                    PHASE_MARK(PH_REPRODUCE);
+                                    eval_exact_primary_n<2, true>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
+                                    PHASE_MARK(PH_FITNESS);
+                                }
+                                BIOIK_LANE_SCOPE;
+                                const int i0r = t0 + tid, i0 = i0r < total ? i0r : 0, i1 = i0r + 64 < total ? i0r + 64 : i0;
+                                const int sp0 = i0 >= ne0 ? 1 : 0, sp1 = i1 >= ne0 ? 1 : 0;
+                                const int r0 = i0 - (sp0 ? ne0 : 0), r1 = i1 - (sp1 ? ne0 : 0);
+                                if (pb->n_link_primary < pb->n_primary) {  // (primary goals over the joint values: the accessors are built again behind the walk)
+                                    const int32_t* const ord0 = (const int32_t*)(lds + L.g_first + L.order);
+                                    const int c0 = ord0[sp0 * 2 * L.g_stride + r0], c1 = ord0[sp1 * 2 * L.g_stride + r1];
+                                    const double *pa = lds + (sp0 ? cbo[1] : cbo[0]), *pc = lds + (sp1 ? cbo[1] : cbo[0]);
+                                    const ChildX<PB> cx[2] = {make_child_x(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, pa + M, pa + 3 * M),
+                                                              make_child_x(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, pc + M, pc + 3 * M)};
+                                    f[0] += nonlink_primary(pb, cx[0], qc), f[1] += nonlink_primary(pb, cx[1], qc);
+                                } else {
+                                    f[0] += 0.0, f[1] += 0.0;
+                                }
+                                f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc), f[1] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
+                                if (i0r < total) (lds + L.g_first + sp0 * L.g_stride + L.fitp)[r0] = f[0];
+                                if (i0r + 64 < total) (lds + L.g_first + sp1 * L.g_stride + L.fitp)[r1] = f[1];
+                            }
+                            p_wave_sync();
+                            {
+                                BIOIK_LANE_SCOPE;
+                                const double* const s_fit2 = gbase + L.fitp;
+                                const int ne_own = grp ? total - ne0 : ne0;
+                                for (int r = gtid; r < ne_own; r += G) offer(s_fit2[r], r + 2);
+                            }
+                        } else {
                         for (int i0 = tid; i0 < total; i0 += 128) {
                             const int i1 = i0 + 64 < total ? i0 + 64 : i0;  // (an odd tail repeats the first item and drops it)
                             const int sp0 = i0 >= ne0 ? 1 : 0, sp1 = i1 >= ne0 ? 1 : 0;
@@ -665,6 +714,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         top2_wave64_minima(t1f[0], t1p[0], t2f[0], t2p[0]);
                         top2_wave64_minima(t1f[1], t1p[1], t2f[1], t2p[1]);
                         b1f = grp ? t1f[1] : t1f[0], b1p = grp ? t1p[1] : t1p[0], b2f = grp ? t2f[1] : t2f[0], b2p = grp ? t2p[1] : t2p[0];
+                        }
                     }
                 } else if (!JOINT && columnless && child_pairs && exact) {
                     // two children per trip, both computed where they are read: two independent dependency chains per lane
@@ -759,7 +809,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 BIOIK_LANE_SCOPE;
                 if constexpr (SLIM) S = species_load(rank_now()), popS = s_pop + S.slot * SP, cb = popS + S.cur * BF, p0g = cb, p0d = cb + M, p1d = cb + 3 * M;
                 const uint32_t ctr1w = SLIM ? rng_ctr1((uint32_t)step * 16u + (uint32_t)gen, (uint32_t)S.id, RNG_REPRODUCE) : ctr1;  // (the winners' stream: not carried through the walks under SLIM)
-                if (!JOINT) top2_wave(b1f, b1p, b2f, b2p, G);  // (the joint walk has reduced over the whole wavefront already)
+                // (the joint walk has reduced over the whole wavefront already; under SLIM it parks its values like the other walks, and the reduction
+                // inside the half stands here, between the lanes' reads of the species record above and its update below)
+                if (!JOINT || SLIM) top2_wave(b1f, b1p, b2f, b2p, G);
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 PHASE_MARK(PH_SEL_XWAVE);
@@ -835,6 +887,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 S.pf1 = second.f;
                 if constexpr (SLIM)
                     if (gtid == 0) species_store(rank_now(), S);
+                group_sync(G);
                 PHASE_MARK(PH_SEL_COPY);
                 group_sync(G);
                 PHASE_MARK(PH_SEL_BAR);

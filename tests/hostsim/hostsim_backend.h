@@ -48,6 +48,13 @@ static int next_unfinished(int me) {
     while (fib.done[nx] && nx != me);
     return nx;
 }
+static unsigned long long n_site_mismatches = 0;  // (relaxed: a diagnostic counter read by the tests between launches)
+void site_mismatch(int first, int now) {
+    // (the second rendezvous of a two-phase collective carries the negated line)
+    if (__atomic_fetch_add(&n_site_mismatches, 1ull, __ATOMIC_RELAXED) < 8)
+        std::fprintf(stderr, "[hostsim] divergent collective: lane %d of workgroup %d arrived from line %d at a rendezvous opened from line %d\n", tid, blk->block_id, now, first);
+    if (std::getenv("BIOIK_HOSTSIM_SITES_FATAL")) std::abort();
+}
 void yield() {
     const int me = tid, nx = next_unfinished(me);
     if (nx == me) return;
@@ -73,7 +80,13 @@ static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body
         blk.nthreads = block;
         blk.block_id = (int)b;
         blk.bar.n = block;
-        blk.wave_bar.assign((size_t)(block / 64), sim::Rendezvous{64, 0, 0u});
+        blk.bar.rounds.assign((size_t)block, 0ull);
+        {
+            sim::Rendezvous of_a_wave;
+            of_a_wave.n = 64;
+            of_a_wave.rounds.assign((size_t)block, 0ull);
+            blk.wave_bar.assign((size_t)(block / 64), of_a_wave);
+        }
         blk.xchg.assign((size_t)block, 0);
         f.n = f.alive = block;
         f.ctx.assign((size_t)block, ucontext_t());
@@ -94,3 +107,20 @@ static void be_launch(uint64_t grid, int block, size_t lds_bytes, stream_t, Body
 }
 #define LAUNCH(KERNEL, BODYCALL, grid, block, lds, stream, args) be_launch(grid, block, lds, stream, [&](uint64_t b_, double* l_) { BODYCALL; })
 static void be_allow_lds(size_t) {}
+// What the tests read of the simulator itself (tests/test_hostsim_parity.py): how often lanes met at DIFFERENT collectives so far -- on the device that
+// is a silent exchange of garbage --, and a launch that does it on purpose (odd lanes synchronise from another line than even ones)
+extern "C" unsigned long long hostsim_divergent_collectives() { return __atomic_load_n(&sim::n_site_mismatches, __ATOMIC_RELAXED); }
+extern "C" void hostsim_selftest_divergence(int diverge) {
+    be_launch(1, 64, 64, nullptr, [&](uint64_t, double* l) {
+        const int lane = p_tid();
+        l[0] = 0.0;
+        p_wave_sync();
+        if (diverge && (lane & 1)) {
+            p_wave_sync();
+        } else {
+            p_wave_sync();
+        }
+        const int sum = p_read_lane(lane, 63) + p_shfl_xor(lane, 1);  // (collectives from one line each: no report)
+        if (lane == 0) l[0] = (double)sum;
+    });
+}

@@ -16,13 +16,23 @@ typedef const DevProblem* ProbPtr;
 typedef const DevProblemLean* LeanProbPtr;
 
 namespace sim {
+extern thread_local int tid;
 struct Rendezvous {  // of `n` fibres of one OS thread
     int n = 0, arrived = 0;
     unsigned generation = 0;
+    int site = 0;  // source line of the collective the first lane of this round arrived from
+    unsigned long long round_of_first = 0;  // how many rounds of THIS rendezvous that lane has been to
+    std::vector<unsigned long long> rounds;  // per lane of the workgroup
 };
+void site_mismatch(int first, int now);  // (hostsim_backend.h) lanes of one wavefront / workgroup met at DIFFERENT collectives: a divergent collective
 void yield();  // to the next unfinished lane of the workgroup (hostsim_backend.h)
-inline void arrive_and_wait(Rendezvous& r) {
+// `site`: the source line of the collective (every p_* collective passes its caller's line on, __builtin_LINE): on the device lanes that
+// reach different collectives exchange garbage silently; here the round's first arrival names the site and every other arrival must agree
+inline void arrive_and_wait(Rendezvous& r, int site) {
     const unsigned g = r.generation;
+    const unsigned long long mine = ++r.rounds[tid];
+    if (r.arrived == 0) r.site = site, r.round_of_first = mine;
+    else if (r.site != site || r.round_of_first != mine) site_mismatch(r.site, site);
     if (++r.arrived == r.n) {
         r.arrived = 0, r.generation++;
         return;
@@ -38,54 +48,53 @@ struct Block {
     char* lds = nullptr;
 };
 extern thread_local Block* blk;
-extern thread_local int tid;
 }  // namespace sim
 
 BIOIK_DEV int p_tid() { return sim::tid; }
 BIOIK_DEV int p_nthreads() { return sim::blk->nthreads; }
-BIOIK_DEV void p_barrier() { sim::arrive_and_wait(sim::blk->bar); }
-BIOIK_DEV void p_wave_sync() { sim::arrive_and_wait(sim::blk->wave_bar[sim::tid >> 6]); }
+BIOIK_DEV void p_barrier(int site = __builtin_LINE()) { sim::arrive_and_wait(sim::blk->bar, site); }
+BIOIK_DEV void p_wave_sync(int site = __builtin_LINE()) { sim::arrive_and_wait(sim::blk->wave_bar[sim::tid >> 6], site); }
 template <class T>
-BIOIK_DEV T p_shfl(T v, int src_lane) {
+BIOIK_DEV T p_shfl(T v, int src_lane, int site = __builtin_LINE()) {
     static_assert(sizeof(T) <= 8, "");
     int w = sim::tid >> 6, l = sim::tid & 63;
     uint64_t bits = 0;
     std::memcpy(&bits, &v, sizeof(T));
     uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
     x[l] = bits;
-    sim::arrive_and_wait(sim::blk->wave_bar[w]);
+    sim::arrive_and_wait(sim::blk->wave_bar[w], site);
     uint64_t r = x[src_lane & 63];
-    sim::arrive_and_wait(sim::blk->wave_bar[w]);
+    sim::arrive_and_wait(sim::blk->wave_bar[w], -site);
     T out;
     std::memcpy(&out, &r, sizeof(T));
     return out;
 }
 template <class T>
-BIOIK_DEV T p_shfl_xor(T v, int mask) { return p_shfl(v, (sim::tid & 63) ^ mask); }
+BIOIK_DEV T p_shfl_xor(T v, int mask, int site = __builtin_LINE()) { return p_shfl(v, (sim::tid & 63) ^ mask, site); }
 template <int MASK, class T>
-BIOIK_DEV T p_quad_xor(T v) { return p_shfl_xor(v, MASK); }
+BIOIK_DEV T p_quad_xor(T v, int site = __builtin_LINE()) { return p_shfl_xor(v, MASK, site); }
 template <int HALF, class T>  // lane i <-> 15 - i of its row of 16 (HALF = 0) or 7 - i of its half row (HALF = 1)
-BIOIK_DEV T p_row_mirror(T v) {
+BIOIK_DEV T p_row_mirror(T v, int site = __builtin_LINE()) {
     const int l = sim::tid & 63;
-    return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))));
+    return p_shfl(v, HALF ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))), site);
 }
 BIOIK_DEV int p_uniform(int v) { return v; }
 template <class T>
-BIOIK_DEV T p_read_lane(T v, int lane) { return p_shfl(v, lane); }
+BIOIK_DEV T p_read_lane(T v, int lane, int site = __builtin_LINE()) { return p_shfl(v, lane, site); }
 BIOIK_DEV int p_fresh(int v) { return v; }
 BIOIK_DEV double p_fresh(double v) { return v; }
 BIOIK_DEV int p_lane_fresh() { return sim::tid & 63; }
 BIOIK_DEV double p_clamp_uniform(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
 BIOIK_DEV int p_tid_fresh() { return sim::tid; }
 BIOIK_DEV int p_wave_index() { return sim::tid >> 6; }
-BIOIK_DEV unsigned long long p_ballot(bool pred) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)
+BIOIK_DEV unsigned long long p_ballot(bool pred, int site = __builtin_LINE()) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)
     const int w = sim::tid >> 6, l = sim::tid & 63;
     uint64_t* x = sim::blk->xchg.data() + (size_t)w * 64;
     x[l] = pred ? 1u : 0u;
-    sim::arrive_and_wait(sim::blk->wave_bar[w]);
+    sim::arrive_and_wait(sim::blk->wave_bar[w], site);
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) m |= (unsigned long long)x[i] << i;
-    sim::arrive_and_wait(sim::blk->wave_bar[w]);
+    sim::arrive_and_wait(sim::blk->wave_bar[w], -site);
     return m;
 }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }

@@ -462,8 +462,9 @@ def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, tem
 
 
 def test_joint_walk_of_both_species_children_full_size(gpus, oracles, templates, monkeypatch):
-    """C3 at its full population runs k_solve_lean_clj (both species on one wavefront, their pre-selected children walked as one list):
-    trajectories equal to the oracle's, and a 1024-query batch equal to the one-half-per-species form bit for bit"""
+    """C3 at its full population runs k_solve_lean_clj4 (both species on one wavefront, their pre-selected children walked as one list, the
+    128-register build: fitness values parked per species in LDS): trajectories equal to the oracle's, and a 1024-query batch equal to the
+    three-wavefront build of the same walk (k_solve_lean_clj) and to the one-half-per-species form bit for bit"""
     h, o, t = gpus["c3"], oracles["c3"], templates["c3"]
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 1024, seed=33)
     p = abi.default_solve_params(population=128, max_steps=5, random_seed=6)
@@ -471,9 +472,16 @@ def test_joint_walk_of_both_species_children_full_size(gpus, oracles, templates,
     with pc.oracle_arithmetic(1):
         w = o.solve_batch(p, orc.RNG_COUNTER, seeds[:24], params[:24], n_threads=8)
     assert all(np.array_equal(x[:24], y) for x, y in zip(a, w))
+    monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+    b = h.solve_batch(p, seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    monkeypatch.delenv("BIOIK_SOLVE_THREE_WAVES")
     monkeypatch.setenv("BIOIK_SOLVE_NO_JOINT", "1")
     b = h.solve_batch(p, seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for pop in (9, 33, 70, 200):  # (lists shorter than a half-wavefront, over several trips, odd tails)
+        monkeypatch.delenv("BIOIK_SOLVE_NO_JOINT", raising=False)
+        pc.trajectory(h, o, t, n=4, pop=pop, steps_list=(3,))
 
 
 def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeypatch):

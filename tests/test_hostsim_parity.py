@@ -23,6 +23,31 @@ def shared_trigonometry():
     orc.set_trig_mode(0)
 
 
+@pytest.fixture(autouse=True)
+def no_divergent_collectives(hostsim_lib, request):
+    """Every collective of the simulator (wavefront rendezvous, shuffles, ballots, the workgroup barrier) carries the source line it is called from;
+    lanes that meet at DIFFERENT collectives -- a silent exchange of garbage on the device -- are counted.  No test may cause one."""
+    import ctypes
+    count = hostsim_lib.hostsim_divergent_collectives
+    count.restype = ctypes.c_ulonglong
+    before = count()
+    yield
+    if "divergence_selftest" not in request.node.name:
+        assert count() == before, "lanes of a wavefront met at different collectives (see the [hostsim] lines on stderr)"
+
+
+def test_divergence_selftest(hostsim_lib):
+    """the detector itself: a launch whose odd lanes synchronise from another line than its even ones is reported, the same launch without is not"""
+    import ctypes
+    count = hostsim_lib.hostsim_divergent_collectives
+    count.restype = ctypes.c_ulonglong
+    before = count()
+    hostsim_lib.hostsim_selftest_divergence(0)
+    assert count() == before
+    hostsim_lib.hostsim_selftest_divergence(1)
+    assert count() == before + 32
+
+
 @pytest.fixture(scope="module")
 def sims(hostsim_lib, templates, oracles):
     return {k: HipSolver(t, lib=hostsim_lib) for k, t in templates.items()}
@@ -362,6 +387,23 @@ def test_kernels_compiled_for_one_mapping(sims, oracles, templates, monkeypatch)
     pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=33, steps_list=(2,), islands=2)
     monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "1")  # ... and resumed from a hand-over
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
+
+
+def test_joint_walk_under_the_small_register_budget(sims, oracles, templates, monkeypatch):
+    """k_solve_lean_clj4 (solve_body<.., JOINT, SLIM, FIXED = 4>): both species of a query on the halves of one wavefront, secondary goals, the
+    pre-selected children of both species walked as ONE list whose fitness values are parked per species in LDS -- what the launcher picks for
+    the two-armed problem wherever a CU's LDS holds more than twelve queries.  Populations around the lane counts (a list shorter than a half, a
+    list over several trips, odd tails), islands, a resumed launch; and the three-wavefront kernel of the same mapping gives the same trajectories."""
+    for k, v in {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}.items():
+        monkeypatch.setenv(k, v)
+    for pop in (9, 33, 70):
+        pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=pop, steps_list=(2,))
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=200, steps_list=(1, 2), islands=2)
+    monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=33, steps_list=(2,))
+    monkeypatch.delenv("BIOIK_SOLVE_THREE_WAVES")
+    monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "1")
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=64, steps_list=(3,))
 
 
 def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
