@@ -244,6 +244,7 @@ struct bioik_problem {
     unsigned long long* d_clocks = nullptr;
     unsigned clock_next = 0;
     static constexpr unsigned kClocks = 64;
+    unsigned int* d_resident = nullptr;  // workgroups of the throughput schedule's launches that are running now (SolveArgs::resident), all streams of this handle
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
     ProbPtr pb() const { return (ProbPtr)d_pb; }
@@ -282,6 +283,11 @@ struct SolveSwitches {
     bool report = false;        // BIOIK_SOLVE_REPORT
     bool three_waves = false, four_waves = false, no_joint = false;
     int dense_handover = 0;     // BIOIK_SOLVE_DENSE_HANDOVER=K: a throughput solve hands the queries that pass K steps over to the latency mapping (0: never)
+    int drain_below = 1024;     // BIOIK_SOLVE_DRAIN_BELOW=N: the dense kernel's stragglers leave for the latency mapping when fewer than N wavefronts of the handle's launches
+                                // are left on the chip (0: never): isolated chip-filling calls of the latency schedule (launch_solve: latency_drain)
+    bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
+    int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
+    int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
     bool two_phase_set = false, two_phase_init = false;
     std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
     std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
@@ -305,6 +311,10 @@ static SolveSwitches parse_switches() {
     w.four_waves = std::getenv("BIOIK_SOLVE_FOUR_WAVES") != nullptr;
     w.no_joint = std::getenv("BIOIK_SOLVE_NO_JOINT") != nullptr;
     w.dense_handover = geti("BIOIK_SOLVE_DENSE_HANDOVER", 0);
+    w.drain_below = geti("BIOIK_SOLVE_DRAIN_BELOW", 1024);
+    w.drain_throughput = geti("BIOIK_SOLVE_DRAIN_THROUGHPUT", 0) != 0;
+    w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
+    w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
         w.two_phase_init = std::strcmp(e, "init") == 0;
@@ -534,7 +544,15 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // (nth / sp keep the LATENCY mapping: a throughput solve may hand its stragglers over to it, sw.dense_handover; its own launch takes the
     // dense mapping where it is made, `halves` below)
     // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
-    const bool dense = throughput && !sw.three_waves && dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
+    // BIOIK_SCHEDULE_LATENCY, a batch that fills the chip (>= 2048 queries) under k_solve_lean_cl4's mapping: the dense kernel first -- every query of up to 4096
+    // resident from the start, most steps retired per ms while the chip is full -- and, when the chip runs empty, the stragglers on to k_solve_lean_cl4 whose lone
+    // step is a third shorter (SolveArgs::resident).  An isolated 4096-query call: 9.2 -> 8.5 ms (profiles/r04_drain_handover.log).  Streams of solves keep the
+    // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
+    const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
+                          dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
+    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 2048 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
+                               !sw.two_phase_set;
+    const bool dense = (throughput || latency_drain) && dense_ok;
     if (sw.columnless > 0 && can_columnless) {
         sp.columnless = 1, sp.child_cols = 1;
         sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
@@ -623,14 +641,21 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // BIOIK_SOLVE_TWO_PHASE=K (or K1,K2,... / init) forces hand-overs after those steps for any problem (0: never) -- the parity suites run every
     // mapping through it.
     std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
+    bool when_draining = false;  // ... or: whenever the chip runs empty (SolveArgs::resident), every unit from the step it is at
     const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
-    if (sw.two_phase_set) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
+    if (sw.drain_test > 0 && sp.max_steps > 1 && sp.solver == 0) {
+        when_draining = true;
+        handovers.push_back(sp.max_steps);
+    } else if (sw.two_phase_set) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
         if (sw.two_phase_init) handovers.push_back(0);  // (experiment: the first launch only initialises)
         for (const long k : sw.two_phase)
             if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
     } else if (throughput) {
         // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
         if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
+        else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1) when_draining = true, handovers.push_back(sp.max_steps);
+    } else if (latency_drain) {
+        when_draining = true, handovers.push_back(sp.max_steps);
     } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
         // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
         // profiles/r04_ab_latency_schedule_kernel.log)
@@ -669,8 +694,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             size_t lds_j = lds;
             if (j == 0 && halves_ok && !manual) halves(aj, lanes, lds_j);
             aj.carry = (double*)ws;
+            if (when_draining) {  // (the last launch counts its wavefronts too; it has no list to leave for)
+                aj.resident = p->d_resident;
+                aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (sw.drain_below + 7) / 8;  // (per XCD: eight on this chip)
+                aj.drain_min_steps = sw.drain_min_steps;
+            }
             if (j > 0) {
-                aj.step_begin = handovers[j - 1];
+                aj.step_begin = when_draining ? -1 : handovers[j - 1];
                 aj.unit_list = (const int32_t*)((char*)ws + list_off + (j - 1) * list_bytes);
                 aj.unit_count = (const unsigned int*)((char*)ws + count_off + (j - 1) * 64);
             }
@@ -753,6 +783,8 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     DeviceGuard on_device(model->device);
     p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
     p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kClocks * sizeof(unsigned long long));
+    p->d_resident = (unsigned int*)be_alloc(16 * 128);
+    be_zero_async(p->d_resident, 16 * 128, 0);
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
     be_sync(0);
     *out = p.release();
@@ -762,6 +794,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     if (!p) return;
     be_free(p->d_pb);
     be_free(p->d_clocks);
+    be_free(p->d_resident);
     for (auto& sl : p->io) {
         if (sl.pending) {  // (a submitted solve nobody waited for: let it finish before its buffers go)
             try {

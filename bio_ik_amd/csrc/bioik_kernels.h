@@ -187,6 +187,46 @@ BIOIK_DEV void top2_wave(double& b1f, int& b1p, double& b2f, int& b2p, int G) {
     TOP2_DPP_STEP(p_quad_xor<1>)
 #undef TOP2_DPP_STEP
 }
+// Bitonic sort of G * E (fitness, child index) pairs held in REGISTERS, E per lane, ascending by (fitness, index) -- the order of a stable sort by
+// fitness.  Sorted position p lives in lane p / E, register p % E.  The compare-exchange partners of the network's step (k, j) sit at positions that
+// differ in bit j: for j < E that is another register of the same lane (no data moves), else the same register of lane ^ (j / E) (one ds_bpermute per
+// dword: three per pair).  Against the same network over two arrays in LDS (four reads, up to four writes per exchange, a dependent write -> read
+// between any two of its log2(n)(log2(n)+1)/2 rounds) the 512 children of the 31-joint chain take 21 rounds of 24 permutes instead of 45 rounds of 24
+// reads and writes with their address arithmetic.  G: lanes of the group, a power of two <= 64 (a half or a whole wavefront).
+template <int E>
+BIOIK_DEV void sort_pairs_in_registers(double (&f)[E], int (&c)[E], int gtid, int G) {
+    const int n = G * E;
+    for (int k = 2; k <= n; k <<= 1) {
+        const bool ascending = ((gtid * E) & k) == 0;  // (k >= E: the direction of a block is the same for all registers of a lane)
+        for (int j = k >> 1; j >= E; j >>= 1) {
+            const int d = j / E;  // (E: a power of two, known at compile time)
+            const bool keep_low = ((gtid & d) == 0) == ascending;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const double of = p_shfl_xor(f[i], d);
+                const int oc = p_shfl_xor(c[i], d);
+                const bool mine_after = (f[i] > of) || (f[i] == of && c[i] > oc);
+                const bool take = mine_after == keep_low;
+                f[i] = take ? of : f[i], c[i] = take ? oc : c[i];
+            }
+        }
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1) {
+            if (j >= k) continue;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                if (i & j) continue;
+                const int i2 = i | j;
+                const bool asc = k >= E ? ascending : ((i & k) == 0);
+                const bool a_after_b = (f[i] > f[i2]) || (f[i] == f[i2] && c[i] > c[i2]);
+                const bool swap = a_after_b == asc;
+                const double fa = f[i], fb = f[i2];
+                const int ca = c[i], cb = c[i2];
+                f[i] = swap ? fb : fa, f[i2] = swap ? fa : fb, c[i] = swap ? cb : ca, c[i2] = swap ? ca : cb;
+            }
+        }
+    }
+}
 // rendezvous of one lane group: a single wavefront needs no s_barrier (p_wave_sync), several wavefronts take the workgroup
 // barrier -- every group of the workgroup then executes the same number of them
 BIOIK_DEV void group_sync(int G) {
@@ -267,6 +307,13 @@ struct SolveArgs {
     // an island of the query has passed the success test (the host fills it with 0xffffffff).  An island that passes files its step count (atomic
     // minimum); an island that finds a count <= its own leaves, because k_select only considers the islands that passed at the least count.
     unsigned int* first_success = nullptr;    // [n]
+    // Hand-over when the chip runs empty (the throughput schedule's straggler tail): the workgroups of every launch that carries this word count
+    // their wavefronts in it while they run (the launches that take the stragglers over too: their work keeps the chip busy just as well).  New workgroups start as fast as old ones leave while any launch has work queued, so a count below `drain_below`
+    // means the queue is empty and the chip is emptying: a unit that has run `drain_min_steps` steps then leaves for the next launch (the mapping with
+    // the faster lone step) whatever step it is at, its step count travelling with its state; that launch has step_begin < 0 and reads it there.
+    // Which units leave when depends on timing; their results do not (every mapping computes the same trajectory).
+    unsigned int* resident = nullptr;              // [16][32]: word 32 x of XCD x
+    int32_t drain_below = 0, drain_min_steps = 0;  // (wavefronts per XCD)  // (drain_below < 0: test pattern -- unit u leaves after 1 + hash(u) % -drain_below steps)
 };
 
 struct SpeciesState {
@@ -344,6 +391,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     const PB pb = (PB)a.pb;
     const DevSolveParams& sp = a.sp;
     const int tid0 = p_tid(), nth = HALVES ? 64 : (WAVE2 ? 128 : p_nthreads());
+    // (counted in wavefronts: the launches that share the words differ in theirs.  One word per XCD, 128 bytes apart, each touched by the workgroups of
+    // ITS XCD only: a word all eight L2s fight over cost 15 % of a stream's throughput, profiles/r04_drain_handover.log)
+    unsigned int* const my_resident = a.resident ? a.resident + 32 * p_xcc_id() : nullptr;
+    if (my_resident && tid0 == 0) p_atomic_add(my_resident, (unsigned int)(nth >> 6));
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
@@ -494,11 +545,12 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             s_deadline[0] = (double)(t1 >> 32), s_deadline[1] = (double)(t1 & 0xffffffffull);
         }
     }
-    int steps = a.step_begin;
-    bool success = false, expired = false, overtaken_out = false;
+    const int step_first = a.step_begin >= 0 ? a.step_begin : (int)s_state[16];  // (< 0: the step this unit left its last launch at, SolveArgs::resident)
+    int steps = step_first;
+    bool success = false, expired = false, overtaken_out = false, drained = false;
     double final_fit = BIOIK_DBL_MAX;
     const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
-    for (int step = a.step_begin; step < step_end; step++) {
+    for (int step = step_first; step < step_end; step++) {
         const int rank_begin = groups == 2 ? (SLIM ? 0 : (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G)) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
         for (int rank_it = rank_begin; rank_it < rank_end; rank_it++) {
             // (DENSE: a half-wavefront runs the species of its own number, read off the lane number wherever it is needed: no register carries it)
@@ -543,6 +595,47 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 }
                 if (has_sec) {
                     // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
+                    bool sorted = false;
+                    if constexpr (CL) {
+                        // one wavefront (or half of one) per species and four or eight children per lane: lane l scores the children l E ... l E + E - 1 and the
+                        // pairs (fitness, child) are sorted where they are, in registers (sort_pairs_in_registers); only the order reaches LDS
+                        auto presort = [&](auto e_tag) {
+                            constexpr int E = decltype(e_tag)::value;
+                            double sf[E];
+                            int sc[E];
+#pragma unroll
+                            for (int i0 = 0; i0 < E; i0 += 4) {
+                                int cj[4];
+#pragma unroll
+                                for (int j = 0; j < 4; j++) cj[j] = gtid * E + i0 + j < lambda ? gtid * E + i0 + j : 0;  // (padding scores child 0 and drops it)
+                                double e[4];
+                                if constexpr (DENSE || WAVE2) {
+                                    const double* const pgt = popS + (S.cur ^ 1) * BF;
+                                    const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
+                                                              make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
+                                    secondary_fitness_n<4>(pb, cx, qc, e, inside_mask);
+                                } else {
+                                    const ChildX<PB> cx[4] = {make_child_x(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, p0d, p1d),
+                                                              make_child_x(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, p0d, p1d), make_child_x(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, p0d, p1d)};
+                                    secondary_fitness_n<4>(pb, cx, qc, e);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; j++) sf[i0 + j] = gtid * E + i0 + j < lambda ? e[j] : P_INF, sc[i0 + j] = gtid * E + i0 + j;
+                            }
+                            PHASE_MARK(PH_SELECTION);
+                            sort_pairs_in_registers<E>(sf, sc, gtid, G);
+#pragma unroll
+                            for (int i = 0; i < E; i++) s_order[gtid * E + i] = sc[i];
+                            group_sync(G);
+                            sorted = true;
+                        };
+                        const int per_lane = (G <= 64 && (G & (G - 1)) == 0) ? n_sort / G : 0;
+                        if constexpr (!WAVE2 && !LIN && !DENSE)
+                            if (per_lane == 4) presort(std::integral_constant<int, 4>{});
+                        if constexpr (!JH && !LIN && !DENSE)
+                            if (per_lane == 8) presort(std::integral_constant<int, 8>{});
+                    }
+                    if (!sorted) {
                     if (columnless && lambda >= 4 * G) {  // four children per lane and trip: four independent hash -> Gaussian -> clip -> cost chains
                         for (int c = gtid; c < lambda; c += 4 * G) {
                             int cj[4];
@@ -585,6 +678,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     // ascending by (secondary fitness, child index) -- the order of a stable sort -- with a bitonic network over the next power
                     // of two (padding: +inf): log2(n)(log2(n)+1)/2 rounds of n/2 compare-exchanges shared by the group's lanes, instead of
                     // lambda comparisons per child (512 children: 45 x 4 exchanges per lane instead of 4096 comparisons)
+                    PHASE_MARK(PH_SELECTION);  // (profiling build: the children's secondary fitness | the sort | the draw of the survivors' count)
                     for (int i = gtid; i < n_sort; i += G) {
                         if (i >= lambda) s_sec[i] = P_INF;
                         s_order[i] = i;
@@ -601,6 +695,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             }
                             group_sync(G);
                         }
+                    }
+                    PHASE_MARK(PH_MEMETICS);
                     uint32_t o0, o1;
                     philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
                     n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
@@ -1161,9 +1257,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             if (a.first_success && tid == 0) p_atomic_min(a.first_success + q, (unsigned int)steps);  // ik_parallel.h:176-177 `finished = 1`
             break;
         }
-        if (sp.timeout_ticks != 0ull || a.first_success) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
+        if (sp.timeout_ticks != 0ull || a.first_success || (a.resident && a.carry_list)) {  // at least one step has run (ik_parallel.h:160 `iteration != 0`)
             if (tid == 0) {
                 bool stop = false;
+                bool leave = false;  // the chip is emptying: on to the launch with the faster lone step (SolveArgs::resident)
+                if (a.resident && a.carry_list && steps < step_end) {
+                    if (a.drain_below < 0) leave = steps - step_first >= 1 + (int)((((uint32_t)unit + 1u) * 2654435761u >> 16) % (uint32_t)(-a.drain_below));
+                    else leave = steps >= a.drain_min_steps && p_atomic_load(my_resident) < (unsigned int)a.drain_below;
+                }
+                s_wbc[0] = leave ? 1.0 : 0.0;
                 if (sp.timeout_ticks != 0ull) {
                     const unsigned long long deadline = ((unsigned long long)s_deadline[0] << 32) | (unsigned long long)s_deadline[1];
                     stop = p_wall_clock() >= deadline;
@@ -1177,21 +1279,25 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             p_barrier();
             expired = s_wbc[2] != 0.0;
             const bool overtaken = s_wbc[3] != 0.0;
+            drained = s_wbc[0] != 0.0;
             p_barrier();
             if (overtaken) overtaken_out = true;
             if (expired || overtaken) break;
+            if (drained) break;
         }
     }
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
-    const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && step_end < sp.max_steps;  // neither solved nor out of time: the next launch goes on
+    if (my_resident && tid == 0) p_atomic_sub(my_resident, (unsigned int)(nth >> 6));
+    const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && (step_end < sp.max_steps || drained);  // neither solved nor out of time: the next launch goes on
     if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < 2 * BF; i += nth) {
             const int r = i >= BF ? 1 : 0;
             c[i] = s_pop[(int)s_state[r * 8 + 4] * SP + (int)s_state[r * 8 + 5] * BF + (i - r * BF)];  // (slot, cur of the species of rank r: species_store)
         }
-        for (int i = tid; i < M + 24; i += nth) c[2 * BF + i] = i < M ? s_sol[i] : ((i - M == 5 || i - M == 13) ? 0.0 : s_state[i - M]);
+        // (slot 16 of the bookkeeping, a broadcast slot between the steps: the step count, for a launch that continues every unit where it stands)
+        for (int i = tid; i < M + 24; i += nth) c[2 * BF + i] = i < M ? s_sol[i] : ((i - M == 5 || i - M == 13) ? 0.0 : (i - M == 16 ? (double)steps : s_state[i - M]));
         if (tid == 0) a.carry_list[p_atomic_inc(a.carry_count)] = (int32_t)unit;
     }
 

@@ -107,8 +107,13 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     return old ? old : value;
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return atomicAdd(counter, 1u); }  // returns the value before
+BIOIK_DEV int p_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u); }  // the XCD this wavefront runs on (hardware register XCC_ID)
+BIOIK_DEV void p_atomic_add(unsigned int* counter, unsigned int v) { (void)atomicAdd(counter, v); }
+BIOIK_DEV void p_atomic_sub(unsigned int* counter, unsigned int v) { (void)atomicSub(counter, v); }
 BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) { (void)atomicMin(word, value); }
-BIOIK_DEV unsigned int p_atomic_load(const unsigned int* word) { return __atomic_load_n(word, __ATOMIC_RELAXED); }  // (a word other workgroups write: read from memory every time)
+// (a word other workgroups of this device write: device scope -- the default scope of __atomic_load_n is the system's, a load that no cache may answer:
+// 4096 workgroups reading one word once per step that way cost a stream of solves 13 % of its throughput, profiles/r04_drain_handover.log)
+BIOIK_DEV unsigned int p_atomic_load(const unsigned int* word) { return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define P_INF (__builtin_inf())
 #define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
 #define BIOIK_HD __host__ __device__ inline

@@ -105,6 +105,9 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     return __atomic_compare_exchange_n(word, &expected, value, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) ? value : expected;
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL); }
+BIOIK_DEV int p_xcc_id() { return 0; }
+BIOIK_DEV void p_atomic_add(unsigned int* counter, unsigned int v) { (void)__atomic_fetch_add(counter, v, __ATOMIC_ACQ_REL); }
+BIOIK_DEV void p_atomic_sub(unsigned int* counter, unsigned int v) { (void)__atomic_fetch_sub(counter, v, __ATOMIC_ACQ_REL); }
 BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) {
     unsigned int cur = __atomic_load_n(word, __ATOMIC_RELAXED);
     while (value < cur && !__atomic_compare_exchange_n(word, &cur, value, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {

@@ -406,6 +406,19 @@ def test_joint_walk_under_the_small_register_budget(sims, oracles, templates, mo
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=64, steps_list=(3,))
 
 
+def test_units_that_change_launch_at_their_own_step(sims, oracles, templates, monkeypatch):
+    """SolveArgs::resident: the throughput schedule's stragglers leave for the launch with the faster lone step when the chip runs empty -- every
+    unit from whatever step it is at, its step count travelling with its state.  Which unit leaves when is a matter of timing on the device; here
+    the test pattern (BIOIK_SOLVE_DRAIN_TEST=n: unit u after 1 + hash(u) % n steps) stands in for it.  The oracle's trajectories bit for bit, for the
+    dense kernel and its successor, for islands (whose step counts decide the selection) and for problems with secondary goals."""
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_TEST", "5")
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=12, pop=128, steps_list=(9,), schedule=abi.SCHEDULE_THROUGHPUT)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=6, pop=128, steps_list=(7,), islands=2, island_sync=1, schedule=abi.SCHEDULE_THROUGHPUT)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=6, pop=32, steps_list=(8,))
+    pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=4, pop=128, steps_list=(7,))
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=4, pop=16, steps_list=(9,), fk_mode=abi.FK_LINEAR)
+
+
 def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
     """bioik_solve_params::island_sync = 1: "any island succeeds => all stop" (ik_parallel.h:102, 160-178) in lock step -- the answer is the best of the
     islands that passed after the LEAST number of steps, whatever the other islands went on to find; bit for bit the oracle's, under one launch and under

@@ -11,7 +11,7 @@ from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, 
 from bio_ik_amd.solver import HipSolver  # noqa: E402
 from bio_ik_amd.workload import make_queries  # noqa: E402
 
-NAMES = ["init", "reproduce", "fitness", "selection", "memetics", "species", "check", "preselect/candidate", "sel.top2", "sel.xwave", "sel.copy", "sel.barrier",
+NAMES = ["init", "reproduce", "fitness", "preselect.score", "preselect.sort", "species", "check", "preselect/candidate", "sel.top2", "sel.xwave", "sel.copy", "sel.barrier",
          "mem.approx", "mem.grad", "mem.norm", "mem.line", "mem.accept", "mem.tail", "rank", "#mem_iter", "#steps", "linearise", "mem.support_cols", "mem.support_eval"]
 
 
