@@ -468,8 +468,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // lanes get at least one pair of children per generation and whose LDS footprint lets sixteen wavefronts share a CU it beats the kernel with the
     // children kept in columns on every count (C2: lone step 94 -> 91 us, fixed work at 4096 queries +30 %, three solves in flight +26 %, an isolated
     // call +16 %: profiles/r04_ab_latency_schedule_kernel.log)
-    const bool prefer_cl4 = !manual && nth == 128 && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
-                            sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= 160 * 1024;
+    const bool cl4_eligible = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
+                              sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= 160 * 1024;
+    // (... also for the launches that cannot fill the chip, where solve_threads asks for a lane per child: one query 0.928 against 0.942 ms, 256 queries 5.49 against
+    // 5.74 ms, profiles/r04_small_batches.log)
+    if (cl4_eligible && nth == 256) nth = 128;
+    const bool prefer_cl4 = cl4_eligible && nth == 128;
     if (prefer_cl4) {
         sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
     } else if (!manual && nth == 128) {
@@ -544,13 +548,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // (nth / sp keep the LATENCY mapping: a throughput solve may hand its stragglers over to it, sw.dense_handover; its own launch takes the
     // dense mapping where it is made, `halves` below)
     // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
-    // BIOIK_SCHEDULE_LATENCY, a batch that fills the chip (>= 2048 queries) under k_solve_lean_cl4's mapping: the dense kernel first -- every query of up to 4096
+    // BIOIK_SCHEDULE_LATENCY, a batch beyond what the chip holds of k_solve_lean_cl4's workgroups (2048; 2048 queries: 7.27 ms alone, 7.51 ms this way) under its mapping: the dense kernel first -- every query of up to 4096
     // resident from the start, most steps retired per ms while the chip is full -- and, when the chip runs empty, the stragglers on to k_solve_lean_cl4 whose lone
     // step is a third shorter (SolveArgs::resident).  An isolated 4096-query call: 9.2 -> 8.5 ms (profiles/r04_drain_handover.log).  Streams of solves keep the
     // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
     const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
                           dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
-    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 2048 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
+    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 3072 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set;
     const bool dense = (throughput || latency_drain) && dense_ok;
     if (sw.columnless > 0 && can_columnless) {

@@ -393,8 +393,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     const int tid0 = p_tid(), nth = HALVES ? 64 : (WAVE2 ? 128 : p_nthreads());
     // (counted in wavefronts: the launches that share the words differ in theirs.  One word per XCD, 128 bytes apart, each touched by the workgroups of
     // ITS XCD only: a word all eight L2s fight over cost 15 % of a stream's throughput, profiles/r04_drain_handover.log)
-    unsigned int* const my_resident = a.resident ? a.resident + 32 * p_xcc_id() : nullptr;
-    if (my_resident && tid0 == 0) p_atomic_add(my_resident, (unsigned int)(nth >> 6));
+    auto my_resident = [&]() { return a.resident + 32 * p_xcc_id(); };  // (computed where it is used: no register carries it through the kernel)
+    if (a.resident && tid0 == 0) p_atomic_add(my_resident(), (unsigned int)(nth >> 6));
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
@@ -551,6 +551,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double final_fit = BIOIK_DBL_MAX;
     const int step_end = a.step_end < sp.max_steps ? a.step_end : sp.max_steps;
     for (int step = step_first; step < step_end; step++) {
+        // the count of its XCD's wavefronts, asked for HERE and read when the step is over (SolveArgs::resident): the load goes straight to LDS (the spare
+        // eighth double of the prefix frame) and nothing waits for it -- read where it is used, every workgroup stalled on it once per step: -13 % on a stream
+        // of ten solves in flight (profiles/r04_drain_handover.log)
+        if (a.resident && a.carry_list && a.drain_below > 0 && (HALVES ? p_lane_fresh() : p_tid_fresh()) == 0) p_prefetch_word_to_lds(my_resident(), s_prefix + 7);
         const int rank_begin = groups == 2 ? (SLIM ? 0 : (g_shift >= 0 ? p_fresh(tid0) >> g_shift : p_fresh(tid0) / G)) : 0, rank_end = groups == 2 ? rank_begin + 1 : 2;
         for (int rank_it = rank_begin; rank_it < rank_end; rank_it++) {
             // (DENSE: a half-wavefront runs the species of its own number, read off the lane number wherever it is needed: no register carries it)
@@ -1263,7 +1267,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 bool leave = false;  // the chip is emptying: on to the launch with the faster lone step (SolveArgs::resident)
                 if (a.resident && a.carry_list && steps < step_end) {
                     if (a.drain_below < 0) leave = steps - step_first >= 1 + (int)((((uint32_t)unit + 1u) * 2654435761u >> 16) % (uint32_t)(-a.drain_below));
-                    else leave = steps >= a.drain_min_steps && p_atomic_load(my_resident) < (unsigned int)a.drain_below;
+                    else leave = steps >= a.drain_min_steps && p_prefetched_word(s_prefix + 7) < (unsigned int)a.drain_below;
                 }
                 s_wbc[0] = leave ? 1.0 : 0.0;
                 if (sp.timeout_ticks != 0ull) {
@@ -1288,7 +1292,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     }
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
-    if (my_resident && tid == 0) p_atomic_sub(my_resident, (unsigned int)(nth >> 6));
+    if (a.resident && tid == 0) p_atomic_sub(my_resident(), (unsigned int)(nth >> 6));
     const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && (step_end < sp.max_steps || drained);  // neither solved nor out of time: the next launch goes on
     if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;

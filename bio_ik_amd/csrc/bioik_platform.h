@@ -108,6 +108,17 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return atomicAdd(counter, 1u); }  // returns the value before
 BIOIK_DEV int p_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u); }  // the XCD this wavefront runs on (hardware register XCC_ID)
+// One 32-bit word from device memory straight into LDS (global_load_lds_dword: no register receives it, so nothing waits for it until p_prefetched_word
+// does).  Called by ONE lane (the instruction writes lane l's word at the LDS address + 4 l).  The compiler does not know of the load: its own waits on the
+// vector-memory counter only become stricter for it, and the reader waits for the counter itself.
+BIOIK_DEV void p_prefetch_word_to_lds(const unsigned int* src, double* lds_slot) {
+    const unsigned int lds_off = (unsigned int)(size_t)lds_slot;  // (the low half of a flat LDS address is the LDS offset)
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off sc1" : : "v"(src), "s"(lds_off) : "m0", "memory");
+}
+BIOIK_DEV unsigned int p_prefetched_word(const double* lds_slot) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return *(const volatile unsigned int*)lds_slot;
+}
 BIOIK_DEV void p_atomic_add(unsigned int* counter, unsigned int v) { (void)atomicAdd(counter, v); }
 BIOIK_DEV void p_atomic_sub(unsigned int* counter, unsigned int v) { (void)atomicSub(counter, v); }
 BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) { (void)atomicMin(word, value); }
