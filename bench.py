@@ -6,8 +6,9 @@ right-arm 7-DOF PoseGoal queries (BASELINE.json configs[1]: pop=128, 1xMI355X), 
 `value` = successful solves of all ranks / wall time of the K timed steps (max over ranks).  N>1: one process per
 GPU (torch.distributed, backend nccl = RCCL), every rank solves its own 4096-query shard (weak scaling, no data-path
 collective: queries are independent; RCCL only carries the barrier and the two scalar reductions of the timing).
-Consecutive steps are issued round-robin on up to twenty HIP streams (`--in-flight`, config.batches_in_flight: by default the largest of twenty, ten, eight,
-six, five, four that divides the number of timed steps; twenty: +2.5 % over ten at the driver's 20 steps, +1 % at 60, profiles/r04_drain_handover.log) under
+Consecutive steps are issued round-robin on six to ten HIP streams (`--in-flight`, config.batches_in_flight: by default the largest of ten, eight, six,
+five, four that divides the number of timed steps; twenty would give the headline +2 % at the driver's 20 steps, but twenty-six streams in one process cost the
+C3 / C4 legs 11 % and the host-pointer leg a third, whatever GPU_MAX_HW_QUEUES says: profiles/r04_streams_in_process.log) under
 bioik_solve_params::schedule = BIOIK_SCHEDULE_THROUGHPUT (`--schedule`): the library's mapping for streams of batches (both species of a query on
 one wavefront: 27 % more steps per ms on a full chip, a step 2.5 x as long), under which the tail of one launch — a handful of queries that
 use the whole step budget, 64 sequential steps wherever they start — lasts ~16 ms and six or more solves in flight (a hardware queue each:
@@ -41,7 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the (up to) twenty solves this bench keeps in flight want a
+# The HIP runtime maps a process's streams onto FOUR hardware queues unless told otherwise; the (up to) ten solves this bench keeps in flight want a
 # queue each (profiles/r03_inflight_and_schedule.log), and so do the library's own six streams of the host-pointer leg, which live in the same
 # process: with sixteen queues for those seventeen streams the host-pointer pipeline shared queues and ran at 7.3e5 instead of 9.0e5 (session 58 in
 # the same log): twenty-four.  Must be set before the runtime initialises.
@@ -234,8 +235,8 @@ def main():
                          "bio_ik_amd.batch.solve_mixed); BIOIK_BENCH_C5_BATCH sets the global batch (default 262144)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BIOIK_BENCH_IN_FLIGHT", "0")),
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams (1 = strictly one after the other).  "
-                         "Default (0): under the throughput schedule the first of twenty / ten / eight / six / five / four that divides the K timed steps (else six), so that "
-                         "every stream solves the same number of batches (K = 20 and K = 60: twenty; profiles/r03_inflight_and_schedule.log, r04_drain_handover.log) --, three "
+                         "Default (0): under the throughput schedule the first of ten / eight / six / five / four that divides the K timed steps (else six), so that "
+                         "every stream solves the same number of batches (K = 20 and K = 60: ten; profiles/r03_inflight_and_schedule.log, short runs) --, three "
                          "under the latency schedule")
     ap.add_argument("--schedule", default=os.environ.get("BIOIK_BENCH_SCHEDULE", "throughput"), choices=["throughput", "latency"],
                     help="bioik_solve_params::schedule of the timed steps (include/bioik_hip.h): throughput = the mapping for streams of batches (six in "
@@ -312,7 +313,7 @@ def main():
     # which the chip is nearly empty; with more launches in flight the next batches' bulk fills it.  Every step is a complete
     # pass of the hot path over one batch and every batch's results are complete when the timed region ends.
     if args.in_flight <= 0:
-        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (20, 10, 8, 6, 5, 4) if args.steps % k == 0), 6)
+        args.in_flight = 3 if args.schedule == "latency" else next((k for k in (10, 8, 6, 5, 4) if args.steps % k == 0), 6)
     nfl = max(1, args.in_flight)
     streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
     bufs = [(torch.empty((BATCH, V), dtype=torch.float64, device=dev), torch.empty(BATCH, dtype=torch.float64, device=dev),
