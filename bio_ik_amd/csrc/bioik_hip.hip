@@ -390,7 +390,7 @@ struct DevBuf {
 #endif
 static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0).total * 8;
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
@@ -566,7 +566,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
     if (sw.report) {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
-                                        groups, sp.child_pairs ? 2 : 1);
+                                        groups, sp.child_pairs ? 2 : 1, (sp.columnless && exact) ? 1 : 0, 1);
         int n_rev = 0, n_pos = 0, n_rot = 0;  // revolute ops and how many of them the walk takes through a sparse form
         for (int k = 0; k < dp.n_chain_ops; k++)
             if (dp.ops[k].type == BIOIK_OP_REVOLUTE) n_rev++, n_pos += dp.ops[k].pos_kind != BIOIK_POS_GENERAL, n_rot += dp.ops[k].rot_kind != BIOIK_ROT_GENERAL;

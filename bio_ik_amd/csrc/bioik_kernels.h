@@ -28,7 +28,7 @@ struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species g
     int fitp;            // fit_park: the children's fitness values of one generation [lambda], on the space of the memetic phase's vectors
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
-                               int groups = 1, int slot_sets = 1, int fit_park = 0) {
+                               int groups = 1, int slot_sets = 1, int fit_park = 0, int fc_in_pop = 0) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -53,7 +53,11 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.xp = g, g += m;
     L.dv = g, g += 4 * m;
     g += g & 1;  // (two-double alignment of the component blocks)
-    L.fc = g, g += 4 * 8 * (T > 0 ? T : 1);
+    // The four frame sets of the line search (fc, 32 T doubles) are written and read inside the memetic phase, when the species' OTHER elite buffer (4 m doubles)
+    // holds nothing: the next generation's winners overwrite it.  Where they fit they lie there (fc_in_pop: the solver's layouts; fc = -1) -- for the two-armed
+    // problem 1 KiB per query, which is what lets a CU's LDS hold sixteen of its queries instead of fifteen
+    L.fc = -1;
+    if (!(fc_in_pop && 4 * 8 * (T > 0 ? T : 1) <= 4 * m)) L.fc = g, g += 4 * 8 * (T > 0 ? T : 1);
     L.tips = g, g += T * 7;
     L.delta = g, g += T * m * 7;
     L.base = g, g += m;
@@ -410,7 +414,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     const int groups = FIXED ? 2 : (sp.species_parallel ? 2 : 1);
     const int G = HALVES ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
     const int g_shift = HALVES ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0, 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -1112,7 +1116,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         double f2p = 0.0, fa = 0.0, fnorm = 0.0;
                         for (int round = 0; round < 3; round++) {
                             double* dv0 = s_dv + (round == 0 ? 0 : round == 1 ? 1 : 3) * M;
-                            double* fc0 = s_fc + (round == 0 ? 0 : round == 1 ? 1 : 3) * FB;
+                            double* fc0 = (L.fc >= 0 ? s_fc : popS + (S.cur ^ 1) * BF) + (round == 0 ? 0 : round == 1 ? 1 : 3) * FB;  // (make_layout: fc_in_pop)
                             if (round == 0) {
                                 for (int k = gtid; k < n_ops; k += Gw) dv0[k] = ((active_mask >> k) & 1ull) ? el[k] - s_base[k] : 0.0;
                             } else if (round == 1) {
