@@ -571,6 +571,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         for (int k = 0; k < dp.n_chain_ops; k++)
             if (dp.ops[k].type == BIOIK_OP_REVOLUTE) n_rev++, n_pos += dp.ops[k].pos_kind != BIOIK_POS_GENERAL, n_rot += dp.ops[k].rot_kind != BIOIK_ROT_GENERAL;
         std::fprintf(stderr, "[bioik] joint program: %d revolute ops, sparse position %d, sparse rotation %d\n", n_rev, n_pos, n_rot);
+        std::string prog;  // op (source, gene): the shape of the tree the walk takes
+        for (int k = 0; k < dp.n_chain_ops; k++) {
+            char buf[48];
+            std::snprintf(buf, sizeof buf, " %d(%d,%d%s%s)", k, (int)dp.ops[k].src, (int)dp.ops[k].gene, dp.ops[k].load_slot >= 0 ? ",load" : "", dp.ops[k].save_slot >= 0 ? ",save" : "");
+            prog += buf;
+        }
+        std::fprintf(stderr, "[bioik] joint program: prefix %d, serial %d, op(source,gene):%s\n", (int)dp.n_prefix, (int)dp.serial_chain, prog.c_str());
         std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d columnless %d | LDS %zu B "
                      "(genotype columns %d, parked frames %d, per-group %d x %d) -> %d workgroups = %d wavefronts per CU\n",
                      dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, sp.columnless, lds, (L.slots - L.xcol) * 8,

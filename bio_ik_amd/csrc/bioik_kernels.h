@@ -587,7 +587,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
                 uint64_t inside_mask = 0ull;  // (WAVE2: the ops no child of this generation can take out of AvoidJointLimitsGoal's free zone)
-                if constexpr (DENSE || WAVE2) {
+                if constexpr (DENSE || WAVE2 || JH) {
                     // the two forms of the parents' mixed momentum (ChildT), lane k the column of op k, into the species' other elite buffer
                     double* const pgt = popS + (S.cur ^ 1) * BF;
                     bool inside = false;
@@ -617,7 +617,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) cj[j] = gtid * E + i0 + j < lambda ? gtid * E + i0 + j : 0;  // (padding scores child 0 and drops it)
                                 double e[4];
-                                if constexpr (DENSE || WAVE2) {
+                                if constexpr (DENSE || WAVE2 || JH) {
                                     const double* const pgt = popS + (S.cur ^ 1) * BF;
                                     const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
                                                               make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
@@ -650,7 +650,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
 #pragma unroll
                             for (int j = 0; j < 4; j++) cj[j] = c + j * G < lambda ? c + j * G : c;  // (a tail repeats the first child and drops it)
                             double e[4];
-                            if constexpr (DENSE || WAVE2) {
+                            if constexpr (DENSE || WAVE2 || JH) {
                                 const double* const pgt = popS + (S.cur ^ 1) * BF;
                                 const ChildT<PB> cx[4] = {make_child_t(pb, key, ctr1, (uint32_t)cj[0] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[1] + 2u, p0g, pgt, M),
                                                           make_child_t(pb, key, ctr1, (uint32_t)cj[2] + 2u, p0g, pgt, M), make_child_t(pb, key, ctr1, (uint32_t)cj[3] + 2u, p0g, pgt, M)};
@@ -743,6 +743,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         // its random stream, its sorted order -- is uniform inside that half: one v_readlane each.
                         const int cb_off = (int)(cb - lds);
                         const int cbo[2] = {p_read_lane(cb_off, 0), p_read_lane(cb_off, 32)};
+                        const int ob_off = (int)(popS + (S.cur ^ 1) * BF - lds);  // (the species' other elite buffer: under SLIM the table of the parents' mixed momentum)
+                        const int obo[2] = {p_read_lane(ob_off, 0), p_read_lane(ob_off, 32)};
                         const int ct[2] = {p_read_lane((int)ctr1, 0), p_read_lane((int)ctr1, 32)};
                         const int ne0 = p_read_lane(n_eval, 0), total = ne0 + p_read_lane(n_eval, 32);
                         const int32_t* const ord[2] = {(const int32_t*)(lds + L.g_first + L.order), (const int32_t*)(lds + L.g_first + L.g_stride + L.order)};
@@ -763,8 +765,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                     const int32_t* const ord0 = (const int32_t*)(lds + L.g_first + L.order);
                                     const int c0 = ord0[sp0 * 2 * L.g_stride + r0], c1 = ord0[sp1 * 2 * L.g_stride + r1];
                                     const double *pa = lds + (sp0 ? cbo[1] : cbo[0]), *pc = lds + (sp1 ? cbo[1] : cbo[0]);
-                                    const ChildX<PB> cx[2] = {make_child_x(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, pa + M, pa + 3 * M),
-                                                              make_child_x(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, pc + M, pc + 3 * M)};
+                                    // (the parents' mixed momentum from the item's species' table, built where the generation began: the species' other elite buffer)
+                                    const ChildT<PB> cx[2] = {make_child_t(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, lds + (sp0 ? obo[1] : obo[0]), M),
+                                                              make_child_t(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, lds + (sp1 ? obo[1] : obo[0]), M)};
                                     PHASE_MARK(PH_REPRODUCE);
                                     eval_exact_primary_n<2, true>(pb, cx, qc, s_slots, pb->n_slots * 7 * nth, f, s_prefix);
                                     PHASE_MARK(PH_FITNESS);
