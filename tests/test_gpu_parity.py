@@ -499,6 +499,32 @@ def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeyp
     assert all(np.array_equal(x, y) for x, y in zip(a, c))
 
 
+def test_stragglers_that_leave_when_the_chip_runs_empty(gpus, oracles, templates, monkeypatch):
+    """SolveArgs::resident on the device: a chip-filling call of the latency schedule starts under the dense kernel and hands its stragglers to
+    k_solve_lean_cl4 when fewer than BIOIK_SOLVE_DRAIN_BELOW wavefronts are left -- which query leaves at which step is a matter of timing, the results
+    are not: equal to the one-kernel solve (threshold 0) bit for bit, for thresholds that hand over nearly everything and nearly nothing, with and
+    without islands; and the test pattern of the host simulator's suite (every unit at its own step) against the oracle"""
+    h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 4096, seed=41)
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=9)
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_BELOW", "0")
+    a = h.solve_batch(p, seeds, params)
+    for below in ("1024", "100000", "16"):
+        monkeypatch.setenv("BIOIK_SOLVE_DRAIN_BELOW", below)
+        b = h.solve_batch(p, seeds, params)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), below
+    p2 = abi.default_solve_params(population=128, max_steps=24, random_seed=9, islands=2, island_sync=1)
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_BELOW", "0")
+    a = h.solve_batch(p2, seeds[:2048], params[:2048])
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_BELOW", "2048")
+    b = h.solve_batch(p2, seeds[:2048], params[:2048])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    monkeypatch.delenv("BIOIK_SOLVE_DRAIN_BELOW")
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_TEST", "6")
+    pc.trajectory(h, o, t, n=48, pop=128, steps_list=(10,), schedule=abi.SCHEDULE_THROUGHPUT)
+    pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=16, pop=128, steps_list=(8,))
+
+
 def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
     """bioik_solve_params::island_sync = 1 on the device: islands of a query that run in different workgroups at different times, the answer still the
     oracle's lock-step answer bit for bit (an island leaves early only when its result can no longer be chosen)"""
