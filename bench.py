@@ -490,8 +490,8 @@ def main():
                      "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
                      "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
                              "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl64w4 (both "
-                             "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY two (k_solve_lean_cl: the first step of every query, "
-                             "k_solve_lean: the unsolved queries to the end); kernel_ms is the event-bracketed duration of a solve while %d solves "
+                             "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY one of k_solve_lean_cl4 (a wavefront per species) or, for a batch beyond what the "
+                             "chip holds of its workgroups, k_solve_lean_cl64w4 first and k_solve_lean_cl4 for the stragglers it hands over when the chip runs empty; kernel_ms is the event-bracketed duration of a solve while %d solves "
                              "share the chip, so `frac` is per solve and `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
                              "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
                      "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,

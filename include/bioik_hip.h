@@ -104,13 +104,14 @@ enum {
 };
 
 /* What the launcher optimises a solve for.
- * LATENCY (default): the time of THIS call.  A query gets the lanes that make its steps short (128: 96 us per step of the 7-joint arm), and a batch
- *   that fills the chip runs its first step under the denser mapping below and hands the unsolved queries over.  Three such solves in flight
- *   keep an MI355X busy.
+ * LATENCY (default): the time of THIS call.  A query gets the lanes that make its steps short (128: 95 us per step of the 7-joint arm; one query 0.93 ms), and a
+ *   batch beyond what the chip holds of such workgroups (3072 queries and more) starts under the denser mapping below -- every query resident from the first
+ *   moment -- and hands its stragglers to the short-step mapping when the chip runs empty (8.6 ms for 4096 queries).  Three such solves in flight keep an
+ *   MI355X busy.
  * THROUGHPUT: solves per second of a STREAM of batches.  Both species of a query share one wavefront and the children are computed where they
  *   are read, sixteen queries per CU: a third more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for
- *   up to 16 ms.  It pays with six to eight batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
- *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call a quarter more time (12.6 against 10.3 ms for 4096 queries).  Problems the denser mapping does not exist for (secondary
+ *   up to 12 ms.  It pays with six to ten batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
+ *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call a fifth more time (10.5 against 8.6 ms for 4096 queries).  Problems the denser mapping does not exist for (secondary
  *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      
  * AUTO: LATENCY, except in bioik_solve_batch_submit when two or more solves of the handle are already in flight: THROUGHPUT then (a caller
  *   that streams batches through the asynchronous entry gets the dense mapping once its pipeline is three deep: 8.4e5 against 8.0e5 solves/s
