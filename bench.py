@@ -110,7 +110,8 @@ def other_configs(dev, nfl, streams, cpu_baseline=False):
     n = 4096
     res = {}
     for name, template, pop, max_steps, n_moving, n_rev, n_pose, reps in (
-            ("c3", ProblemTemplate(pr2_like(), "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]), 128, 128, 17, 14, 2, 6),
+            # (c3: fifteen moving joints -- the torso and two arms of seven; the kernels walk the torso once per arm, the algorithm needs it once)
+            ("c3", ProblemTemplate(pr2_like(), "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]), 128, 128, 15, 14, 2, 6),
             ("c4", ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]), 512, 32, 31, 31, 1, 6)):
         h = HipSolver(template, device=dev.index)
         p = abi.default_solve_params(population=pop, max_steps=max_steps, random_seed=1)
@@ -128,11 +129,15 @@ def other_configs(dev, nfl, streams, cpu_baseline=False):
         suc, steps = np.full(n, suc_mean), np.full(n, steps_sum / n)
         gens = steps.sum() * 16
         # both configurations have a secondary goal: a generation walks a random prefix of its pre-selected children, uniform on
-        # 1 ... pop - 1 (ik_evolution_2.cpp:366-378), pop / 2 on average -- the algorithmic evaluations of the reference itself
-        evaluations = gens * pop * 0.5 + 4.0 * steps.sum()
+        # 1 ... lambda - 1 (ik_evolution_2.cpp:366-378).  Counted, not estimated: the prefix lengths are a function of the counter RNG (query, step,
+        # generation, species), so the steps the device reports for every query say how many children it walked (workload.preselected_children)
+        from bio_ik_amd.workload import preselected_children
+        cum = preselected_children(p.random_seed, 0, n, max_steps, pop)
+        walked = sum(float(cum[np.arange(n), o[3].cpu().numpy().astype(np.int64)].sum()) * share[k] for k, o in enumerate(bufs)) / reps  # per launch, over the timed launches
+        evaluations = walked + 4.0 * steps.sum()
         flops = evaluations * flops_per_evaluation(n_moving, n_rev, n_pose)
         b_gen = 8 * (pop * (3 * h.D + 1) + 8 * h.D)
-        res[name] = {"value": float(suc.sum()) / dt, "evaluations_note": "a generation walks pop / 2 children on average (random prefix of the pre-selection)", "unit": "solves/s", "ms_per_step": dt * 1e3, "success_rate": float(suc.mean()), "mean_steps_per_solve": float(steps.mean()),
+        res[name] = {"value": float(suc.sum()) / dt, "evaluations_per_launch": evaluations, "evaluations_note": "children walked = the random prefixes of the pre-selection, counted from the device-reported steps and the counter RNG (workload.preselected_children) + four exact evaluations per step", "unit": "solves/s", "ms_per_step": dt * 1e3, "success_rate": float(suc.mean()), "mean_steps_per_solve": float(steps.mean()),
                      "batch": n, "population": pop, "max_steps": max_steps, "D": h.D, "tips": h.T, "batches_in_flight": nfl, "batches_timed": reps, "kernel_ms": kernel_ms,
                      "roofline": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                                   "frac": flops / (kernel_ms * 1e-3) / FP64_PEAK, "chip_level_frac": flops / dt / FP64_PEAK,

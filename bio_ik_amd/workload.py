@@ -55,3 +55,43 @@ def make_queries(template, active_variables, fk_genes, n, seed=0xB101C, kind="gl
         elif g.opcode == abi.GOAL_ORIENTATION:
             params[:, off:off + 4] = frames[:, t, 3:]
     return seeds, params, targets
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# How many children a solve has walked: the counter RNG on the host (what bench.py's roofline counts for problems with secondary goals)
+# ---------------------------------------------------------------------------------------------------------------------------
+def philox2x32_10(key, c0, c1):
+    """Philox2x32-10 (Random123 constants) on uint32 arrays -- the control-draw generator of the kernels (csrc/bioik_device.h: philox2x32_10)"""
+    key = np.asarray(key, dtype=np.uint64) & 0xFFFFFFFF
+    c0 = np.asarray(c0, dtype=np.uint64) & 0xFFFFFFFF
+    c1 = np.asarray(c1, dtype=np.uint64) & 0xFFFFFFFF
+    key, c0, c1 = np.broadcast_arrays(key, c0, c1)
+    key, c0, c1 = key.copy(), c0.copy(), c1.copy()
+    for r in range(10):
+        if r > 0:
+            key = (key + 0x9E3779B9) & 0xFFFFFFFF
+        p = 0xD256D193 * c0  # (< 2^64: both factors are below 2^32)
+        hi, lo = p >> 32, p & 0xFFFFFFFF
+        c0 = hi ^ key ^ c1
+        c1 = lo
+    return c0.astype(np.uint32), c1.astype(np.uint32)
+
+
+def preselected_children(random_seed, first_query, n_queries, max_steps, population, generations=8):
+    """cum[q, s] = the children the kernels WALK (exact FK, primary goals) in the first s steps of query q of a problem with secondary goals: in every
+    generation of every step each of the two species walks a random prefix of its pre-selected children, n = o0 % (lambda - 1) + 1 with
+    o0 = philox2x32_10(key(q), 0, (step * 16 + generation) << 4 | species << 3 | RNG_PRESELECT)  (bioik_kernels.h: solve_body, `n_eval`;
+    reference: ik_evolution_2.cpp:366-378).  A function of the counters alone, so the host can count what the device did from the steps it reports."""
+    lam = population - 2
+    q = np.arange(n_queries, dtype=np.uint64) + np.uint64(first_query)
+    seed = np.uint64(random_seed)
+    key, _ = philox2x32_10(seed & np.uint64(0xFFFFFFFF), q & np.uint64(0xFFFFFFFF), (seed >> np.uint64(32)) ^ (q >> np.uint64(32)))  # (island 0: rng_query_key)
+    step = np.arange(max_steps, dtype=np.uint64)[None, :, None, None]
+    gen = np.arange(generations, dtype=np.uint64)[None, None, :, None]
+    species = np.arange(2, dtype=np.uint64)[None, None, None, :]
+    ctr1 = ((step * np.uint64(16) + gen) << np.uint64(4)) | (species << np.uint64(3)) | np.uint64(1)
+    o0, _ = philox2x32_10(key.astype(np.uint64)[:, None, None, None], np.uint64(0), ctr1)
+    per_step = (o0.astype(np.uint64) % np.uint64(lam - 1) + np.uint64(1)).sum(axis=(2, 3))
+    cum = np.zeros((n_queries, max_steps + 1), dtype=np.uint64)
+    np.cumsum(per_step, axis=1, out=cum[:, 1:])
+    return cum
