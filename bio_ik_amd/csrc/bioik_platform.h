@@ -113,7 +113,8 @@ BIOIK_DEV int p_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 2
 // vector-memory counter only become stricter for it, and the reader waits for the counter itself.
 BIOIK_DEV void p_prefetch_word_to_lds(const unsigned int* src, double* lds_slot) {
     const unsigned int lds_off = (unsigned int)(size_t)lds_slot;  // (the low half of a flat LDS address is the LDS offset)
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off sc1" : : "v"(src), "s"(lds_off) : "m0", "memory");
+    unsigned int m0_before;  // (M0 carries the LDS address of the instruction; whatever the compiler keeps there is put back)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0" : "=&s"(m0_before) : "v"(src), "s"(lds_off) : "memory");
 }
 BIOIK_DEV unsigned int p_prefetched_word(const double* lds_slot) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
