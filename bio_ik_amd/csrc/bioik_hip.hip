@@ -288,6 +288,7 @@ struct SolveSwitches {
     bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
+    int sort_key_drop = 10;     // BIOIK_SOLVE_SORT_KEY_DROP=b (parity suites, 10 ... 52): the pre-selection's sort keys give up b low bits of a fitness, so that the exact path runs often
     bool two_phase_set = false, two_phase_init = false;
     std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
     std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
@@ -315,6 +316,8 @@ static SolveSwitches parse_switches() {
     w.drain_throughput = geti("BIOIK_SOLVE_DRAIN_THROUGHPUT", 0) != 0;
     w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
     w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
+    w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
+    if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
         w.two_phase_init = std::strcmp(e, "init") == 0;
@@ -593,6 +596,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.params = d_params;
     a.phase_cycles = nullptr;
     a.launch_clock = nullptr;
+    a.sort_key_drop = sw.sort_key_drop;
     if (sp.timeout_ticks != 0) {
         a.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
         be_zero_async(a.launch_clock, sizeof(unsigned long long), stream);

@@ -231,6 +231,46 @@ BIOIK_DEV void sort_pairs_in_registers(double (&f)[E], int (&c)[E], int gtid, in
         }
     }
 }
+// The same network over 64-bit KEYS: one unsigned compare per exchange and two dwords per element instead of three compares and three dwords.  The caller
+// builds a key from a non-negative fitness and its child index (sort_key) -- unique, so every order is strict.
+template <int E>
+BIOIK_DEV void sort_keys_in_registers(unsigned long long (&key)[E], int gtid, int G) {
+    const int n = G * E;
+    for (int k = 2; k <= n; k <<= 1) {
+        const bool ascending = ((gtid * E) & k) == 0;
+        for (int j = k >> 1; j >= E; j >>= 1) {
+            const int d = j / E;
+            const bool keep_low = ((gtid & d) == 0) == ascending;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                const unsigned long long other = p_shfl_xor(key[i], d);
+                key[i] = ((key[i] > other) == keep_low) ? other : key[i];
+            }
+        }
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1) {
+            if (j >= k) continue;
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                if (i & j) continue;
+                const int i2 = i | j;
+                const bool asc = k >= E ? ascending : ((i & k) == 0);
+                const unsigned long long a = key[i], b = key[i2];
+                const bool swap = (a > b) == asc;
+                key[i] = swap ? b : a, key[i2] = swap ? a : b;
+            }
+        }
+    }
+}
+// A non-negative double orders like its bit pattern.  The key keeps the upper 54 bits of the pattern and carries the child index (< 1024) in the lower ten:
+// keys order like (fitness, index) wherever two fitness values differ above their lowest ten mantissa bits or not at all.  Pairs that differ ONLY there
+// (relative difference below 2.3e-13) are ordered by index, possibly wrongly -- the caller finds them among the sorted neighbours and sorts exactly then.
+// (drop: the low bits of the pattern the key gives up, ten in the product; the parity suites raise it so that the exact path is taken often)
+BIOIK_DEV unsigned long long sort_key(double f, int index, int drop) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &f, 8);
+    return (b & ~((1ull << drop) - 1ull)) | (unsigned long long)index;
+}
 // rendezvous of one lane group: a single wavefront needs no s_barrier (p_wave_sync), several wavefronts take the workgroup
 // barrier -- every group of the workgroup then executes the same number of them
 BIOIK_DEV void group_sync(int G) {
@@ -316,6 +356,7 @@ struct SolveArgs {
     // means the queue is empty and the chip is emptying: a unit that has run `drain_min_steps` steps then leaves for the next launch (the mapping with
     // the faster lone step) whatever step it is at, its step count travelling with its state; that launch has step_begin < 0 and reads it there.
     // Which units leave when depends on timing; their results do not (every mapping computes the same trajectory).
+    int32_t sort_key_drop = 10;                    // the pre-selection's sort keys give up this many low bits of a fitness for the child index (sort_key)
     unsigned int* resident = nullptr;              // [16][32]: word 32 x of XCD x
     int32_t drain_below = 0, drain_min_steps = 0;  // (wavefronts per XCD)  // (drain_below < 0: test pattern -- unit u leaves after 1 + hash(u) % -drain_below steps)
 };
@@ -631,7 +672,35 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 for (int j = 0; j < 4; j++) sf[i0 + j] = gtid * E + i0 + j < lambda ? e[j] : P_INF, sc[i0 + j] = gtid * E + i0 + j;
                             }
                             PHASE_MARK(PH_SELECTION);
-                            sort_pairs_in_registers<E>(sf, sc, gtid, G);
+                            // Keys first (sort_key: one compare and two dwords per exchange).  The exact values wait in LDS for the check behind the sort: sorted
+                            // neighbours whose keys agree above the index bits are equal (then the index order is the stable order) or differ in their lowest
+                            // ten mantissa bits only -- in that case, which a generation meets about once in a billion, the pairs are sorted again, exactly.
+                            bool exact_order = true;
+                            if constexpr (E * 64 <= 1024) {
+                                unsigned long long sk[E];
+#pragma unroll
+                                for (int i = 0; i < E; i++) sk[i] = sort_key(sf[i], sc[i], a.sort_key_drop), s_sec[gtid * E + i] = sf[i];
+                                sort_keys_in_registers<E>(sk, gtid, G);
+                                group_sync(G);  // (every lane's values are in LDS)
+                                const unsigned long long next_lane = p_shfl(sk[0], (tid & 63) + 1);  // (the first key of the lane behind this one; the group's last lane has none)
+                                bool wrong = false;
+#pragma unroll
+                                for (int i = 0; i < E; i++) {
+                                    const unsigned long long a = sk[i], b2 = i + 1 < E ? sk[i + 1 < E ? i + 1 : i] : next_lane;
+                                    const bool has_next = i + 1 < E || gtid + 1 < G;
+                                    if (has_next && ((a ^ b2) >> 10) == 0ull) wrong = wrong || s_sec[(int)(a & 0x3ffull)] > s_sec[(int)(b2 & 0x3ffull)];
+                                }
+                                exact_order = p_ballot(wrong) == 0ull;  // (both halves of a wavefront that carries two species decide together: the network is the same code)
+#pragma unroll
+                                for (int i = 0; i < E; i++) sc[i] = (int)(sk[i] & 0x3ffull);
+                                if (!exact_order) {
+#pragma unroll
+                                    for (int i = 0; i < E; i++) sc[i] = gtid * E + i, sf[i] = s_sec[gtid * E + i];
+                                }
+                            } else {
+                                exact_order = false;
+                            }
+                            if (!exact_order) sort_pairs_in_registers<E>(sf, sc, gtid, G);
 #pragma unroll
                             for (int i = 0; i < E; i++) s_order[gtid * E + i] = sc[i];
                             group_sync(G);

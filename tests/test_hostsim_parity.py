@@ -406,6 +406,23 @@ def test_joint_walk_under_the_small_register_budget(sims, oracles, templates, mo
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=64, steps_list=(3,))
 
 
+def test_preselection_sort_keys_and_the_exact_path_behind_them(sims, oracles, templates, monkeypatch):
+    """The pre-selection orders the children of a species by 64-bit keys -- the upper 54 bits of a secondary fitness and the child index -- and sorts
+    exactly whenever sorted neighbours differ in the dropped bits only (about once in a billion generations).  With keys that give up 36 or 50 bits that
+    happens in most generations: the oracle's trajectories bit for bit either way, for four and for eight children per lane (C3's and C4's kernels),
+    for all-zero costs (C4: every child inside AvoidJointLimitsGoal's free zone ties with every other) and for the generic computed-children kernel."""
+    for drop in ("36", "50", "10"):
+        monkeypatch.setenv("BIOIK_SOLVE_SORT_KEY_DROP", drop)
+        pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=512, steps_list=(2,))
+        for k, v in {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}.items():
+            monkeypatch.setenv(k, v)
+        pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
+        monkeypatch.setenv("BIOIK_SOLVE_THREE_WAVES", "1")
+        pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=1, pop=100, steps_list=(2,))
+        for k in ("BIOIK_SOLVE_THREADS", "BIOIK_SOLVE_SPECIES_PARALLEL", "BIOIK_SOLVE_COLUMNLESS", "BIOIK_SOLVE_THREE_WAVES"):
+            monkeypatch.delenv(k)
+
+
 def test_units_that_change_launch_at_their_own_step(sims, oracles, templates, monkeypatch):
     """SolveArgs::resident: the throughput schedule's stragglers leave for the launch with the faster lone step when the chip runs empty -- every
     unit from whatever step it is at, its step count travelling with its state.  Which unit leaves when is a matter of timing on the device; here
