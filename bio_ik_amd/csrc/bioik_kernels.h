@@ -262,6 +262,16 @@ BIOIK_DEV void sort_keys_in_registers(unsigned long long (&key)[E], int gtid, in
         }
     }
 }
+// the least key of a half-wavefront group, known to all of its lanes: one permute across the two rows of 16, then DPP moves inside a row (as top2_wave)
+BIOIK_DEV unsigned long long half_min_u64(unsigned long long k) {
+    unsigned long long o = p_shfl_xor(k, 16);
+    k = o < k ? o : k;
+    o = p_row_mirror<0>(k), k = o < k ? o : k;
+    o = p_row_mirror<1>(k), k = o < k ? o : k;
+    o = p_quad_xor<2>(k), k = o < k ? o : k;
+    o = p_quad_xor<1>(k), k = o < k ? o : k;
+    return k;
+}
 // A non-negative double orders like its bit pattern.  The key keeps the upper 54 bits of the pattern and carries the child index (< 1024) in the lower ten:
 // keys order like (fitness, index) wherever two fitness values differ above their lowest ten mantissa bits or not at all.  Pairs that differ ONLY there
 // (relative difference below 2.3e-13) are ordered by index, possibly wrongly -- the caller finds them among the sorted neighbours and sorts exactly then.
@@ -859,13 +869,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 if (i0r < total) (lds + L.g_first + sp0 * L.g_stride + L.fitp)[r0] = f[0];
                                 if (i0r + 64 < total) (lds + L.g_first + sp1 * L.g_stride + L.fitp)[r1] = f[1];
                             }
-                            p_wave_sync();
-                            {
-                                BIOIK_LANE_SCOPE;
-                                const double* const s_fit2 = gbase + L.fitp;
-                                const int ne_own = grp ? total - ne0 : ne0;
-                                for (int r = gtid; r < ne_own; r += G) offer(s_fit2[r], r + 2);
-                            }
+                            p_wave_sync();  // (the selection below reads the parked values of its own species back, as keys)
                         } else {
                         for (int i0 = tid; i0 < total; i0 += 128) {
                             const int i1 = i0 + 64 < total ? i0 + 64 : i0;  // (an odd tail repeats the first item and drops it)
@@ -939,7 +943,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             if (r < n_eval) s_fit[r] = f[0];
                             if (two) s_fit[r1] = f[1];
                         }
-                        {
+                        if constexpr (!DENSE) {  // (DENSE: the selection below reads the parked values itself, as keys)
                             BIOIK_LANE_SCOPE;
                             const double* const s_fit2 = gbase + L.fitp;
                             for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);  // (its own entries: a lane's LDS accesses stay in program order)
@@ -987,7 +991,38 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t ctr1w = SLIM ? rng_ctr1((uint32_t)step * 16u + (uint32_t)gen, (uint32_t)S.id, RNG_REPRODUCE) : ctr1;  // (the winners' stream: not carried through the walks under SLIM)
                 // (the joint walk has reduced over the whole wavefront already; under SLIM it parks its values like the other walks, and the reduction
                 // inside the half stands here, between the lanes' reads of the species record above and its update below)
-                if (!JOINT || SLIM) top2_wave(b1f, b1p, b2f, b2p, G);
+                if constexpr (DENSE || JH) {
+                    // The two best children of a half-wavefront's species from KEYS (sort_key: the fitness's upper bits and the position): a lane's candidates
+                    // are its entries of the parked values, the group's least key and the least of the rest are two minimum reductions of one 64-bit number
+                    // each (against a butterfly that merges sorted (fitness, position) pairs: half the instructions).  Exact unless a second candidate
+                    // shares the upper bits of a winner's fitness: the runner-up is the second least key, so nobody shares the winner's unless the runner-up
+                    // does, and the candidates that share the runner-up's are counted; then, or on exact ties, the pairs themselves are reduced.
+                    const double* const s_fit2 = gbase + L.fitp;
+                    const int drop = a.sort_key_drop;
+                    unsigned long long k1 = ~0ull, k2 = ~0ull;
+                    for (int r = gtid; r < n_eval; r += G) {
+                        const unsigned long long k = sort_key(s_fit2[r], r + 2, drop);
+                        const bool w1 = k < k1, w2 = k < k2;
+                        k2 = w1 ? k1 : (w2 ? k : k2);
+                        k1 = w1 ? k : k1;
+                    }
+                    const unsigned long long B1 = half_min_u64(k1);
+                    const unsigned long long B2 = half_min_u64(k1 == B1 ? k2 : k1);
+                    int shares = 0;  // this lane's candidates with the runner-up's upper bits (the runner-up itself is one of the group's)
+                    for (int r = gtid; r < n_eval; r += G) shares += ((sort_key(s_fit2[r], r + 2, drop) ^ B2) >> drop) == 0ull ? 1 : 0;
+                    const unsigned long long one = p_ballot(shares > 0), more = p_ballot(shares > 1);
+                    const uint32_t mine = grp ? (uint32_t)(one >> 32) : (uint32_t)one;
+                    const bool in_doubt = B2 != ~0ull && ((mine & (mine - 1u)) != 0u);
+                    if (p_ballot(in_doubt) == 0ull && more == 0ull) {  // (the halves of the wavefront decide together: one path through the code)
+                        b1p = (int)(B1 & 1023ull), b1f = s_fit2[b1p - 2];
+                        if (B2 != ~0ull) b2p = (int)(B2 & 1023ull), b2f = s_fit2[b2p - 2];
+                    } else {
+                        for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);
+                        top2_wave(b1f, b1p, b2f, b2p, G);
+                    }
+                } else {
+                    if (!JOINT || SLIM) top2_wave(b1f, b1p, b2f, b2p, G);
+                }
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 PHASE_MARK(PH_SEL_XWAVE);

@@ -59,6 +59,16 @@ BIOIK_DEV double p_quad_xor(double v) {
     const int lo = p_quad_xor<MASK>((int)b), hi = p_quad_xor<MASK>((int)(b >> 32));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+template <int HALF>
+BIOIK_DEV unsigned long long p_row_mirror(unsigned long long v) {
+    const int lo = p_row_mirror<HALF>((int)v), hi = p_row_mirror<HALF>((int)(v >> 32));
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+template <int MASK>
+BIOIK_DEV unsigned long long p_quad_xor(unsigned long long v) {
+    const int lo = p_quad_xor<MASK>((int)v), hi = p_quad_xor<MASK>((int)(v >> 32));
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
 BIOIK_DEV int p_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // the value lane `lane` of the wavefront holds (lane: wavefront-uniform), in every lane: v_readlane_b32, a scalar register as the carrier
 BIOIK_DEV int p_read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

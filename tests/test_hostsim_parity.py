@@ -410,10 +410,14 @@ def test_preselection_sort_keys_and_the_exact_path_behind_them(sims, oracles, te
     """The pre-selection orders the children of a species by 64-bit keys -- the upper 54 bits of a secondary fitness and the child index -- and sorts
     exactly whenever sorted neighbours differ in the dropped bits only (about once in a billion generations).  With keys that give up 36 or 50 bits that
     happens in most generations: the oracle's trajectories bit for bit either way, for four and for eight children per lane (C3's and C4's kernels),
-    for all-zero costs (C4: every child inside AvoidJointLimitsGoal's free zone ties with every other) and for the generic computed-children kernel."""
+    for all-zero costs (C4: every child inside AvoidJointLimitsGoal's free zone ties with every other) and for the generic computed-children kernel.  The
+    half-wavefront kernels pick the two best children of a generation from keys of the same kind (the primary fitness's upper bits and the position),
+    with the exact reduction behind a count of the candidates that share the runner-up's upper bits."""
     for drop in ("36", "50", "10"):
         monkeypatch.setenv("BIOIK_SOLVE_SORT_KEY_DROP", drop)
         pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=512, steps_list=(2,))
+        # (the same keys pick the two best children of a generation in the half-wavefront kernels: the dense kernel here, the joint walk below)
+        pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=4, pop=128, steps_list=(4,), schedule=abi.SCHEDULE_THROUGHPUT)
         for k, v in {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}.items():
             monkeypatch.setenv(k, v)
         pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
