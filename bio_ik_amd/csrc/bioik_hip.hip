@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -76,6 +77,11 @@ static void* be_alloc_async(size_t bytes, stream_t s) {
 }
 static void be_free_async(void* p, stream_t s) {
     if (p) (void)hipFreeAsync(p, s);
+}
+static bool be_stream_capturing(stream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+    return st != hipStreamCaptureStatusNone;
 }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t s) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
@@ -245,6 +251,14 @@ struct bioik_problem {
     unsigned clock_next = 0;
     static constexpr unsigned kClocks = 64;
     unsigned int* d_resident = nullptr;  // workgroups of the throughput schedule's launches that are running now (SolveArgs::resident), all streams of this handle
+    // Scratch of a solve that needs some (per-island results, the state of handed-over units): one persistent buffer per (stream, purpose), grown when a
+    // solve asks for more.  Solves on one stream follow each other, so they may share it; solves on other streams have their own.  (Stream-ordered
+    // allocations did this until round 4 -- but a captured graph that contains an allocation and its release aborts on its second replay on this ROCm.)
+    struct Scratch {
+        void* base = nullptr;
+        size_t capacity = 0;
+    };
+    std::map<std::pair<stream_t, int>, Scratch> scratch;
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
     ProbPtr pb() const { return (ProbPtr)d_pb; }
@@ -405,7 +419,26 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
-    void* island_ws = nullptr;  // per-island results of this launch (islands > 1), stream-ordered; released on every path out
+    // scratch of this solve: the handle's persistent buffer for (stream, purpose), or -- while the stream is being captured and the buffer would have to
+    // grow, or for the sixty-fifth stream of a handle -- a stream-ordered allocation released on every path out (null: nothing to release)
+    auto scratch = [&](int purpose, size_t bytes, void*& async_owned) -> void* {
+        const auto key = std::make_pair(stream, purpose);
+        auto it = p->scratch.find(key);
+        if (it == p->scratch.end() && p->scratch.size() < 128) it = p->scratch.emplace(key, bioik_problem::Scratch{}).first;
+        if (it != p->scratch.end()) {
+            bioik_problem::Scratch& sc = it->second;
+            if (sc.capacity >= bytes) return sc.base;
+            if (!be_stream_capturing(stream)) {
+                be_free(sc.base);  // (hipFree waits for the work that may still use it)
+                sc.base = nullptr, sc.capacity = 0;
+                sc.base = be_alloc(bytes + bytes / 2), sc.capacity = bytes + bytes / 2;
+                return sc.base;
+            }
+        }
+        async_owned = be_alloc_async(bytes, stream);
+        return async_owned;
+    };
+    void* island_ws = nullptr;  // (a stream-ordered fallback allocation of the per-island results, if any)
     struct AsyncFree {
         void*& p;
         stream_t s;
@@ -418,8 +451,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             return;
         }
         const size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
-        island_ws = be_alloc_async(units * per + 64 + n * 4, stream);
-        char* w = (char*)island_ws;
+        char* w = (char*)scratch(0, units * per + 64 + n * 4, island_ws);
         args.solutions = (double*)w, w += units * dp.V * 8;
         args.fitness = (double*)w, w += units * 8;
         args.success = (int32_t*)w, w += units * 4;
@@ -557,8 +589,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
     const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
                           dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
+    // (not on a stream that is being captured: a hipGraph with the two launches of this hand-over returns a wrong result for unit 0 from its SECOND replay on
+    // -- the second launch finds a count of one and continues unit 0 from a state nobody wrote; eager calls, back to back on one stream or not, and graphs of
+    // the hand-over after a fixed step are right; unexplained, DESIGN.md section 8 -- so captured calls get the one-launch mapping, which replays correctly)
+    const bool capturing = be_stream_capturing(stream);
     const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 3072 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
-                               !sw.two_phase_set;
+                               !sw.two_phase_set && !capturing;
     const bool dense = (throughput || latency_drain) && dense_ok;
     if (sw.columnless > 0 && can_columnless) {
         sp.columnless = 1, sp.child_cols = 1;
@@ -668,7 +704,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     } else if (throughput) {
         // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
         if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
-        else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1) when_draining = true, handovers.push_back(sp.max_steps);
+        else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing) when_draining = true, handovers.push_back(sp.max_steps);
     } else if (latency_drain) {
         when_draining = true, handovers.push_back(sp.max_steps);
     } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
@@ -700,8 +736,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const size_t carry_n = 9 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;  // (solve_body: carry_n)
         const size_t list_bytes = (units * 4 + 63) / 64 * 64;
         const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + nh * list_bytes;
-        void* ws = be_alloc_async(count_off + nh * 64, stream);
-        AsyncFree ws_guard{ws, stream};
+        void* ws_async = nullptr;
+        AsyncFree ws_guard{ws_async, stream};
+        void* ws = scratch(1, count_off + nh * 64, ws_async);
         be_zero_async((char*)ws + count_off, nh * 64, stream);
         for (size_t j = 0; j <= nh; j++) {  // launch j runs the steps [handovers[j-1], handovers[j])
             SolveArgs aj = a;
@@ -810,6 +847,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     be_free(p->d_pb);
     be_free(p->d_clocks);
     be_free(p->d_resident);
+    for (auto& kv : p->scratch) be_free(kv.second.base);
     for (auto& sl : p->io) {
         if (sl.pending) {  // (a submitted solve nobody waited for: let it finish before its buffers go)
             try {

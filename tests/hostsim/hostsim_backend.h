@@ -23,6 +23,7 @@ static void be_free(void* p) { std::free(p); }
 static void* be_alloc_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 static void be_free_pinned(void* p) { std::free(p); }
 static void* be_alloc_async(size_t bytes, stream_t) { return std::malloc(bytes ? bytes : 1); }
+static bool be_stream_capturing(stream_t) { return false; }
 static void be_free_async(void* p, stream_t) { std::free(p); }
 static void be_h2d(void* d, const void* h, size_t bytes, stream_t) { std::memcpy(d, h, bytes); }
 static void be_d2h(void* h, const void* d, size_t bytes, stream_t) { std::memcpy(h, d, bytes); }

@@ -525,6 +525,36 @@ def test_stragglers_that_leave_when_the_chip_runs_empty(gpus, oracles, templates
     pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=16, pop=128, steps_list=(8,))
 
 
+def test_hipgraph_capture_of_a_chip_filling_call(gpus, templates):
+    """bioik_solve_batch_device enqueues on the caller's stream without synchronising: a chip-filling call of the latency schedule -- two launches, a
+    stream-ordered workspace, the resident words -- can be captured into a hipGraph and replayed; the replay's results equal the eager call's"""
+    import torch
+    h, t = gpus["c2"], templates["c2"]
+    n = 4096
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=43)
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=3)
+    ref = h.solve_batch(p, seeds, params)
+    dev = torch.device("cuda", 0)
+    ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
+    o = (torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+         torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+    s = torch.cuda.Stream(dev)
+
+    def enqueue():
+        h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), s.cuda_stream)
+    with torch.cuda.stream(s):
+        enqueue()  # (warm: allocations of the first call stay outside the capture)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        enqueue()
+    for _ in range(2):
+        o[0].zero_(), o[2].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3])
+
+
 def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
     """bioik_solve_params::island_sync = 1 on the device: islands of a query that run in different workgroups at different times, the answer still the
     oracle's lock-step answer bit for bit (an island leaves early only when its result can no longer be chosen)"""
