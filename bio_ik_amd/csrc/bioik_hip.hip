@@ -591,9 +591,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
     const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
                           dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
-    // (not on a stream that is being captured: a hipGraph with the two launches of this hand-over returns a wrong result for unit 0 from its SECOND replay on
-    // -- the second launch finds a count of one and continues unit 0 from a state nobody wrote; eager calls, back to back on one stream or not, and graphs of
-    // the hand-over after a fixed step are right; unexplained, DESIGN.md section 8 -- so captured calls get the one-launch mapping, which replays correctly)
+    // (not on a stream that is being captured: a hipGraph of a 4096-query solve in TWO launches -- this hand-over or the one after a fixed step -- is right on
+    // its first replay and wrong (unit 0 continued from a state nobody wrote) or aborting from its second on, whatever the resident words do; eager calls, back
+    // to back on one stream or not, are right; unexplained, DESIGN.md section 8 -- so captured calls get a one-launch mapping, which replays correctly)
     const bool capturing = be_stream_capturing(stream);
     const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 3072 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set && !capturing;
@@ -709,7 +709,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing) when_draining = true, handovers.push_back(sp.max_steps);
     } else if (latency_drain) {
         when_draining = true, handovers.push_back(sp.max_steps);
-    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24) {
+    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24 && !capturing) {
         // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
         // profiles/r04_ab_latency_schedule_kernel.log)
         handovers.push_back(1);
