@@ -292,11 +292,13 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
 
 /* Device-pointer variant: all arrays already resident in HBM on the problem's device; enqueues on
  * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising.
- * Solves of ONE problem handle on different streams may be in flight together (their result arrays must differ; all
- * scratch is allocated and released in stream order): keeping two or three batches in flight hides the slow tail of each
+ * Solves of ONE problem handle on different streams may be in flight together (their result arrays must differ; the scratch
+ * of a solve is one persistent buffer per (handle, stream), taken from the stream-ordered pool by the first call on that stream and
+ * released with the handle): keeping two or three batches in flight hides the slow tail of each
  * solve behind the bulk of the next.  A call enqueues one kernel or a short chain of kernels (large
- * batches pass their unsolved queries from a first launch to a second through device memory; islands > 1 add a selection
- * kernel); nothing in it waits for the host, so it may be captured into a hipGraph. */
+ * batches pass their stragglers from a first launch to a second through device memory; islands > 1 add a selection
+ * kernel); nothing in it waits for the host, so it may be captured into a hipGraph and replayed: make one eager call on the stream
+ * first (it sizes the scratch); a call on a capturing stream always takes a one-launch mapping. */
 int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds,
                              const double* d_goal_params, double* d_solutions, double* d_fitness,
                              int32_t* d_success, int32_t* d_steps, void* hip_stream);
