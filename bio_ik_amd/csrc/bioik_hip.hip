@@ -90,8 +90,27 @@ static void be_d2h(void* h, const void* d, size_t bytes, stream_t s) {
     if (bytes) HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
 }
 static void be_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize(s)); }
-static void be_zero_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
-static void be_fill_ff_async(void* p, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(p, 0xff, bytes, s)); }
+// The words a solve needs (re)set in stream order -- the hand-over's counters, the launch clock, the islands' first-success words -- are written by a KERNEL
+// of this library, not by hipMemsetAsync: a hipGraph that holds a memset node in front of these kernels replays correctly once and writes to a wild address
+// from its second replay on under this runtime's AQL packet capture (ROCm 7.2; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 cures it, so does having no memset node:
+// profiles/r05_graph_replay_root_cause.log, tools/graph_replay_raw_probe.py).  g_memset_nodes (BIOIK_SOLVE_MEMSET_NODES=1) brings the memsets back for that probe.
+__global__ void __launch_bounds__(256) k_fill_words(unsigned int* p, size_t n, unsigned int value) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+static bool g_memset_nodes = false;
+static void be_fill_async(void* p, size_t bytes, int byte_value, stream_t s) {  // bytes: a multiple of four
+    if (bytes == 0) return;
+    if (g_memset_nodes) {
+        HIP_CHECK(hipMemsetAsync(p, byte_value, bytes, s));
+        return;
+    }
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned int*)p, n, (unsigned int)(byte_value & 0xff) * 0x01010101u);
+    HIP_CHECK(hipGetLastError());
+}
+static void be_zero_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0, s); }
+static void be_fill_ff_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0xff, s); }
 static stream_t be_stream_create() {
     hipStream_t s = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -254,11 +273,15 @@ struct bioik_problem {
     // Scratch of a solve that needs some (per-island results, the state of handed-over units): one persistent buffer per (stream, purpose), grown when a
     // solve asks for more.  Solves on one stream follow each other, so they may share it; solves on other streams have their own.  (Stream-ordered
     // allocations did this until round 4 -- but a captured graph that contains an allocation and its release aborts on its second replay on this ROCm.)
+    // Lifetime under hipGraph capture: a captured solve bakes the buffer's address into its graph, so a buffer a capture has used is PINNED -- it is never
+    // released or handed to an eager solve again before the handle goes; the next eager solve on that stream retires it (the graphs keep it) and allocates its own.
     struct Scratch {
         void* base = nullptr;
         size_t capacity = 0;
+        bool pinned = false;
     };
     std::map<std::pair<stream_t, int>, Scratch> scratch;
+    std::vector<void*> retired_scratch;  // pinned buffers that eager solves have moved away from: captured graphs may still replay into them
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
     ProbPtr pb() const { return (ProbPtr)d_pb; }
@@ -302,10 +325,13 @@ struct SolveSwitches {
     bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
+    bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
+    bool capture_one_launch = false;  // BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: a call on a stream that is being captured gets a one-launch mapping (round 4's rule)
     int sort_key_drop = 10;     // BIOIK_SOLVE_SORT_KEY_DROP=b (parity suites, 10 ... 52): the pre-selection's sort keys give up b low bits of a fitness, so that the exact path runs often
     bool two_phase_set = false, two_phase_init = false;
     std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
     std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
+    std::string handover_dump;    // BIOIK_SOLVE_HANDOVER_DUMP=path (probes): every solve in several launches appends "scratch list_off count_off units" to this file
     bool manual() const { return threads > 0 || store_children >= 0 || child_pairs >= 0 || species_parallel >= 0 || columnless >= 0; }
 };
 static SolveSwitches parse_switches() {
@@ -331,6 +357,8 @@ static SolveSwitches parse_switches() {
     w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
     w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
+    w.capture_one_launch = geti("BIOIK_SOLVE_CAPTURE_ONE_LAUNCH", 0) != 0;
+    w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -344,10 +372,17 @@ static SolveSwitches parse_switches() {
         }
     }
     if (const char* e = std::getenv("BIOIK_PHASE_DUMP")) w.phase_dump = e;
+    if (const char* e = std::getenv("BIOIK_SOLVE_HANDOVER_DUMP")) w.handover_dump = e;
     return w;
 }
 static std::mutex g_switch_mtx;
-static SolveSwitches g_switches = parse_switches();
+static SolveSwitches apply_switches(SolveSwitches w) {  // (what the back end itself reads of them)
+#if !defined(BIOIK_BACKEND_HEADER)
+    g_memset_nodes = w.memset_nodes;
+#endif
+    return w;
+}
+static SolveSwitches g_switches = apply_switches(parse_switches());
 static SolveSwitches switches() {
     std::lock_guard<std::mutex> lock(g_switch_mtx);
     return g_switches;
@@ -427,8 +462,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         if (it == p->scratch.end() && p->scratch.size() < 128) it = p->scratch.emplace(key, bioik_problem::Scratch{}).first;
         if (it != p->scratch.end()) {
             bioik_problem::Scratch& sc = it->second;
-            if (sc.capacity >= bytes) return sc.base;
-            if (!be_stream_capturing(stream)) {
+            if (be_stream_capturing(stream)) {
+                if (sc.capacity >= bytes) {
+                    sc.pinned = true;  // (the graph being captured keeps this address: see bioik_problem::Scratch)
+                    return sc.base;
+                }
+            } else {
+                if (sc.pinned) p->retired_scratch.push_back(sc.base), sc = bioik_problem::Scratch{};
+                if (sc.capacity >= bytes) return sc.base;
                 // (stream-ordered on THIS stream, kept until it has to grow or the handle goes: no call here waits for the device -- hipMalloc / hipFree do, which
                 // cost the first solves of a pipeline over the handle's six streams a factor of three)
                 be_free_async(sc.base, stream);
@@ -594,7 +635,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // (not on a stream that is being captured: a hipGraph of a 4096-query solve in TWO launches -- this hand-over or the one after a fixed step -- is right on
     // its first replay and wrong (unit 0 continued from a state nobody wrote) or aborting from its second on, whatever the resident words do; eager calls, back
     // to back on one stream or not, are right; unexplained, DESIGN.md section 8 -- so captured calls get a one-launch mapping, which replays correctly)
-    const bool capturing = be_stream_capturing(stream);
+    const bool capturing = sw.capture_one_launch && be_stream_capturing(stream);
     const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 3072 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set && !capturing;
     const bool dense = (throughput || latency_drain) && dense_ok;
@@ -742,6 +783,11 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         AsyncFree ws_guard{ws_async, stream};
         void* ws = scratch(1, count_off + nh * 64, ws_async);
         be_zero_async((char*)ws + count_off, nh * 64, stream);
+        if (!sw.handover_dump.empty())
+            if (FILE* f = std::fopen(sw.handover_dump.c_str(), "a")) {
+                std::fprintf(f, "%llu %zu %zu %llu %zu\n", (unsigned long long)(size_t)ws, list_off, count_off, (unsigned long long)units, carry_n);
+                std::fclose(f);
+            }
         for (size_t j = 0; j <= nh; j++) {  // launch j runs the steps [handovers[j-1], handovers[j])
             SolveArgs aj = a;
             int lanes = nth;
@@ -792,7 +838,7 @@ int bioik_goal_param_count(int goal_type) { return bioik::goal_param_count(goal_
 int bioik_debug_reload_switches(void) {  // diagnostics only: the BIOIK_SOLVE_* switches are otherwise read once, when the library is loaded
     SolveSwitches w = parse_switches();
     std::lock_guard<std::mutex> lock(g_switch_mtx);
-    g_switches = std::move(w);
+    g_switches = apply_switches(std::move(w));
     return BIOIK_OK;
 }
 
@@ -850,6 +896,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     be_free(p->d_clocks);
     be_free(p->d_resident);
     for (auto& kv : p->scratch) be_free(kv.second.base);
+    for (void* q : p->retired_scratch) be_free(q);
     for (auto& sl : p->io) {
         if (sl.pending) {  // (a submitted solve nobody waited for: let it finish before its buffers go)
             try {

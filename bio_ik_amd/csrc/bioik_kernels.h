@@ -439,8 +439,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     static_assert(CL || !JOINT, "the joint walk of both species' children exists for computed children only");
     const bool resume = a.unit_list != nullptr;
     if (resume) {  // (uniform over the workgroup, before the first barrier)
-        if (unit >= (uint64_t)*a.unit_count) return;
-        unit = (uint64_t)a.unit_list[unit];
+        if (unit >= (uint64_t)p_atomic_load(a.unit_count)) return;
+        unit = (uint64_t)p_load_device(a.unit_list + unit);  // (device-scope loads of everything the last launch left: bioik_platform.h, p_load_device)
     }
     typedef typename std::conditional<LEAN, LeanProbPtr, ProbPtr>::type PB;
     const PB pb = (PB)a.pb;
@@ -550,13 +550,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     } else {
         const double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < M + 24; i += nth) {
-            const double v = c[2 * BF + i];
+            const double v = p_load_device(c + 2 * BF + i);
             if (i < M) s_sol[i] = v;
             else s_state[i - M] = v;
         }
         for (int i = tid; i < 2 * BF; i += nth) {  // species of rank r: into buffer 0 of its slot (the record travels with cur = 0)
             const int r = i >= BF ? 1 : 0;
-            s_pop[(int)c[2 * BF + M + r * 8 + 4] * SP + (i - r * BF)] = c[i];
+            s_pop[(int)p_load_device(c + 2 * BF + M + r * 8 + 4) * SP + (i - r * BF)] = p_load_device(c + i);
         }
     }
     for (int k = tid; k < n_ops; k += nth) s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
@@ -1409,11 +1409,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < 2 * BF; i += nth) {
             const int r = i >= BF ? 1 : 0;
-            c[i] = s_pop[(int)s_state[r * 8 + 4] * SP + (int)s_state[r * 8 + 5] * BF + (i - r * BF)];  // (slot, cur of the species of rank r: species_store)
+            p_store_device(c + i, s_pop[(int)s_state[r * 8 + 4] * SP + (int)s_state[r * 8 + 5] * BF + (i - r * BF)]);  // (slot, cur of the species of rank r: species_store)
         }
         // (slot 16 of the bookkeeping, a broadcast slot between the steps: the step count, for a launch that continues every unit where it stands)
-        for (int i = tid; i < M + 24; i += nth) c[2 * BF + i] = i < M ? s_sol[i] : ((i - M == 5 || i - M == 13) ? 0.0 : (i - M == 16 ? (double)steps : s_state[i - M]));
-        if (tid == 0) a.carry_list[p_atomic_inc(a.carry_count)] = (int32_t)unit;
+        for (int i = tid; i < M + 24; i += nth) p_store_device(c + 2 * BF + i, i < M ? s_sol[i] : ((i - M == 5 || i - M == 13) ? 0.0 : (i - M == 16 ? (double)steps : s_state[i - M])));
+        if (tid == 0) p_store_device(a.carry_list + p_atomic_inc(a.carry_count), (int32_t)unit);
     }
 
     // result of this island; ranking fitness of ik_parallel.h:229-246
@@ -1448,6 +1448,7 @@ struct SelectArgs {
     int32_t* success;
     int32_t* steps;
 };
+// (the islands' results were written by the launches in front of this one: device-scope loads, p_load_device)
 BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
     if (q >= a.n) return;
     int best = 0;
@@ -1456,23 +1457,23 @@ BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
     if (a.sync)
         for (int i = 0; i < a.islands; i++) {
             uint64_t u = q * (uint64_t)a.islands + i;
-            if (a.isl_success[u] && a.isl_steps[u] < least_steps) least_steps = a.isl_steps[u];
+            if (p_load_device(a.isl_success + u) && p_load_device(a.isl_steps + u) < least_steps) least_steps = p_load_device(a.isl_steps + u);
         }
     for (int i = 0; i < a.islands; i++) {
         uint64_t u = q * (uint64_t)a.islands + i;
-        if (a.isl_success[u] && (!a.sync || a.isl_steps[u] == least_steps) && a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
+        if (p_load_device(a.isl_success + u) && (!a.sync || p_load_device(a.isl_steps + u) == least_steps) && p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
     }
     if (best_fit == BIOIK_DBL_MAX) {
         for (int i = 0; i < a.islands; i++) {
             uint64_t u = q * (uint64_t)a.islands + i;
-            if (a.isl_fitness[u] < best_fit) best_fit = a.isl_fitness[u], best = i;
+            if (p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
         }
     }
     uint64_t u = q * (uint64_t)a.islands + best;
-    for (int v = 0; v < a.V; v++) a.solutions[q * a.V + v] = a.isl_solutions[u * a.V + v];
+    for (int v = 0; v < a.V; v++) a.solutions[q * a.V + v] = p_load_device(a.isl_solutions + u * a.V + v);
     a.fitness[q] = best_fit;
-    a.success[q] = a.isl_success[u];
-    a.steps[q] = a.isl_steps[u];
+    a.success[q] = p_load_device(a.isl_success + u);
+    a.steps[q] = p_load_device(a.isl_steps + u);
 }
 
 // ---------------------------------------------------------------------------------------------------------

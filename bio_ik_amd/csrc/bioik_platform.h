@@ -136,6 +136,21 @@ BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) { (void)atom
 // (a word other workgroups of this device write: device scope -- the default scope of __atomic_load_n is the system's, a load that no cache may answer:
 // 4096 workgroups reading one word once per step that way cost a stream of solves 13 % of its throughput, profiles/r04_drain_handover.log)
 BIOIK_DEV unsigned int p_atomic_load(const unsigned int* word) { return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The state a unit hands from one launch to the next (SolveArgs::carry, carry_list): written and read with DEVICE-scope accesses (global_store / global_load
+// ... sc1).  The chip has eight XCDs with an L2 each; a plain load may be answered by a line the reader's L2 kept from an EARLIER launch, and what makes
+// that impossible between two eager launches -- the acquire at the start of every dispatch -- is not there between the kernel nodes of a replayed hipGraph
+// (tools/micro/graph_handover_repro.hip: wrong from the second replay on with plain accesses, right with these).
+#if defined(BIOIK_HANDOVER_PLAIN)  // (A/B builds only: the accesses as they were until round 4)
+template <class T>
+BIOIK_DEV T p_load_device(const T* p) { return *p; }
+template <class T>
+BIOIK_DEV void p_store_device(T* p, T v) { *p = v; }
+#else
+template <class T>
+BIOIK_DEV T p_load_device(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+BIOIK_DEV void p_store_device(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 #define P_INF (__builtin_inf())
 #define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
 #define BIOIK_HD __host__ __device__ inline

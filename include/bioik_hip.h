@@ -297,8 +297,14 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
  * released with the handle): keeping two or three batches in flight hides the slow tail of each
  * solve behind the bulk of the next.  A call enqueues one kernel or a short chain of kernels (large
  * batches pass their stragglers from a first launch to a second through device memory; islands > 1 add a selection
- * kernel); nothing in it waits for the host, so it may be captured into a hipGraph and replayed: make one eager call on the stream
- * first (it sizes the scratch); a call on a capturing stream always takes a one-launch mapping. */
+ * kernel); nothing in it waits for the host, so it may be captured into a hipGraph and replayed any number of times, on new contents of the
+ * captured arrays too: make one eager call of the same size on the stream first (it sizes the scratch).  The words a solve resets per
+ * call (hand-over counters, the timeout's clock, the islands' first-success words) are written by a kernel of this library, NOT by
+ * hipMemsetAsync: on ROCm 7.2 a graph with a memset node in front of these kernels faults on its second replay.
+ * Lifetime of the scratch under capture: a buffer a captured call has used is PINNED -- the graph holds its address -- and stays alive until
+ * bioik_problem_destroy; the next eager call on that stream moves on to a buffer of its own, whatever its size.  Graphs captured from ONE
+ * stream of one handle share that stream's pinned buffer: launch them on one stream (or capture from different streams).  Destroy the
+ * graphs before the handle. */
 int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds,
                              const double* d_goal_params, double* d_solutions, double* d_fitness,
                              int32_t* d_success, int32_t* d_steps, void* hip_stream);

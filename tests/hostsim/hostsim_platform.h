@@ -116,6 +116,10 @@ BIOIK_DEV void p_atomic_min(unsigned int* word, unsigned int value) {
     }
 }
 BIOIK_DEV unsigned int p_atomic_load(const unsigned int* word) { return __atomic_load_n(word, __ATOMIC_RELAXED); }
+template <class T>
+BIOIK_DEV T p_load_device(const T* p) { return *(const volatile T*)p; }
+template <class T>
+BIOIK_DEV void p_store_device(T* p, T v) { *(volatile T*)p = v; }
 #define P_INF (__builtin_inf())
 
 #define BIOIK_FP_STRICT

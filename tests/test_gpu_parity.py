@@ -525,34 +525,93 @@ def test_stragglers_that_leave_when_the_chip_runs_empty(gpus, oracles, templates
     pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=16, pop=128, steps_list=(8,))
 
 
-def test_hipgraph_capture_of_a_chip_filling_call(gpus, templates):
-    """bioik_solve_batch_device enqueues on the caller's stream without synchronising: a chip-filling call of the latency schedule -- two launches, a
-    stream-ordered workspace, the resident words -- can be captured into a hipGraph and replayed; the replay's results equal the eager call's"""
+def _graph_fixture(h, t, n, seed):
     import torch
-    h, t = gpus["c2"], templates["c2"]
-    n = 4096
-    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=43)
-    p = abi.default_solve_params(population=128, max_steps=64, random_seed=3)
-    ref = h.solve_batch(p, seeds, params)
     dev = torch.device("cuda", 0)
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=seed)
     ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(params).to(dev)
     o = (torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
          torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
-    s = torch.cuda.Stream(dev)
+    return seeds, params, ds, dp, o
+
+
+def test_hipgraph_capture_of_a_chip_filling_call(gpus, templates, monkeypatch):
+    """bioik_solve_batch_device enqueues on the caller's stream without synchronising: a chip-filling call of the latency schedule -- TWO launches (the dense
+    kernel, then the stragglers under k_solve_lean_cl4 when the chip runs empty), the hand-over list in the handle's scratch, the resident words -- is
+    captured into a hipGraph and replayed FOUR times, the third and fourth on new queries written into the captured input arrays; every replay equals the
+    eager solve of the same queries bit for bit.  (Until round 4 the second replay of such a graph went wrong: the runtime's memset NODE in front of the
+    kernels, see bioik_hip.hip: be_fill_async; the words a solve resets are now written by a kernel of the library.)  The same with a hand-over after a
+    fixed step (BIOIK_SOLVE_TWO_PHASE), which hands nearly every unit over."""
+    import torch
+    h, t = gpus["c2"], templates["c2"]
+    n = 4096
+    p = abi.default_solve_params(population=128, max_steps=64, random_seed=3)
+    for two_phase in (None, "1"):
+        if two_phase:
+            monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", two_phase)
+        seeds, params, ds, dp, o = _graph_fixture(h, t, n, 43)
+        seeds2, params2, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=44)
+        ref, ref2 = h.solve_batch(p, seeds, params), h.solve_batch(p, seeds2, params2)
+        s = torch.cuda.Stream(torch.device("cuda", 0))
+
+        def enqueue():
+            h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), s.cuda_stream)
+        with torch.cuda.stream(s):
+            enqueue()  # (warm: the scratch of the first call on this stream is allocated outside the capture)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            enqueue()
+        for i in range(4):
+            want = ref if i < 2 else ref2
+            if i == 2:
+                ds.copy_(torch.from_numpy(seeds2)), dp.copy_(torch.from_numpy(params2))
+            o[0].zero_(), o[2].zero_(), o[3].zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(o[0].cpu().numpy(), want[0]) and np.array_equal(o[2].cpu().numpy(), want[2]) and np.array_equal(o[3].cpu().numpy(), want[3]), (two_phase, i)
+        del g
+        monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE", raising=False)
+
+
+def test_hipgraph_replay_with_islands_timeout_and_eager_solves_between(gpus, templates):
+    """What else a captured solve depends on, replayed: the islands' first-success words (island_sync; a 0xff fill per replay), the launch clock of a
+    timeout (zeroed per replay), k_select behind the solve kernels, and the scratch the graph's addresses point into -- an eager solve on the SAME handle
+    and stream that needs MORE scratch (more queries, more islands) runs between the replays and must not take the graph's buffer away (a buffer a
+    capture has used is pinned until the handle goes; bioik_hip.hip: bioik_problem::Scratch)."""
+    import torch
+    h, t = gpus["c2"], templates["c2"]
+    n = 1536
+    p = abi.default_solve_params(population=128, max_steps=48, random_seed=5, islands=2, island_sync=1, timeout=3600.0)
+    seeds, params, ds, dp, o = _graph_fixture(h, t, n, 47)
+    ref = h.solve_batch(p, seeds, params)
+    big_n = 3000
+    pb = abi.default_solve_params(population=128, max_steps=48, random_seed=6, islands=4, island_sync=1)
+    bseeds, bparams, bds, bdp, bo = _graph_fixture(h, t, big_n, 48)
+    bref = h.solve_batch(pb, bseeds, bparams)
+    s = torch.cuda.Stream(torch.device("cuda", 0))
 
     def enqueue():
         h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), s.cuda_stream)
+
+    def eager_big():
+        with torch.cuda.stream(s):
+            h.solve_batch_device(pb, big_n, bds.data_ptr(), bdp.data_ptr(), bo[0].data_ptr(), bo[1].data_ptr(), bo[2].data_ptr(), bo[3].data_ptr(), s.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(bo[0].cpu().numpy(), bref[0]) and np.array_equal(bo[3].cpu().numpy(), bref[3])
     with torch.cuda.stream(s):
-        enqueue()  # (warm: allocations of the first call stay outside the capture)
+        enqueue()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
         enqueue()
-    for _ in range(2):
-        o[0].zero_(), o[2].zero_()
+    for i in range(4):
+        o[0].zero_(), o[2].zero_(), o[3].zero_()
         g.replay()
         torch.cuda.synchronize()
-        assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3])
+        assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3]), i
+        if i < 3:
+            eager_big()  # (needs more scratch than the graph's solve: grows on a buffer of its own)
 
 
 def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
