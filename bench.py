@@ -224,6 +224,64 @@ def bench_c5(args, rank, world, gpu, dev):
         dist.destroy_process_group()
 
 
+def small_batches(h, template, dev, seeds, params, cpu=True):
+    """Calls that cannot fill the chip (MoveIt's own pattern is ONE pose per call, kinematics_plugin.cpp:437-655): ms per call for n = 1 ... 1024 queries of
+    the headline workload, device arrays in and out, one call at a time, under the plugin's default (islands = BIOIK_ISLANDS_AUTO: as many islands as the idle
+    part of the chip carries, stopping each other) and with one island; beside them the reference's own code on one host thread and on all of them for the
+    same n queries."""
+    import numpy as np
+    import torch
+    from bio_ik_amd import abi
+    sizes, out = (1, 16, 64, 256, 1024), []
+    pa = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, islands=abi.ISLANDS_AUTO)
+    p1 = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1)
+    s = torch.cuda.Stream(dev)
+    r = None
+    if cpu:
+        try:
+            from oracle import ref
+            if ref.release_available():
+                r = ref.Reference(template, abi.default_solve_params(mode="bio2_memetic", random_seed=1), release=True)
+                r.solve_batch(seeds[:4], params[:4], 512)
+        except Exception:
+            r = None
+    for n in sizes:
+        reps = 16 if n <= 256 else 4
+        o = (torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+        sets = [((k * n) % (BATCH - n + 1)) for k in range(reps)]  # windows of the headline batch: different queries per call
+        dsets = [(torch.from_numpy(seeds[a:a + n]).to(dev), torch.from_numpy(params[a:a + n]).to(dev)) for a in sets]
+        e = {"n": n}
+        for key, p in (("gpu_ms", pa), ("gpu_one_island_ms", p1)):
+            def call(ds, dp):
+                h.solve_batch_device(p, n, ds.data_ptr(), dp.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), s.cuda_stream)
+                s.synchronize()
+            call(*dsets[0]), call(*dsets[0])
+            ts, suc, st = [], 0.0, []
+            for ds, dp in dsets:
+                t1 = time.perf_counter()
+                call(ds, dp)
+                ts.append(time.perf_counter() - t1)
+                suc += float(o[2].sum().item())
+                st.append(float(o[3].max().item()))
+            e[key] = 1e3 * float(np.mean(ts))
+            if key == "gpu_ms":
+                e["gpu_solves_per_s"] = suc / float(np.sum(ts))
+                e["gpu_success_rate"] = suc / (reps * n)
+                e["gpu_islands"] = max(1, min(16, 2048 // n))
+                e["gpu_max_steps_of_a_call"] = float(np.mean(st))
+        if r is not None:
+            ts = []
+            for a in sets[:8 if n <= 256 else 2]:
+                t1 = time.perf_counter()
+                r.solve_batch(seeds[a:a + n], params[a:a + n], 512)
+                ts.append(time.perf_counter() - t1)
+            e["reference_1thread_ms"] = 1e3 * float(np.mean(ts))
+        out.append(e)
+    return {"sizes": out, "what": "ms per call, one call at a time, device arrays; gpu_ms: islands = BIOIK_ISLANDS_AUTO (the plugin's default); reference: oracle/_ref on ONE host thread, "
+                                  "its own parameters (pop 16, linearised FK, <= 512 steps), the same queries"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,7 +545,8 @@ def main():
         "max_rot_err_rad_of_successes": rot_err,
         "pose_check": pose_check_by,
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
+                     "frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,  # chip level: the flops of all timed solves over the timed region's wall time
+                     "frac_per_solve": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
                      "kernel": "k_solve_lean_cl64w4" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
                      "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
@@ -497,7 +556,7 @@ def main():
                              "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl64w4 (both "
                              "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY one of k_solve_lean_cl4 (a wavefront per species) or, for a batch beyond what the "
                              "chip holds of its workgroups, k_solve_lean_cl64w4 first and k_solve_lean_cl4 for the stragglers it hands over when the chip runs empty; kernel_ms is the event-bracketed duration of a solve while %d solves "
-                             "share the chip, so `frac` is per solve and `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
+                             "share the chip, so `frac_per_solve` is per solve and `frac` = `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
                              "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
                      "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                              "algorithmic_bytes_per_launch": alg_bytes, "chip_level_achieved": alg_bytes * args.steps / elapsed / 1e9 if elapsed > 0 else 0.0,
@@ -723,7 +782,28 @@ def main():
         if "reference_parameters" in out and cb.get("kind") == "reference" and cb["value"] > 0:
             out["speedup_at_reference_parameters_vs_cpu_1thread"] = out["reference_parameters"]["value"] / cb["value"]
 
+    if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_SMALL", "1") != "0":
+        out["small_batches"] = small_batches(h, template, dev, seeds, params, cpu=not args.no_cpu_baseline)
+
     if rank == 0:
+        # the figures a reader looks for first, in one object at the END of the line (what a truncated tail still shows)
+        c = out.get("configs", {})
+        sb = {str(e["n"]): e for e in out.get("small_batches", {}).get("sizes", [])}
+
+        def r3(x):
+            return None if x is None else float("%.3g" % x)
+        out["summary"] = {
+            "value": r3(out["value"]), "chip_frac": r3(out["roofline"]["chip_level_frac"]),
+            "lat3": r3(out.get("latency_schedule_three_in_flight", {}).get("value")),
+            "one_at_a_time": r3(out.get("one_batch_at_a_time", {}).get("value")),
+            "host_pipelined": r3(out.get("host_pointer_pipelined", {}).get("value")),
+            "ref_params": r3(out.get("reference_parameters", {}).get("value")),
+            "c3": [r3(c.get("c3", {}).get("value")), r3(c.get("c3", {}).get("roofline", {}).get("chip_level_frac"))],
+            "c4": [r3(c.get("c4", {}).get("value")), r3(c.get("c4", {}).get("roofline", {}).get("chip_level_frac"))],
+            "ms_per_call_n1_n16_n256": [r3(sb.get(k, {}).get("gpu_ms")) for k in ("1", "16", "256")],
+            "ref_1thread_ms_n1_n16_n256": [r3(sb.get(k, {}).get("reference_1thread_ms")) for k in ("1", "16", "256")],
+            "cpu_1thread": r3(out.get("cpu_baseline", {}).get("value")), "x_cpu": r3(out.get("speedup_vs_cpu_1thread")),
+        }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -65,6 +65,9 @@ class SolveParams(C.Structure):
                 ("island_sync", C.c_int32), ("reserved0", C.c_int32)]
 
 
+ISLANDS_AUTO = 0  # bioik_solve_params::islands: as many islands as the idle part of the chip carries (include/bioik_hip.h)
+
+
 def default_solve_params(**kw):
     """bioik_default_solve_params + keyword overrides (yaml-key spelling: mode may be a string)."""
     p = SolveParams()

@@ -54,7 +54,9 @@ struct Settings {  // IKParams (src/utils.h:64-85) as far as the device path rea
     int random_seed = 0;
     double dpos = DBL_MAX, drot = DBL_MAX, dtwist = 1e-5;
     bool no_wipeout = false;
-    int gpu_population = 128, gpu_islands = 1, gpu_max_steps = 4096;
+    int gpu_population = 128, gpu_islands = 0, gpu_max_steps = 4096;  // gpu_islands: 0 = BIOIK_ISLANDS_AUTO (bioik_hip.h): the reference's island threads, as many as the
+                                                                    // part of the chip a call leaves idle carries -- MoveIt's one pose per call gets sixteen,
+                                                                    // a batch of 2048 and more one; N > 0: exactly N
     bool gpu_island_sync = true;  // gpu_islands > 1 (and the _2 / _4 / _8 solver names): "any island succeeds => all stop", the reference's island loop
                                   // (ik_parallel.h:102, 160-178) in its deterministic form (bioik_solve_params::island_sync); false: every island to its own end
     std::string gpu_fk = "exact";
@@ -329,7 +331,7 @@ public:
         sp.random_seed = (uint64_t)(uint32_t)settings_.random_seed;
         sp.dpos = settings_.dpos, sp.drot = settings_.drot, sp.dtwist = settings_.dtwist;
         sp.no_wipeout = settings_.no_wipeout ? 1 : 0;
-        sp.island_sync = (settings_.gpu_island_sync && sp.islands > 1) ? 1 : 0;
+        sp.island_sync = (settings_.gpu_island_sync && sp.islands != 1) ? 1 : 0;  // (islands 0 = BIOIK_ISLANDS_AUTO: sized per call, stopping each other)
         const size_t rows = n * K;
         tk->sol.resize(rows * V), tk->fit.resize(rows), tk->suc.resize(rows), tk->steps.resize(rows);
         // problem.timeout = t0 + timeout with t0 taken at entry (:448, :504): what the marshalling above has used is off the budget (one

@@ -206,7 +206,7 @@ struct BioIKKinematicsPlugin : kinematics::KinematicsBase {
         lookupParam("dtwist", p.dtwist, 1e-5);
         lookupParam("no_wipeout", p.no_wipeout, false);
         lookupParam("gpu_population", p.gpu_population, 128);   // children per species and generation (reference: 16, ik_evolution_2.cpp:138)
-        lookupParam("gpu_islands", p.gpu_islands, 1);
+        lookupParam("gpu_islands", p.gpu_islands, 0);  // 0: as many as the idle part of the chip carries (BIOIK_ISLANDS_AUTO)
         lookupParam("gpu_island_sync", p.gpu_island_sync, true);  // islands stop once one of them has a solution, as the reference's solver threads do
         lookupParam("gpu_host_goal_candidates", p.gpu_host_goal_candidates, 4);  // candidates per query that the host scores when the goal list holds callback goals
         lookupParam("gpu_max_steps", p.gpu_max_steps, 4096);    // safety cap; the caller's timeout is what normally ends a query

@@ -557,7 +557,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
 }
 
-DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query) {
+DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query, size_t n_queries) {
     if (p.struct_size != sizeof(bioik_solve_params)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_params: struct_size mismatch");
     DevSolveParams o;
     std::memset(&o, 0, sizeof(o));
@@ -574,6 +574,10 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.fk_mode = p.fk_mode;
     o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
     o.islands = p.islands > 0 ? p.islands : 1;
+    // BIOIK_ISLANDS_AUTO: the islands the idle part of the chip carries (2048 workgroups of the latency schedule's kernel are resident at once), at most
+    // sixteen per query; they stop each other (profiles/r05_small_batches.log)
+    const bool auto_islands = p.islands <= 0 && o.solver == 0 && n_queries > 0;
+    if (auto_islands) o.islands = (int32_t)std::max<size_t>(1, std::min<size_t>(16, 2048 / n_queries));
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
     if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
         const double ticks = p.timeout * 1e8;
@@ -585,7 +589,7 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.schedule = p.schedule;
     o.generations = o.memetic ? 8 : 16;  // ik_evolution_2.cpp:349-351
     if (p.island_sync != 0 && p.island_sync != 1) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "island_sync must be 0 or 1");
-    o.island_sync = (p.island_sync && o.islands > 1) ? 1 : 0;
+    o.island_sync = ((p.island_sync || auto_islands) && o.islands > 1) ? 1 : 0;
     return o;
 }
 

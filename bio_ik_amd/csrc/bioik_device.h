@@ -230,15 +230,6 @@ struct XV {
     BIOIK_DEV double operator()(int k) const { return p[(size_t)k * s]; }
 };
 
-// A child whose op values AND their half-angle sines / cosines were computed beforehand by other lanes of the workgroup (the wide kernel of launches that
-// cannot fill the chip, solve_body<.., FIXED = 5>): three [op][child] arrays in LDS, child index fastest.  The chain walk that reads such an individual
-// does the compositions only; the numbers are those the walk itself would have computed (the same ChildT::operator() and bioik_sincos of the same value).
-struct XPre {
-    const double *x, *sn, *cs;  // LDS, this child's column of the three arrays
-    int s;                      // their stride from op to op (the padded child count)
-    BIOIK_DEV double operator()(int k) const { return x[(size_t)k * s]; }
-};
-
 // ---------------------------------------------------------------------------------------------------------
 // goal costs (goal_types.h); joint-set goals walk the active ops.
 // ---------------------------------------------------------------------------------------------------------
@@ -797,15 +788,6 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
     }
     if constexpr (pb_flavour<PB>::general && std::is_same<XA, XV>::value)
         for (int j = 0; j < N; j++) multi_joint_prologue(pb, x[j], slots + (size_t)j * slot_set_stride);
-    double pre_sn[N], pre_cs[N];  // XPre: the sine / cosine pair of the op the loop is about to reach
-#pragma unroll
-    for (int j = 0; j < N; j++) pre_sn[j] = 0.0, pre_cs[j] = 1.0;
-    if constexpr (std::is_same<XA, XPre>::value) {
-        if (k_begin < n_chain) {
-#pragma unroll
-            for (int j = 0; j < N; j++) pre_sn[j] = x[j].sn[(size_t)k_begin * x[j].s], pre_cs[j] = x[j].cs[(size_t)k_begin * x[j].s];
-        }
-    }
     for (int k = k_begin; k < n_chain; k++) {
         // every scalar of the joint is requested here, in one burst of scalar loads that is waited for once (reading
         // them where they are used costs one exposed scalar-cache round trip per branch of the loop body)
@@ -820,14 +802,6 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
         double xv[N];
 #pragma unroll
         for (int j = 0; j < N; j++) xv[j] = joint_value(x[j], k, msrc, mf, mo);
-        double cur_sn[N], cur_cs[N];
-#pragma unroll
-        for (int j = 0; j < N; j++) cur_sn[j] = pre_sn[j], cur_cs[j] = pre_cs[j];
-        if constexpr (std::is_same<XA, XPre>::value) {  // the next op's pair is asked for HERE, a whole composition ahead of its use
-            const int kn = k + 1 < n_chain ? k + 1 : k;
-#pragma unroll
-            for (int j = 0; j < N; j++) pre_sn[j] = x[j].sn[(size_t)kn * x[j].s], pre_cs[j] = x[j].cs[(size_t)kn * x[j].s];
-        }
         if (ls >= 0) {
             const int tid = p_tid_fresh();
 #pragma unroll
@@ -845,13 +819,8 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
         // and the frame applied inside each branch so that the constants stay scalar operands
         if (type == BIOIK_OP_REVOLUTE) {
             double sn[N], cs[N];
-            if constexpr (std::is_same<XA, XPre>::value) {  // (computed beforehand, by the very call below, and parked in LDS: XPre)
 #pragma unroll
-                for (int j = 0; j < N; j++) sn[j] = cur_sn[j], cs[j] = cur_cs[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
-            }
+            for (int j = 0; j < N; j++) p_sincos(xv[j] * 0.5, &sn[j], &cs[j]);
             revolute_apply<N>(f, sn, cs, RevConst{cp0, cp1, cp2, ca0, ca1, ca2, ca3, cb0, cb1, cb2, cb3, pk, rk});
         } else {
 #pragma unroll

@@ -177,14 +177,6 @@ __global__ void __launch_bounds__(64, 4) k_solve_lean_clj4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, true, true, 4>(a, blockIdx.x, lds);
 }
-// Launches that cannot fill the chip (a single query of the plugin ... a few hundred): 512 lanes per (query, island), two species groups of four wavefronts;
-// the values and the half-angle trigonometry of a generation's (child, op) pairs are spread over all eight wavefronts, one lane per child composes the
-// chain (solve_body<.., FIXED = 5>).  A lone wavefront issues one instruction per ~4.3 cycles whatever it does: what shortens a lone step is fewer
-// instructions per wavefront (profiles/r05_wide_kernel.log)
-__global__ void __launch_bounds__(512, 4) k_solve_lean_wide(SolveArgs a) {
-    extern __shared__ double lds[];
-    solve_body<true, true, false, true, 5>(a, blockIdx.x, lds);
-}
 // the point solvers gd_c / jac (bioik_gradient.h): one wavefront per query
 __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     extern __shared__ double lds[];
@@ -233,7 +225,6 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_lin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -334,7 +325,6 @@ struct SolveSwitches {
     bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
-    int wide = 256;  // BIOIK_SOLVE_WIDE=N: launches of up to N (query, island) units of a problem the wide kernel covers run k_solve_lean_wide (0: never)
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
     bool capture_one_launch = false;  // BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: a call on a stream that is being captured gets a one-launch mapping (round 4's rule)
     int sort_key_drop = 10;     // BIOIK_SOLVE_SORT_KEY_DROP=b (parity suites, 10 ... 52): the pre-selection's sort keys give up b low bits of a fitness, so that the exact path runs often
@@ -369,7 +359,6 @@ static SolveSwitches parse_switches() {
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
     w.capture_one_launch = geti("BIOIK_SOLVE_CAPTURE_ONE_LAUNCH", 0) != 0;
     w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
-    w.wide = geti("BIOIK_SOLVE_WIDE", 256);
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -451,9 +440,9 @@ struct DevBuf {
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3  // register budget of k_solve: wavefronts per SIMD (its __launch_bounds__)
 #endif
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false, bool wide = false) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0, wide ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
@@ -563,10 +552,6 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // 5.74 ms, profiles/r04_small_batches.log)
     if (cl4_eligible && nth == 256) nth = 128;
     const bool prefer_cl4 = cl4_eligible && nth == 128;
-    // ... and the wide kernel for what cannot fill the chip at all (k_solve_lean_wide: 512 lanes per unit, the same problems as k_solve_lean_cl4)
-    constexpr int kWideLanes = 512;
-    const bool wide = prefer_cl4 && sw.wide > 0 && units <= (uint64_t)sw.wide && sp.lambda <= kWideLanes / 2 && !sw.two_phase_init &&
-                      lds_bytes(p, kWideLanes, sp.lambda, 0, 2, 1, true, true, true) <= 160 * 1024;
     if (prefer_cl4) {
         sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
     } else if (!manual && nth == 128) {
@@ -659,9 +644,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
     }
     const int groups = sp.species_parallel ? 2 : 1;
-    if (wide) nth = kWideLanes, sp.child_pairs = 0;
-    const size_t lds = wide ? lds_bytes(p, kWideLanes, sp.lambda, 0, 2, 1, true, true, true)
-                            : lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
+    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
     if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
     if (sw.report) {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
@@ -719,14 +702,11 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const bool joint4 = joint && !sw.three_waves && (160 * 1024 / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
-        const bool wide_launch = wide && lanes == kWideLanes && args.sp.columnless && !args.sp.child_pairs;
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
-                         !lean ? "k_solve" : wide_launch ? "k_solve_lean_wide" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? (joint4 ? "k_solve_lean_clj4" : "k_solve_lean_clj") : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? (joint4 ? "k_solve_lean_clj4" : "k_solve_lean_clj") : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
                          lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
-        if (lean && wide_launch)
-            LAUNCH(k_solve_lean_wide, (solve_body<true, true, false, true, 5>(args, b_, l_)), units, lanes, lds_b, stream, args);
-        else if (lean && lin_launch)
+        if (lean && lin_launch)
             LAUNCH(k_solve_lean_lin, (solve_body<true, true, false, true, 3>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && joint && joint4)
             LAUNCH(k_solve_lean_clj4, (solve_body<true, true, true, true, 4>(args, b_, l_)), units, lanes, lds_b, stream, args);
@@ -959,7 +939,7 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     std::lock_guard<std::mutex> lock(p->mtx);
     DeviceGuard on_device(p->model->device);
-    DevSolveParams sp = bioik::normalize_params(*params, p->first_query);
+    DevSolveParams sp = bioik::normalize_params(*params, p->first_query, n);
     launch_solve(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream);
     API_END
 }
@@ -1013,7 +993,7 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
     be_h2d(dd, hd, in_bytes, st);
-    DevSolveParams sp = bioik::normalize_params(params, first_query);
+    DevSolveParams sp = bioik::normalize_params(params, first_query, n);
     // The results go from the kernels straight into the page-locked arena (it is mapped into the device's address space; 1.5 MB per 4096 queries,
     // written once per query).  A transfer out enqueued behind the solve would sit at the head of a DMA queue until the solve is over -- 12 ms
     // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
@@ -1108,6 +1088,12 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
     if (n && (!seeds || !solutions || !fitness || !success || !steps || (P > 0 && !goal_params))) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     const uint64_t first = problems[0]->first_query;
     const size_t W = (size_t)n_problems;
+    // BIOIK_ISLANDS_AUTO: one island count for the whole batch, sized to the largest shard (what one device gets), so that every shard runs the same solve
+    bioik_solve_params shard_params = *params;
+    if (params->islands <= 0 && n > 0) {
+        const DevSolveParams r = bioik::normalize_params(*params, 0, (n + W - 1) / W);
+        shard_params.islands = r.islands, shard_params.island_sync = r.island_sync;
+    }
     std::vector<int> status(W, BIOIK_OK);
     std::vector<std::string> message(W);
     std::vector<std::thread> workers;
@@ -1116,7 +1102,7 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
         if (a == b) continue;
         workers.emplace_back([&, r, a, b]() {
             try {
-                solve_host(problems[r], *params, first + a, b - a, seeds + a * V, P ? goal_params + a * P : nullptr, solutions + a * V, fitness + a,
+                solve_host(problems[r], shard_params, first + a, b - a, seeds + a * V, P ? goal_params + a * P : nullptr, solutions + a * V, fitness + a,
                            success + a, steps + a);
             } catch (const Error& e) {
                 status[r] = e.code, message[r] = e.what();

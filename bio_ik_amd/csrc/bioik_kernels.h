@@ -26,10 +26,9 @@ struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species g
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
     int xm, xp, dv, fc;  // memetic phase (per group): support points x -+ g, gene displacements [4][m], tip-frame components [4][T*8]
     int fitp;            // fit_park: the children's fitness values of one generation [lambda], on the space of the memetic phase's vectors
-    int pre, pre_stride; // the wide kernel (solve_body<.., FIXED = 5>), per group: op values, half-angle sines and cosines of every child of the generation, [3][m][pre_stride]
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
-                               int groups = 1, int slot_sets = 1, int fit_park = 0, int fc_in_pop = 0, int wide = 0) {
+                               int groups = 1, int slot_sets = 1, int fit_park = 0, int fc_in_pop = 0) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -81,8 +80,6 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
         L.sec = g, g += n_sec;
         L.order = g, g += n_order;
     }
-    L.pre = g, L.pre_stride = 0;
-    if (wide) L.pre_stride = (lambda + 63) / 64 * 64, g += 3 * m * L.pre_stride;  // (children in whole wavefronts: a wavefront of the precompute owns 64 children of one op)
     L.g_first = o;
     L.g_stride = g;
     o += g * (groups > 0 ? groups : 1);
@@ -431,12 +428,10 @@ struct SpeciesState {
 // read and walked in pairs, no secondary goal (k_solve_lean_cl64w4);  2 = 128 lanes, a wavefront per species, exact FK, computed children in pairs,
 // secondary goals allowed (k_solve_lean_cl4);  3 = 64 lanes, the species on the halves of one wavefront, LINEARISED phenotypes, one computed child per
 // lane and trip (k_solve_lean_lin: populations of up to 32 children per species -- the reference's own parameters);  4 = 64 lanes, halves, exact FK,
-// secondary goals, the pre-selected children of both species walked as one list (JOINT; k_solve_lean_clj4);  5 = the WIDE kernel of launches that cannot fill the
-// chip: 256 ... 1024 lanes per query, two species groups of four ... eight wavefronts, the (child, op) values and trigonometry of a generation spread over all
-// of them, one lane per child for the compositions, no secondary goal (k_solve_lean_wide)
+// secondary goals, the pre-selected children of both species walked as one list (JOINT; k_solve_lean_clj4)
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
-    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, JH = FIXED == 4, WIDE = FIXED == 5, HALVES = DENSE || LIN || JH;
+    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, JH = FIXED == 4, HALVES = DENSE || LIN || JH;
     static_assert(FIXED != 4 || JOINT, "FIXED = 4 is the joint walk of both species' children (64 lanes, halves, exact FK, secondary goals: k_solve_lean_clj4)");
     static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
@@ -460,9 +455,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
-    const bool has_sec = (DENSE || WIDE) ? false : (JH ? true : pb->n_secondary > 0);
+    const bool has_sec = DENSE ? false : (JH ? true : pb->n_secondary > 0);
     const bool exact = LIN ? false : (FIXED ? true : sp.fk_mode == FK_EXACT);
-    const bool child_pairs = (LIN || WIDE) ? false : (FIXED ? true : sp.child_pairs != 0);
+    const bool child_pairs = LIN ? false : (FIXED ? true : sp.child_pairs != 0);
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
     constexpr bool columnless = CL;
     // The two species of bio2 only meet in the species management at the end of a step, so with >= 2 wavefronts the
@@ -470,7 +465,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     const int groups = FIXED ? 2 : (sp.species_parallel ? 2 : 1);
     const int G = HALVES ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
     const int g_shift = HALVES ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0, 1, WIDE ? 1 : 0);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0, 1);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -643,7 +638,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 const uint32_t ctr1 = rng_ctr1(gctr, (uint32_t)S.id, RNG_REPRODUCE);
                 int n_eval = lambda;
                 uint64_t inside_mask = 0ull;  // (WAVE2: the ops no child of this generation can take out of AvoidJointLimitsGoal's free zone)
-                if constexpr (DENSE || WAVE2 || JH || WIDE) {
+                if constexpr (DENSE || WAVE2 || JH) {
                     // the two forms of the parents' mixed momentum (ChildT), lane k the column of op k, into the species' other elite buffer
                     double* const pgt = popS + (S.cur ^ 1) * BF;
                     bool inside = false;
@@ -802,64 +797,6 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = !columnless && n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
-                if constexpr (WIDE) {
-                    // The wide kernel (launches that cannot fill the chip: a lone wavefront is bound by its own instruction count, so the generation's work is
-                    // spread over ALL wavefronts of the species group, four or eight of them).  (1) Every wavefront takes items (64 children, one op): the
-                    // child's value of the op -- hash, Gaussian, mutation, clamp: ChildT -- and its half-angle sine and cosine, ~4/5 of a joint's instructions
-                    // and independent of the chain, into three [op][child] arrays in LDS.  (2) One lane per child composes the chain from them (fk_walk_n over
-                    // XPre: the same numbers in the same order as the walk that computes them itself) and scores the tip.
-                    {
-                        BIOIK_LANE_SCOPE;
-                        const double* const pgt = popS + (S.cur ^ 1) * BF;
-                        double* const pre = gbase + L.pre;
-                        const int PS = L.pre_stride, CH = PS >> 6, W = G >> 6;
-                        const int wv = p_uniform(gtid >> 6), lane = gtid & 63;  // (the op of an item is wavefront-uniform: its constants are scalar operands)
-                        const int k_first = pb->n_prefix, items = CH * (pb->n_chain_ops - k_first);
-                        // (four items per trip: a lone wavefront is bound by the latency of ONE dependent chain -- hash, Gaussian, clamp, the sincos polynomials --
-                        // unless it has several to interleave)
-                        for (int it0 = wv; it0 < items; it0 += 4 * W) {
-                            int kk[4], child[4];
-                            double v[4], sn[4], cs[4];
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int it = it0 + j * W < items ? it0 + j * W : it0;  // (a missing item repeats the first and is not stored)
-                                const int kq = it / CH, chunk = it - kq * CH;
-                                kk[j] = k_first + kq, child[j] = chunk * 64 + lane;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const ChildT<PB> cx = make_child_t(pb, key, ctr1, (uint32_t)(child[j] < lambda ? child[j] : 0) + 2u, p0g, pgt, M);  // (a padding lane repeats child 0 into its own column)
-                                v[j] = cx(kk[j]);
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                sn[j] = 0.0, cs[j] = 1.0;
-                                if (pb->ops[kk[j]].type == BIOIK_OP_REVOLUTE) p_sincos(v[j] * 0.5, &sn[j], &cs[j]);
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if (j == 0 || it0 + j * W < items)
-                                    pre[(size_t)kk[j] * PS + child[j]] = v[j], pre[(size_t)(M + kk[j]) * PS + child[j]] = sn[j], pre[(size_t)(2 * M + kk[j]) * PS + child[j]] = cs[j];
-                        }
-                        PHASE_MARK(PH_REPRODUCE);
-                    }
-                    group_sync(G);
-                    {
-                        BIOIK_LANE_SCOPE;
-                        const double* const pre = gbase + L.pre;
-                        const int PS = L.pre_stride;
-                        for (int r = gtid; r < n_eval; r += G) {
-                            const XPre cx[1] = {XPre{pre + r, pre + (size_t)M * PS + r, pre + (size_t)2 * M * PS + r, PS}};
-                            double f[1];
-                            eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
-                            if (pb->n_link_primary < pb->n_primary) f[0] += nonlink_primary(pb, cx[0], qc);
-                            else f[0] += 0.0;
-                            f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
-                            offer(f[0], r + 2);
-                        }
-                        PHASE_MARK(PH_FITNESS);
-                    }
-                } else
                 if (!JOINT && stored && child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
                     for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
@@ -1141,9 +1078,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         const int c = has_sec ? s_order[id - 2] : id - 2;
                         const ChildX<PB> cx = make_child_x(pb, key, ctr1w, (uint32_t)c + 2u, p0g, p0d, p1d);
                         auto derive = [&](int k) {
-                            double gene;
-                            if constexpr (WIDE) gene = (gbase + L.pre)[(size_t)k * L.pre_stride + c];  // (every child's op values of this generation are still in LDS)
-                            else gene = cx(k);
+                            const double gene = cx(k);
                             double mom = 0.0;
                             if ((active_mask >> k) & 1ull) {
                                 const double parent_gradient = p0d[k] * (1.0 - cx.fmix) + p1d[k] * cx.fmix;

@@ -91,7 +91,7 @@ DEFAULT_PARAMS = {
     "rotation_scale": 0.5, "position_only_ik": False, "center_joints_weight": 0.0, "avoid_joint_limits_weight": 0.0,
     "minimal_displacement_weight": 0.0,
     # additive keys of the GPU build
-    "gpu_population": 128, "gpu_fk": "exact", "gpu_islands": 1, "gpu_max_steps": 64, "gpu_devices": None, "gpu_reproducible_calls": False, "gpu_schedule": "auto",
+    "gpu_population": 128, "gpu_fk": "exact", "gpu_islands": 0, "gpu_max_steps": 64, "gpu_devices": None, "gpu_reproducible_calls": False, "gpu_schedule": "auto",
 }
 
 

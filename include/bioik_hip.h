@@ -117,6 +117,14 @@ enum {
  *   that streams batches through the asynchronous entry gets the dense mapping once its pipeline is three deep: 8.4e5 against 8.0e5 solves/s
  *   with three in flight, 0.94e6 with six; an isolated call stays as fast as it can be). */
 enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1, BIOIK_SCHEDULE_AUTO = 2 };
+/* bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): as many islands per query as the part of the chip the call leaves idle can carry,
+ * max(1, min(16, 2048 / n)) for a call of n queries (per device), stopping each other (island_sync is then taken as 1) -- the reference's
+ * four island threads with "any thread succeeds => all stop" (ik_parallel.h:102, 141-178), sized to the hardware.  A call that cannot fill the
+ * chip is bound by its slowest query's number of steps, and islands cut exactly that: MI355X, PoseGoal on a 7-joint arm, pop 128: 16 queries
+ * 3.27 -> 1.67 ms per call, 256 queries 6.2 -> 3.06 ms, one query 1.07 -> 0.89 ms (profiles/r05_small_batches.log); calls of 2048 queries and
+ * more run one island as before.  The answer of a query then depends on the size of the call it came in (the island count is a function of
+ * n); give an explicit count where that matters.  The bio2 family only: for gd / jac an island count names another solver ("gd_8"). */
+enum { BIOIK_ISLANDS_AUTO = 0 };
 
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */
 enum {
@@ -186,7 +194,8 @@ typedef struct bioik_solve_params {
     int32_t islands;         /* independent islands per query (reference concurrency()==4 identical
                                 clones, ik_evolution_2.cpp:649 + utils.h:423); new key "gpu_islands".  Applies to
                                 every mode: for gd / gd_r / gd_c / jac, islands = N > 1 is the reference's "gd_N" ...
-                                (islands 1 ... N - 1 start at random configurations)                       */
+                                (islands 1 ... N - 1 start at random configurations).  0 = BIOIK_ISLANDS_AUTO (above);
+                                bioik_default_solve_params sets 1                                            */
     int32_t max_steps;       /* budget in IKEvolution2::step() calls per island (deterministic; checked after
                                 every step like the success test of ik_parallel.h:173-181)               */
     uint64_t random_seed;    /* yaml "random_seed" (kinematics_plugin.cpp:256)                           */

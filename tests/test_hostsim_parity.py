@@ -11,6 +11,7 @@ import pytest
 import parity_cases as pc
 from bio_ik_amd import PoseGoal, ProblemTemplate, abi
 from bio_ik_amd.solver import HipSolver
+from bio_ik_amd.workload import make_queries
 from conftest import gnarly_goals
 from oracle import orc
 
@@ -459,6 +460,20 @@ def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.all(b[3] <= a[3]) and np.any(b[3] < a[3])
     with pytest.raises(Exception):
         h.solve_batch(abi.default_solve_params(islands=2, island_sync=2), seeds[:1], params[:1])
+
+
+def test_islands_sized_to_the_idle_chip(sims, templates):
+    """bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): max(1, min(16, 2048 / n)) islands per query that stop each other -- the same solve as that count
+    given explicitly with island_sync = 1; the gradient family keeps one island (an island count there names another solver)"""
+    h, t = sims["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=21)
+    a = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=abi.ISLANDS_AUTO, fk_mode=abi.FK_LINEAR), seeds, params)
+    b = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=16, island_sync=1, fk_mode=abi.FK_LINEAR), seeds, params)
+    c = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=1, fk_mode=abi.FK_LINEAR), seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[0], c[0])
+    g0 = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=abi.ISLANDS_AUTO, mode="gd_c"), seeds, params)
+    g1 = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=1, mode="gd_c"), seeds, params)
+    assert all(np.array_equal(x, y) for x, y in zip(g0, g1))
 
 
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):

@@ -185,8 +185,11 @@ def test_python_plugin_on_the_device(pr2):
         got = link_transform(pr2, pr2.link_index("r_wrist_roll_link"), state)
         want = frame_concat(base, poses[k, 0])
         assert np.linalg.norm(got[:3] - want[:3]) < 1e-4 and 2 * np.arccos(min(1.0, abs(got[3:] @ want[3:]))) < 1e-3
+    # (the plugin's default gpu_islands = 0 sizes the islands to the call -- sixteen per query for 128 queries, eight for 256 --, so a call is compared
+    # with a call of its own size)
+    sols128, ok128, _, _ = p.searchPositionIKBatch(poses[:128], seeds[:128])
     a = p.searchPositionIKBatchAsync(poses[:128], seeds[:128])
     b = p.searchPositionIKBatchAsync(poses[:128], seeds[:128])
     ra, rb = p.searchPositionIKBatchWait(a), p.searchPositionIKBatchWait(b)
-    assert np.array_equal(ra[0], sols[:128]) and np.array_equal(rb[0], sols[:128]) and np.array_equal(ra[1], ok[:128])
+    assert np.array_equal(ra[0], sols128) and np.array_equal(rb[0], sols128) and np.array_equal(ra[1], ok128)
     p.close()
