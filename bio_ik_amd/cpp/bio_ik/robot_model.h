@@ -124,6 +124,24 @@ public:
             if (joint_type[l] == BIOIK_JOINT_FLOATING) out[joint_first_variable[l] + 6] = 1.0;  // identity quaternion
         return out;
     }
+    // A joint that mimics a joint that itself mimics another follows the joint at the end of the chain with the composed factor and offset, as MoveIt's
+    // RobotModel::buildMimic leaves every model: x = f1 (f2 y + o2) + o1 -> factor f1 f2, offset o1 + f1 o2 (the loaders call it once the joints exist)
+    void resolveMimicChains() {
+        for (size_t pass = 0; pass <= joint_mimic.size() + 1; pass++) {
+            bool changed = false;
+            for (size_t i = 0; i < joint_mimic.size(); i++) {
+                const int32_t m = joint_mimic[i];
+                if (m >= 0 && joint_mimic[m] >= 0) {
+                    joint_mimic_offset[i] = joint_mimic_offset[i] + joint_mimic_factor[i] * joint_mimic_offset[m];
+                    joint_mimic_factor[i] = joint_mimic_factor[i] * joint_mimic_factor[m];
+                    joint_mimic[i] = joint_mimic[m];
+                    changed = true;
+                }
+            }
+            if (!changed) return;
+        }
+        throw std::runtime_error("mimic joints that follow each other in a circle");
+    }
     bioik_model_desc desc() const {
         bioik_model_desc d{};
         d.struct_size = sizeof(d);

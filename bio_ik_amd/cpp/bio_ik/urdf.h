@@ -334,6 +334,7 @@ inline std::shared_ptr<RobotModel> loadURDF(const std::string& urdf_xml, const s
             m->joint_mimic[i] = m->jointIndex(j.mimic);  // throws for an unknown joint
             m->joint_mimic_factor[i] = j.mimic_factor, m->joint_mimic_offset[i] = j.mimic_offset;
         }
+    m->resolveMimicChains();
     for (const XmlNode* l : root.all("link")) {
         const XmlNode* ine = l->child("inertial");
         if (!ine || !ine->child("mass")) continue;

@@ -105,6 +105,22 @@ HostModel::HostModel(const bioik_model_desc& d) {
             for (int v = 0; v < l.var_count; v++) var_joint[l.first_var + v] = (int)i;
         }
     }
+    // A joint that mimics a joint that itself mimics another: resolved to the joint at the end of the chain with the composed factor and offset, as MoveIt's
+    // RobotModel::buildMimic does before bio_ik ever sees the model (so forward_kinematics.h:230-246 only meets plain mimics):
+    //     x = f1 (f2 y + o2) + o1  ->  factor f1 f2, offset o1 + f1 o2
+    for (size_t pass = 0;; pass++) {
+        bool changed = false;
+        for (Link& l : links)
+            if (l.mimic >= 0 && links[l.mimic].mimic >= 0) {
+                const Link& via = links[l.mimic];
+                l.mimic_offset = l.mimic_offset + l.mimic_factor * via.mimic_offset;
+                l.mimic_factor = l.mimic_factor * via.mimic_factor;
+                l.mimic = via.mimic;
+                changed = true;
+            }
+        if (!changed) break;
+        if (pass > links.size()) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "mimic joints that follow each other in a circle");
+    }
     // RobotInfo (robot_info.h:70-106)
     vars.resize(d.n_variables);
     for (uint32_t v = 0; v < d.n_variables; v++) {
@@ -232,8 +248,6 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     std::vector<DevOp> ops;
     for (int l : schedule) {
         const HostModel::Link& L = m->links[l];
-        if (L.mimic >= 0 && m->links[L.mimic].mimic >= 0)
-            throw Error(BIOIK_ERR_UNSUPPORTED, "chains of mimic joints (a mimic of a mimic) have no device implementation in this version");
         int base_src = L.parent >= 0 ? src_of[L.parent] : -1;
         Frame base_c = L.parent >= 0 ? c_of[L.parent] : identity();
         Frame C = concat(base_c, L.origin);
@@ -557,7 +571,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
 }
 
-DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query, size_t n_queries) {
+DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query, size_t n_queries, size_t resident_units) {
     if (p.struct_size != sizeof(bioik_solve_params)) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "bioik_solve_params: struct_size mismatch");
     DevSolveParams o;
     std::memset(&o, 0, sizeof(o));
@@ -574,10 +588,10 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     o.fk_mode = p.fk_mode;
     o.lambda = p.population > 0 ? p.population : 16;  // reference: 16 children (ik_evolution_2.cpp:138)
     o.islands = p.islands > 0 ? p.islands : 1;
-    // BIOIK_ISLANDS_AUTO: the islands the idle part of the chip carries (2048 workgroups of the latency schedule's kernel are resident at once), at most
+    // BIOIK_ISLANDS_AUTO: the islands the idle part of the chip carries (`resident_units` workgroups of the latency schedule's kernel are resident at once: 2048 on MI355X), at most
     // sixteen per query; they stop each other (profiles/r05_small_batches.log)
     const bool auto_islands = p.islands <= 0 && o.solver == 0 && n_queries > 0;
-    if (auto_islands) o.islands = (int32_t)std::max<size_t>(1, std::min<size_t>(16, 2048 / n_queries));
+    if (auto_islands) o.islands = (int32_t)std::max<size_t>(1, std::min<size_t>(16, resident_units / n_queries));
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
     if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
         const double ticks = p.timeout * 1e8;

@@ -50,6 +50,6 @@ struct HostProblem {
 };
 
 int goal_param_count(int type);
-DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query, size_t n_queries = 0);  // (n_queries: what BIOIK_ISLANDS_AUTO sizes the islands to; 0: one island)
+DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_query, size_t n_queries = 0, size_t resident_units = 2048);  // resident_units: the (query, island) workgroups of the latency schedule's kernel the device holds at once (eight per CU)  // (n_queries: what BIOIK_ISLANDS_AUTO sizes the islands to; 0: one island)
 
 }  // namespace bioik

@@ -1227,7 +1227,10 @@ struct ChildX {
     const double *p0g, *p0d, *p1d;  // LDS, op-indexed: genes of parent 0, momentum of parents 0 and 1
     uint32_t base;                  // (child << 8) * 0x9E3779B1 + stream
     double mutation_rate, fmix, gradient_factor;
-    BIOIK_DEV double operator()(int k) const {
+    // UNIFORM: the op index is the same in every lane of the wavefront (a loop counter of the chain walk): the clip range then comes as scalar operands
+    // (p_clamp_uniform); false where lane k asks for op k (the winners' re-derivation): the same two instructions on vector operands
+    template <bool UNIFORM = true>
+    BIOIK_DEV double value(int k) const {
         BIOIK_FP_STRICT
         const int g = pb->ops[k].gene;
         const double parent_gene = p0g[k];
@@ -1245,10 +1248,11 @@ struct ChildX {
 #if defined(BIOIK_CLAMP_LIBRARY)
         gn = fmin(fmax(gn, cmin), cmax);
 #else
-        gn = p_clamp_uniform(gn, cmin, cmax);
+        gn = UNIFORM ? p_clamp_uniform(gn, cmin, cmax) : p_clamp(gn, cmin, cmax);
 #endif
         return gn;
     }
+    BIOIK_DEV double operator()(int k) const { return value<true>(k); }
 };
 template <class PB>
 BIOIK_DEV ChildX<PB> make_child_x(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d) {

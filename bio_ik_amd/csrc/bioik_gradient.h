@@ -146,11 +146,11 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
     unsigned long long deadline = 0ull;
     if (sp.timeout_ticks != 0ull) {
         if (tid == 0) {
-            const unsigned long long t0 = p_stamp_once(a.launch_clock, p_wall_clock());
+            const unsigned long long t0 = a.launch_clock ? p_stamp_once(a.launch_clock, p_wall_clock()) + sp.timeout_ticks : a.deadline;  // (SolveArgs::deadline)
             s_ex[6] = (double)(t0 >> 32), s_ex[7] = (double)(t0 & 0xffffffffull);
         }
         p_wave_sync();
-        deadline = (((unsigned long long)s_ex[6] << 32) | (unsigned long long)s_ex[7]) + sp.timeout_ticks;
+        deadline = ((unsigned long long)s_ex[6] << 32) | (unsigned long long)s_ex[7];
         p_wave_sync();
     }
     const int my_op = tid < D ? pb->op_of_gene[tid] : -1;

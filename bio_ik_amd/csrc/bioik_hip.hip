@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -48,6 +49,22 @@ static int be_device_count() {
     return n;
 }
 static void be_set_device(int d) { HIP_CHECK(hipSetDevice(d)); }
+// what the launcher sizes its mappings to (MI355X: 256 CUs in 8 XCDs, 160 KiB of LDS per CU)
+struct DeviceInfo {
+    size_t lds_cu = 160 * 1024;
+    int cus = 256, xcds = 8;
+};
+static DeviceInfo be_device_info(int d) {
+    DeviceInfo di;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess) {
+        if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) di.lds_cu = prop.maxSharedMemoryPerMultiProcessor;
+        if (prop.multiProcessorCount > 0) di.cus = prop.multiProcessorCount;
+    }
+    int x = 0;
+    if (hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, d) == hipSuccess && x > 0 && x <= 16) di.xcds = x;
+    return di;
+}
 static int be_get_device() {
     int d = 0;
     (void)hipGetDevice(&d);
@@ -109,6 +126,24 @@ static void be_fill_async(void* p, size_t bytes, int byte_value, stream_t s) {  
     hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned int*)p, n, (unsigned int)(byte_value & 0xff) * 0x01010101u);
     HIP_CHECK(hipGetLastError());
 }
+__global__ void k_read_clock(unsigned long long* out) { *out = wall_clock64(); }
+// the device's constant 100 MHz clock as of "now" (a one-lane kernel on a stream of its own and a wait for it: ~30 us; launch_solve calls it rarely)
+static unsigned long long be_device_clock_now() {
+    static thread_local hipStream_t cs = nullptr;
+    static thread_local int cs_device = -1;
+    static thread_local unsigned long long* word = nullptr;  // (page-locked and mapped: the kernel writes it, the host reads it after the wait)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (cs_device != dev) {
+        HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        HIP_CHECK(hipHostMalloc((void**)&word, 64, hipHostMallocDefault));
+        cs_device = dev;
+    }
+    hipLaunchKernelGGL(k_read_clock, dim3(1), dim3(1), 0, cs, word);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(cs));
+    return *(volatile unsigned long long*)word;
+}
 static void be_zero_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0, s); }
 static void be_fill_ff_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0xff, s); }
 static stream_t be_stream_create() {
@@ -152,7 +187,10 @@ __global__ void __launch_bounds__(128, 4) k_solve_lean_cl4(SolveArgs a) {
 // barriers) under the register budget of four wavefronts per SIMD
 // (solve_body<.., DENSE>: what the launcher guarantees for this kernel -- 64 lanes, the species on the halves of the wavefront, exact FK, children in
 // pairs, no secondary goal -- is known at compile time, and the fitness values of a generation cross its walks in LDS instead of in registers)
-__global__ void __launch_bounds__(64, 4) k_solve_lean_cl64w4(SolveArgs a) {
+#ifndef BIOIK_DENSE_WAVES
+#define BIOIK_DENSE_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, BIOIK_DENSE_WAVES) k_solve_lean_cl64w4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, false, true, 1>(a, blockIdx.x, lds);
 }
@@ -234,7 +272,8 @@ static void be_allow_lds(size_t bytes) {
 struct bioik_model {
     bioik::HostModel host;
     int device;
-    bioik_model(const bioik_model_desc& d, int dev) : host(d), device(dev) {}
+    DeviceInfo dev;  // of `device`: LDS per CU, CUs, XCDs (hipDeviceProp_t)
+    bioik_model(const bioik_model_desc& d, int dv) : host(d), device(dv), dev(be_device_info(dv)) {}
 };
 struct bioik_problem {
     bioik_model* model;
@@ -265,10 +304,16 @@ struct bioik_problem {
     } io[kIoSlots];
     uint64_t next_ticket = 1;  // ticket t runs on slot t % kIoSlots
     uint64_t first_query = 0;
-    // launch clocks of solves with a wall-clock timeout: a ring of words, one per launch in flight, zeroed in stream order
+    // The caller's timeout counts from the call's SUBMISSION (ik_parallel.h:160, 200): the host reads the device's 100 MHz clock next to its own steady
+    // clock (when the handle first needs it, and again when the pair is older than a few seconds: the two clocks drift by parts per million) and hands every
+    // eager solve its deadline in device ticks (SolveArgs::deadline).  A solve captured into a hipGraph cannot know when it will be replayed: it counts from
+    // its first workgroup's start, on a word of its own that a kernel in the graph zeroes -- one of kCaptureClocks per handle, never reused.
+    bool clock_valid = false;
+    std::chrono::steady_clock::time_point clock_host0;
+    unsigned long long clock_dev0 = 0;
     unsigned long long* d_clocks = nullptr;
     unsigned clock_next = 0;
-    static constexpr unsigned kClocks = 64;
+    static constexpr unsigned kCaptureClocks = 64;
     unsigned int* d_resident = nullptr;  // workgroups of the throughput schedule's launches that are running now (SolveArgs::resident), all streams of this handle
     // Scratch of a solve that needs some (per-island results, the state of handed-over units): one persistent buffer per (stream, purpose), grown when a
     // solve asks for more.  Solves on one stream follow each other, so they may share it; solves on other streams have their own.  (Stream-ordered
@@ -390,7 +435,7 @@ static SolveSwitches switches() {
 
 // lanes per (query, island).  The two species run concurrently on two lane groups when the workgroup has >= 2 wavefronts;
 // each group gets one lane per child up to 128 lanes (pop=128 -> 256 lanes: 4 wavefronts on the 4 SIMDs of a CU).
-static int solve_threads(const DevSolveParams& sp, uint64_t units, const SolveSwitches& sw) {
+static int solve_threads(const DevSolveParams& sp, uint64_t units, const SolveSwitches& sw, uint64_t cus) {
     int t;
     if (sw.threads > 0) {
         t = sw.threads;
@@ -403,7 +448,7 @@ static int solve_threads(const DevSolveParams& sp, uint64_t units, const SolveSw
         // a launch that cannot fill the chip anyway (a single query of the plugin, a few hundred queries): one lane per child,
         // two wavefronts per species — a lone step takes 131 instead of 141 us, 1024 queries run 6 % faster; beyond ~768
         // queries the 128-lane mapping wins (profiles/r01_batch_sweep.log, r01_lone_workgroup_phases.log)
-        if (sp.lambda >= 128 && units <= 768) t = 256;
+        if (sp.lambda >= 128 && units <= 3 * cus) t = 256;  // (768 on MI355X)
     }
     if (t < 64) t = 64;
     t = (t + 63) / 64 * 64;
@@ -445,12 +490,39 @@ static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int ch
     return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
 }
 
+// the timeout of a solve on the device clock (bioik_problem: clock_*)
+static void set_deadline(bioik_problem* p, const DevSolveParams& sp, stream_t stream, SolveArgs& a) {
+    a.launch_clock = nullptr, a.deadline = 0ull;
+    if (sp.timeout_ticks == 0) return;
+    if (be_stream_capturing(stream)) {
+        if (p->clock_next >= bioik_problem::kCaptureClocks) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 solves with a timeout captured into hipGraphs on one problem handle");
+        a.launch_clock = p->d_clocks + p->clock_next++;
+        be_zero_async(a.launch_clock, sizeof(unsigned long long), stream);
+        return;
+    }
+    const auto now = std::chrono::steady_clock::now();
+    if (!p->clock_valid || now - p->clock_host0 > std::chrono::seconds(4)) {
+        try {
+            const auto t0 = std::chrono::steady_clock::now();
+            const unsigned long long dev = be_device_clock_now();
+            const auto t1 = std::chrono::steady_clock::now();
+            p->clock_dev0 = dev, p->clock_host0 = t0 + (t1 - t0) / 2, p->clock_valid = true;  // (the kernel ran somewhere between the two readings: +- half the ~30 us between them)
+        } catch (const Error&) {
+            if (!p->clock_valid) throw;  // (a reading that is a few seconds old still serves: the clocks drift by parts per million)
+        }
+    }
+    const double since = std::chrono::duration<double>(std::chrono::steady_clock::now() - p->clock_host0).count();
+    a.deadline = p->clock_dev0 + (unsigned long long)(since * 1e8) + sp.timeout_ticks;
+}
+
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
                          double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream) {
     if (n == 0) return;
     DevSolveParams sp = sp_in;
     const DevProblem& dp = p->host.dev;
     const SolveSwitches sw = switches();  // (the diagnostic switches as last parsed: no environment access on the launch path)
+    const size_t kLds = p->model->dev.lds_cu;  // LDS of a CU (160 KiB on MI355X)
+    const uint64_t kCus = (uint64_t)p->model->dev.cus;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
     const uint64_t units = (uint64_t)n * sp.islands;
     if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
@@ -519,11 +591,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         SolveArgs pa;
         pa.pb = p->pb(), pa.sp = sp, pa.seeds = d_seeds, pa.params = d_params;
         result_arrays(pa);
-        pa.phase_cycles = nullptr, pa.launch_clock = nullptr;
-        if (sp.timeout_ticks != 0) {
-            pa.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
-            be_zero_async(pa.launch_clock, sizeof(unsigned long long), stream);
-        }
+        pa.phase_cycles = nullptr;
+        set_deadline(p, sp, stream, pa);
         LAUNCH(k_solve_point, point_body(pa, b_, l_), units, 64, lds_point, stream, pa);
         select_islands(pa);
         return;
@@ -533,7 +602,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
     // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
     // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
-    int nth = solve_threads(sp, units, sw);
+    int nth = solve_threads(sp, units, sw, kCus);
     const bool exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
     if (sw.threads <= 0 && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
     const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
@@ -547,7 +616,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // children kept in columns on every count (C2: lone step 94 -> 91 us, fixed work at 4096 queries +30 %, three solves in flight +26 %, an isolated
     // call +16 %: profiles/r04_ab_latency_schedule_kernel.log)
     const bool cl4_eligible = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
-                              sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= 160 * 1024;
+                              sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
     // (... also for the launches that cannot fill the chip, where solve_threads asks for a lane per child: one query 0.928 against 0.942 ms, 256 queries 5.49 against
     // 5.74 ms, profiles/r04_small_batches.log)
     if (cl4_eligible && nth == 256) nth = 128;
@@ -573,13 +642,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             // (computed children in pairs: measured +1.5 % with eight children per lane and generation (C4), -4 % with two (C3))
             if (c.pairs && c.columnless && sp.lambda < 4 * G_c) continue;
             const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact, c.columnless && exact);
-            if (bytes > 160 * 1024) continue;
-            int waves = (int)((160 * 1024) / bytes) * (c.nth / 64);
+            if (bytes > kLds) continue;
+            int waves = (int)(kLds / bytes) * (c.nth / 64);
             if (waves > kCuWaves) waves = kCuWaves;
             // full CU: first (richest) candidate wins; LDS-limited: a later (leaner) candidate wins ties
             if (waves > best_waves || (waves == best_waves && waves < kCuWaves)) best = i, best_waves = waves;
         }
-        if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+        if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
         nth = cands[best].nth;
         sp.species_parallel = nth % 128 == 0 ? 1 : 0;
         const int G_b = nth / (sp.species_parallel ? 2 : 1);
@@ -590,7 +659,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // pre-selection itself, selection, the memetic phase) weigh more; with both species of a query on the halves of ONE wavefront those
         // run once for the two.  Measured: C3 (128 children per species) +14 %, C4 (512: sixteen children per lane) -22 % (tools/c34_mapping_probe.sh).
         if (sp.columnless && dp.n_secondary > 0 && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
-            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact) * kCuWaves <= 160 * 1024) {
+            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact) * kCuWaves <= kLds) {
             nth = 64, sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1;
         }
     } else {
@@ -636,7 +705,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // its first replay and wrong (unit 0 continued from a state nobody wrote) or aborting from its second on, whatever the resident words do; eager calls, back
     // to back on one stream or not, are right; unexplained, DESIGN.md section 8 -- so captured calls get a one-launch mapping, which replays correctly)
     const bool capturing = sw.capture_one_launch && be_stream_capturing(stream);
-    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 3072 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
+    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 12 * kCus && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set && !capturing;
     const bool dense = (throughput || latency_drain) && dense_ok;
     if (sw.columnless > 0 && can_columnless) {
@@ -645,7 +714,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     }
     const int groups = sp.species_parallel ? 2 : 1;
     const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
-    if (lds > 160 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+    if (lds > kLds) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
     if (sw.report) {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
                                         groups, sp.child_pairs ? 2 : 1, (sp.columnless && exact) ? 1 : 0, 1);
@@ -663,7 +732,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         std::fprintf(stderr, "[bioik] solve: ops %d genes %d tips %d slots %d | lanes %d species_parallel %d child_cols %d pairs %d columnless %d | LDS %zu B "
                      "(genotype columns %d, parked frames %d, per-group %d x %d) -> %d workgroups = %d wavefronts per CU\n",
                      dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, sp.columnless, lds, (L.slots - L.xcol) * 8,
-                     (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(160 * 1024 / lds), (int)(160 * 1024 / lds) * (nth / 64));
+                     (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(kLds / lds), (int)(kLds / lds) * (nth / 64));
     }
     if (lds > 64 * 1024) be_allow_lds(lds);
     bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
@@ -674,12 +743,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.seeds = d_seeds;
     a.params = d_params;
     a.phase_cycles = nullptr;
-    a.launch_clock = nullptr;
     a.sort_key_drop = sw.sort_key_drop;
-    if (sp.timeout_ticks != 0) {
-        a.launch_clock = p->d_clocks + (p->clock_next++ % bioik_problem::kClocks);
-        be_zero_async(a.launch_clock, sizeof(unsigned long long), stream);
-    }
+    set_deadline(p, sp, stream, a);
 #if defined(BIOIK_PHASE_TIMING)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
     const char* phase_path = sw.phase_dump.empty() ? nullptr : sw.phase_dump.c_str();
@@ -692,14 +757,14 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
         // (k_solve_lean_cl4 is compiled for exactly this mapping -- solve_body<.., FIXED = 2> --: 128 lanes, a wavefront per species, exact FK, children in pairs)
         const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT && dp.serial_chain != 0;
-        const bool four_waves = cl4_mapping && (((160 * 1024 / lds_b) * (size_t)(lanes / 64) >= 16 && (args.sp.lambda >= 8 * group_lanes || prefer_cl4) && !sw.three_waves) ||
+        const bool four_waves = cl4_mapping && (((kLds / lds_b) * (size_t)(lanes / 64) >= 16 && (args.sp.lambda >= 8 * group_lanes || prefer_cl4) && !sw.three_waves) ||
                                                 sw.four_waves);  // (diagnostic: the 128-register build wherever its mapping is the one in use)
         // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
         // (with a wavefront per species -- 128 lanes, C4 -- the same walk gains nothing: a wavefront that waits at a barrier costs no issue slots,
         // profiles/r03_ab_joint_walk.log)
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
                            !sw.no_joint;
-        const bool joint4 = joint && !sw.three_waves && (160 * 1024 / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
+        const bool joint4 = joint && !sw.three_waves && (kLds / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
         if (sw.report)
@@ -750,7 +815,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing) when_draining = true, handovers.push_back(sp.max_steps);
     } else if (latency_drain) {
         when_draining = true, handovers.push_back(sp.max_steps);
-    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 2048 && sp.max_steps >= 24 && !capturing) {
+    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 8 * kCus && sp.max_steps >= 24 && !capturing) {
         // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
         // profiles/r04_ab_latency_schedule_kernel.log)
         handovers.push_back(1);
@@ -796,7 +861,11 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             aj.carry = (double*)ws;
             if (when_draining) {  // (the last launch counts its wavefronts too; it has no list to leave for)
                 aj.resident = p->d_resident;
-                aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (sw.drain_below + 7) / 8;  // (per XCD: eight on this chip)
+                {  // (per XCD -- eight on MI355X --, the threshold itself scaled to the chip's CUs: BIOIK_SOLVE_DRAIN_BELOW names it for 256 of them)
+                    const int xcds = p->model->dev.xcds > 0 ? p->model->dev.xcds : 1;
+                    const long long below = (long long)sw.drain_below * (long long)kCus / 256;
+                    aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (int32_t)((below + xcds - 1) / xcds);
+                }
                 aj.drain_min_steps = sw.drain_min_steps;
             }
             if (j > 0) {
@@ -882,7 +951,7 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     std::unique_ptr<bioik_problem> p(new bioik_problem(model, *desc));
     DeviceGuard on_device(model->device);
     p->d_pb = (DevProblem*)be_alloc(sizeof(DevProblem));
-    p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kClocks * sizeof(unsigned long long));
+    p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kCaptureClocks * sizeof(unsigned long long));
     p->d_resident = (unsigned int*)be_alloc(16 * 128);
     be_zero_async(p->d_resident, 16 * 128, 0);
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
@@ -939,7 +1008,7 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
         throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null array");
     std::lock_guard<std::mutex> lock(p->mtx);
     DeviceGuard on_device(p->model->device);
-    DevSolveParams sp = bioik::normalize_params(*params, p->first_query, n);
+    DevSolveParams sp = bioik::normalize_params(*params, p->first_query, n, 8 * (size_t)p->model->dev.cus);
     launch_solve(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream);
     API_END
 }
@@ -993,7 +1062,7 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
     be_h2d(dd, hd, in_bytes, st);
-    DevSolveParams sp = bioik::normalize_params(params, first_query, n);
+    DevSolveParams sp = bioik::normalize_params(params, first_query, n, 8 * (size_t)p->model->dev.cus);
     // The results go from the kernels straight into the page-locked arena (it is mapped into the device's address space; 1.5 MB per 4096 queries,
     // written once per query).  A transfer out enqueued behind the solve would sit at the head of a DMA queue until the solve is over -- 12 ms
     // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
@@ -1091,7 +1160,7 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
     // BIOIK_ISLANDS_AUTO: one island count for the whole batch, sized to the largest shard (what one device gets), so that every shard runs the same solve
     bioik_solve_params shard_params = *params;
     if (params->islands <= 0 && n > 0) {
-        const DevSolveParams r = bioik::normalize_params(*params, 0, (n + W - 1) / W);
+        const DevSolveParams r = bioik::normalize_params(*params, 0, (n + W - 1) / W, 8 * (size_t)problems[0]->model->dev.cus);
         shard_params.islands = r.islands, shard_params.island_sync = r.island_sync;
     }
     std::vector<int> status(W, BIOIK_OK);

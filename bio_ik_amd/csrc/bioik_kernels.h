@@ -346,7 +346,8 @@ struct SolveArgs {
     int32_t* success;       // [n*islands]
     int32_t* steps;         // [n*islands]
     unsigned long long* phase_cycles;  // [n*islands][8] or null: per-phase shader cycles (builds with -DBIOIK_PHASE_TIMING)
-    unsigned long long* launch_clock;  // one zeroed word per launch (timeout_ticks != 0): the first workgroup's start on the device clock
+    unsigned long long* launch_clock;  // captured calls only: one zeroed word per launch (timeout_ticks != 0), the first workgroup's start on the device clock
+    unsigned long long deadline = 0ull;  // eager calls (timeout_ticks != 0, launch_clock null): the call's deadline on the device clock, counted from its SUBMISSION
     // A solve in two launches (the launcher's choice, bioik_hip.hip): the first runs the steps [0, step_end) of every unit under the lane
     // mapping that fills the chip best and hands the units that are neither solved nor out of time to the second, which runs them to the
     // end under the mapping with the fastest lone step.  What a unit is between two steps: the species' elites, the solution and
@@ -596,7 +597,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double* s_deadline = s_state + 22;  // the deadline on the device clock as two exact halves (the slots are doubles); only lane 0 reads it
     if (sp.timeout_ticks != 0ull) {
         if (tid == 0) {
-            const unsigned long long t1 = p_stamp_once(a.launch_clock, p_wall_clock()) + sp.timeout_ticks;
+            // (ik_parallel.h:160, 200: the reference's timeout is a point in time fixed when the call comes in.  The host turns it into device ticks
+            // -- launch_solve --; a call captured into a hipGraph cannot know when it will be replayed and counts from its first workgroup's start)
+            const unsigned long long t1 = a.launch_clock ? p_stamp_once(a.launch_clock, p_wall_clock()) + sp.timeout_ticks : a.deadline;
             s_deadline[0] = (double)(t1 >> 32), s_deadline[1] = (double)(t1 & 0xffffffffull);
         }
     }
@@ -1078,7 +1081,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         const int c = has_sec ? s_order[id - 2] : id - 2;
                         const ChildX<PB> cx = make_child_x(pb, key, ctr1w, (uint32_t)c + 2u, p0g, p0d, p1d);
                         auto derive = [&](int k) {
-                            const double gene = cx(k);
+                            const double gene = cx.template value<false>(k);  // (lane k its op k: the clip range differs from lane to lane)
                             double mom = 0.0;
                             if ((active_mask >> k) & 1ull) {
                                 const double parent_gradient = p0d[k] * (1.0 - cx.fmix) + p1d[k] * cx.fmix;

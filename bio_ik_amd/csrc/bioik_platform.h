@@ -109,6 +109,13 @@ BIOIK_DEV double p_clamp_uniform(double x, double lo, double hi) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "s"(hi));
     return r;
 }
+// the same two instructions for bounds that differ from lane to lane (vector-register operands): the winners' re-derivation, where lane k clamps op k
+BIOIK_DEV double p_clamp(double x, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "v"(hi));
+    return r;
+}
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock

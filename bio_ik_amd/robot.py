@@ -187,9 +187,25 @@ class RobotModel:
                 out[v] = 1.0
         return out
 
+    def resolve_mimic_chains(self):
+        """A joint that mimics a joint that itself mimics another follows the joint at the END of the chain with the composed factor and offset, as MoveIt's
+        RobotModel::buildMimic leaves every model before bio_ik sees it: x = f1 (f2 y + o2) + o1 -> factor f1 f2, offset o1 + f1 o2."""
+        for _ in range(len(self.joint_mimic) + 1):
+            changed = False
+            for i, m in enumerate(self.joint_mimic):
+                if m >= 0 and self.joint_mimic[m] >= 0:
+                    self.joint_mimic_offset[i] = self.joint_mimic_offset[i] + self.joint_mimic_factor[i] * self.joint_mimic_offset[m]
+                    self.joint_mimic_factor[i] = self.joint_mimic_factor[i] * self.joint_mimic_factor[m]
+                    self.joint_mimic[i] = self.joint_mimic[m]
+                    changed = True
+            if not changed:
+                return
+        raise ValueError("mimic joints that follow each other in a circle")
+
     # ---- flattening ----
     def arrays(self):
         if self._keep is None:
+            self.resolve_mimic_chains()
             k = {}
             k["link_parent"] = np.asarray(self.link_parent, dtype=np.int32)
             k["link_origin"] = np.asarray(self.link_origin, dtype=np.float64).reshape(-1, 7)

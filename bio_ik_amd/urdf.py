@@ -107,6 +107,7 @@ def load_urdf(urdf_xml, srdf_xml=None):
             m.joint_mimic[i] = m.joint_names.index(j["mimic"][0])
             m.joint_mimic_factor[i] = j["mimic"][1]
             m.joint_mimic_offset[i] = j["mimic"][2]
+    m.resolve_mimic_chains()
     for name, (mass, com) in inertial.items():
         i = m.link_names.index(name)
         m.link_mass[i] = mass

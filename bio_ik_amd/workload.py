@@ -82,7 +82,7 @@ def preselected_children(random_seed, first_query, n_queries, max_steps, populat
     generation of every step each of the two species walks a random prefix of its pre-selected children, n = o0 % (lambda - 1) + 1 with
     o0 = philox2x32_10(key(q), 0, (step * 16 + generation) << 4 | species << 3 | RNG_PRESELECT)  (bioik_kernels.h: solve_body, `n_eval`;
     reference: ik_evolution_2.cpp:366-378).  A function of the counters alone, so the host can count what the device did from the steps it reports."""
-    lam = population - 2
+    lam = population  # (bioik_solve_params::population IS lambda, the children per species and generation: bioik_compile.cpp normalize_params, bioik_kernels.h n_eval)
     q = np.arange(n_queries, dtype=np.uint64) + np.uint64(first_query)
     seed = np.uint64(random_seed)
     key, _ = philox2x32_10(seed & np.uint64(0xFFFFFFFF), q & np.uint64(0xFFFFFFFF), (seed >> np.uint64(32)) ^ (q >> np.uint64(32)))  # (island 0: rng_query_key)

@@ -204,15 +204,16 @@ typedef struct bioik_solve_params {
     int32_t schedule;        /* BIOIK_SCHEDULE_*: what the launcher optimises for; new key "gpu_schedule".  The results do not
                                 depend on it (the lane mapping never changes a trajectory).                              */
     double timeout;          /* the caller's `timeout` of searchPositionIK [s] (kinematics_plugin.cpp:504, 574;
-                                ik_parallel.h:160 `ros::WallTime::now() < timeout`): wall-clock budget of ONE
-                                bioik_solve_batch* call, measured on the device from the moment the launch's first
-                                workgroup starts -- NOT from the submitting call: a solve that waits behind other
-                                solves of the caller's pipeline (bioik_solve_batch_submit with several in flight, or
-                                several device-pointer solves on busy streams) starts its clock when it reaches the
-                                chip, so its wall time from submission exceeds `timeout` by the time it queued.  An
-                                isolated call (the plugin's searchPositionIK) has no such wait.  Every query runs at least one step (ik_parallel.h:160
-                                `iteration != 0`), then stops at the first of: success, max_steps, timeout.
-                                <= 0: no wall-clock limit (results are then independent of timing).          */
+                                ik_parallel.h:160, 200 `ros::WallTime::now() < timeout`): wall-clock budget of ONE
+                                bioik_solve_batch* call, counted FROM THE CALL (round 5): the library keeps the device's
+                                100 MHz clock paired with the host's steady clock and hands the kernels the call's deadline in
+                                device ticks, so a solve that waits behind other solves of the caller's pipeline (several
+                                submits in flight, several device-pointer solves on busy streams) is not granted its wait on
+                                top.  Every query runs at least one step (ik_parallel.h:160 `iteration != 0`), then stops at
+                                the first of: success, max_steps, timeout.  A call CAPTURED into a hipGraph cannot know when it
+                                will be replayed: its budget counts from the moment the replay's first workgroup starts (at most
+                                64 captured calls with a timeout per handle).  <= 0: no wall-clock limit (results are then
+                                independent of timing).                                                                    */
     int32_t island_sync;     /* islands > 1: 0 = every island runs to its own success or budget and the best one is returned (ik_parallel.h:220-269
                                 over independent islands); 1 = "any island succeeds => all stop" (the reference's `finished` flag, ik_parallel.h:102,
                                 160-178) in its deterministic form: the islands of a query advance step by step together and all stop at the end of the

@@ -349,6 +349,14 @@ double orc_counter_uniform(uint32_t key, uint32_t c0, uint32_t c1) {
     return counter_uniform_from(o[0], o[1]);
 }
 uint32_t orc_query_key(uint64_t seed, uint64_t query, uint32_t island) { return query_key(seed, query, island); }
+// the children a species' generation walks when secondary goals pre-select them (ik_evolution_2.cpp:366-378), as the solver's own random source draws the
+// count: what tests/test_evaluation_count.py holds the host-side restatement of bench.py against
+uint32_t orc_preselect_children(uint64_t seed, uint64_t query, uint32_t island, uint32_t step, uint32_t generation, uint32_t species_id, uint32_t lambda) {
+    CounterRandom r;
+    r.key = query_key(seed, query, island);
+    r.set_context(step, generation, species_id);
+    return (uint32_t)(r.preselect_count(2, lambda) - 2);
+}
 
 // ---- L3 ----
 // the restated reference random sources, probed in the order reproduce() / step() consume them (cf. oracle/ref_driver.cpp)

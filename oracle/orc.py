@@ -332,6 +332,13 @@ def counter_gauss32(word, kind="strict"):
     return lib(kind).orc_counter_gauss32(C.c_uint32(word))
 
 
+def preselect_children(seed, query, island, step, generation, species_id, population, kind="strict"):
+    """how many pre-selected children a species walks in one generation (secondary goals present), drawn by the solver's own random source"""
+    L = lib(kind)
+    L.orc_preselect_children.restype = C.c_uint32
+    return int(L.orc_preselect_children(C.c_uint64(seed), C.c_uint64(query), C.c_uint32(island), C.c_uint32(step), C.c_uint32(generation), C.c_uint32(species_id), C.c_uint32(population)))
+
+
 def child_word(key, ctr1, child, w, kind="strict"):
     """random word w of child `child` in the stream (key, ctr1): word 0 is the mutation-rate exponent, word 1 + g the Gaussian of gene g"""
     L = lib(kind)

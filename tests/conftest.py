@@ -98,10 +98,12 @@ def mobile_robot(base="floating", reach=1.0):
     return m
 
 
-def mimic_robot():
+def mimic_robot(chain=None):
     """Axis-aligned 6-joint arm (test fixture only) with two mimic joints (MoveIt JointModel::getMimic): the second elbow
     follows the shoulder pitch (a gene), and a finger on the tip's chain follows a finger that is on no goal chain (so the
-    followed joint is not a gene and keeps the seed's value, reference problem.cpp:191-204)."""
+    followed joint is not a gene and keeps the seed's value, reference problem.cpp:191-204).
+    chain = "chain": the first wrist joint follows the second elbow, which follows the shoulder (a mimic of a mimic: resolved to the joint at the end
+    of the chain as MoveIt's RobotModel::buildMimic does); chain = "resolved": the same robot with that resolution written out by hand."""
     from bio_ik_amd import RobotModel
     m = RobotModel("mimic_arm")
     m.add_link("base")
@@ -109,7 +111,8 @@ def mimic_robot():
     m.add_link("l2", "l1", "s2", "revolute", xyz=(0.0, 0.1, 0.0), axis=(0, 1, 0), lower=-1.8, upper=1.8, velocity=2.0)
     m.add_link("l3", "l2", "e1", "revolute", xyz=(0.35, 0.0, 0.0), axis=(0, 1, 0), lower=-2.2, upper=2.2, velocity=2.5)
     m.add_link("l4", "l3", "e2", "revolute", xyz=(0.25, 0.0, 0.0), axis=(0, 1, 0), lower=-3.0, upper=3.0, velocity=2.5, mimic=("s2", -0.5, 0.1))
-    m.add_link("l5", "l4", "w1", "revolute", xyz=(0.2, 0.0, 0.0), axis=(1, 0, 0), lower=-3.0, upper=3.0, velocity=3.0)
+    w1_mimic = {None: None, "chain": ("e2", 0.8, -0.2), "resolved": ("s2", 0.8 * -0.5, -0.2 + 0.8 * 0.1)}[chain]
+    m.add_link("l5", "l4", "w1", "revolute", xyz=(0.2, 0.0, 0.0), axis=(1, 0, 0), lower=-3.0, upper=3.0, velocity=3.0, mimic=w1_mimic)
     m.add_link("l6", "l5", "w2", "revolute", xyz=(0.1, 0.0, 0.0), axis=(0, 1, 0), lower=-2.0, upper=2.0, velocity=3.0)
     # (the children of l6 in the order a MoveIt-loaded model has them: alphabetical by joint name, bio_ik_amd/urdf.py)
     m.add_link("finger_l", "l6", "finger_l_joint", "prismatic", xyz=(0.05, 0.03, 0.0), axis=(0, 1, 0), lower=0.0, upper=0.04, velocity=0.1)

@@ -84,6 +84,9 @@ int main(int argc, char** argv) {
     ros::set_param("gpu_population", 16);
     ros::set_param("gpu_fk", "linear");
     ros::set_param("gpu_max_steps", 80);
+#ifdef TEST_ISLANDS
+    ros::set_param("gpu_islands", TEST_ISLANDS);  // (the host simulator's runs; the GPU's take the default, BIOIK_ISLANDS_AUTO)
+#endif
     // pluginlib: create the class registered by PLUGINLIB_EXPORT_CLASS, keep it as its base class
     std::unique_ptr<kinematics::KinematicsBase> solver(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
     CHECK(solver != nullptr);

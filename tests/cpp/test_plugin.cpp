@@ -34,6 +34,9 @@ int main() {
     BioIKParams params;
     params.gpu_population = 16, params.gpu_fk = "linear", params.gpu_max_steps = 60, params.random_seed = 3;
     params.gpu_reproducible_calls = true;  // (the determinism check below; by default the random streams advance from call to call)
+#ifdef TEST_ISLANDS
+    params.gpu_islands = TEST_ISLANDS;  // (the host simulator's runs: the default -- sixteen islands for a single pose, BIOIK_ISLANDS_AUTO -- takes the fibres a minute)
+#endif
     CHECK(plugin.initialize(rm, "right_arm", "torso_lift_link", {"r_wrist_roll_link"}, 0.0, params));
     CHECK(plugin.getJointNames().size() == 7 && plugin.getJointNames()[0] == "r_shoulder_pan_joint");
     CHECK(plugin.getLinkNames().size() == 1 && plugin.supportsGroup(nullptr));
@@ -116,6 +119,9 @@ int main() {
         BioIKKinematicsPlugin hybrid;
         BioIKParams hp = params;
         hp.gpu_max_steps = 60, hp.gpu_host_goal_candidates = 4, hp.gpu_reproducible_calls = true;
+#ifdef TEST_ISLANDS
+        hp.gpu_islands = TEST_ISLANDS;
+#endif
         CHECK(hybrid.initialize(rm, "right_arm", "torso_lift_link", {"r_wrist_roll_link"}, 0.0, hp));
         // the candidates themselves: with reproducible calls, candidate j of query 0 draws from stream j -- as query j of a plain batch of four copies does
         std::vector<std::vector<geometry_msgs::Pose>> p4(4, poses[0]);

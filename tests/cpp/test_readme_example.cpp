@@ -71,6 +71,9 @@ int main() {
     ros::set_param("random_seed", 1);
     ros::set_param("gpu_population", 32);
     ros::set_param("gpu_max_steps", EXAMPLE_MAX_STEPS);
+#ifdef TEST_ISLANDS
+    ros::set_param("gpu_islands", TEST_ISLANDS);
+#endif
     moveit::core::RobotModelPtr robot_model = pr2WithGrippersAndHead();
     std::shared_ptr<kinematics::KinematicsBase> solver(static_cast<kinematics::KinematicsBase*>(pluginlib_standin_create("bio_ik_kinematics_plugin::BioIKKinematicsPlugin")));
     if (!solver || !solver->initialize(*robot_model, "all", "base_footprint", std::vector<std::string>{"r_wrist_roll_link", "l_wrist_roll_link"}, 0.0)) return 2;

@@ -12,10 +12,16 @@ thread_local int tid = 0;
 unsigned long long sim_wall_clock() {
     return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }
+static unsigned long long be_device_clock_now() { return sim_wall_clock(); }
 static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, bytes); }
 static void be_fill_ff_async(void* p, size_t bytes, void*) { std::memset(p, 0xff, bytes); }
 typedef void* stream_t;
 static int be_device_count() { return 1; }
+struct DeviceInfo {  // (the simulator stands for an MI355X)
+    size_t lds_cu = 160 * 1024;
+    int cus = 256, xcds = 8;
+};
+static DeviceInfo be_device_info(int) { return DeviceInfo{}; }
 static void be_set_device(int) {}
 static int be_get_device() { return 0; }
 static void* be_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }

@@ -85,6 +85,7 @@ BIOIK_DEV int p_fresh(int v) { return v; }
 BIOIK_DEV double p_fresh(double v) { return v; }
 BIOIK_DEV int p_lane_fresh() { return sim::tid & 63; }
 BIOIK_DEV double p_clamp_uniform(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
+BIOIK_DEV double p_clamp(double x, double lo, double hi) { return __builtin_fmin(__builtin_fmax(x, lo), hi); }
 BIOIK_DEV int p_tid_fresh() { return sim::tid; }
 BIOIK_DEV int p_wave_index() { return sim::tid >> 6; }
 BIOIK_DEV unsigned long long p_ballot(bool pred, int site = __builtin_LINE()) {  // every lane of the wavefront calls it (two rendezvous, as p_shfl)

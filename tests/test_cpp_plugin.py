@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def build_and_run(libdir, libname, tmp_path, timeout_s=None, source="test_plugin"):
     exe = str(tmp_path / source)
-    cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s] if timeout_s else []) + ["-I", os.path.join(ROOT, "bio_ik_amd", "cpp"), "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", source + ".cpp"),
+    cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s, "-DTEST_ISLANDS=2"] if timeout_s else []) + ["-I", os.path.join(ROOT, "bio_ik_amd", "cpp"), "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", source + ".cpp"),
            "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread", "-o", exe]
     subprocess.run(cmd, check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
@@ -43,7 +43,7 @@ def build_and_run_plugin_tu(libdir, libname, tmp_path, timeout_s=None):
     lib = str(tmp_path / "libbio_ik.so")
     subprocess.run(["make", "-s", "-C", cpp, "SOLVER_DIR=" + libdir, "SOLVER=" + libname, "OUT=" + lib], check=True)
     exe = str(tmp_path / "test_kinematics_base")
-    cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s] if timeout_s else []) + [
+    cmd = ["g++", "-std=c++17", "-O1"] + (["-DTEST_TIMEOUT=%g" % timeout_s, "-DTEST_ISLANDS=2"] if timeout_s else []) + [
         "-I", cpp, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(cpp, "standin"), os.path.join(ROOT, "tests", "cpp", "test_kinematics_base.cpp"),
         "-L", str(tmp_path), "-lbio_ik", "-Wl,-rpath," + str(tmp_path), "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread", "-o", exe]
     subprocess.run(cmd, check=True)

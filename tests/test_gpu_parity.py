@@ -49,6 +49,25 @@ def test_function_level_gnarly(gnarly):
     pc.function_level(HipSolver(t2), orc.Oracle(t2), gnarly, np.random.default_rng(3), n=2000)
 
 
+def test_mimic_of_a_mimic():
+    """a joint that follows a joint that itself follows a gene: resolved to the joint at the end of the chain as MoveIt's RobotModel::buildMimic does; the
+    oracle's trajectories, and the same bits as the robot with the resolution written out by hand"""
+    from bio_ik_amd import PoseGoal
+    from bio_ik_amd.solver import HipSolver
+    from conftest import mimic_robot
+    sols = []
+    for chain in ("chain", "resolved"):
+        m = mimic_robot(chain)
+        t = ProblemTemplate(m, "arm", [PoseGoal("tool")])
+        h, o = HipSolver(t, device=0), orc.Oracle(t)
+        assert h.D == o.D == 4
+        pc.function_level(h, o, m, np.random.default_rng(6), n=40, exact_bits=True)
+        pc.trajectory(h, o, t, n=4, pop=128, steps_list=(3,))
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 64, seed=8)
+        sols.append(h.solve_batch(abi.default_solve_params(population=128, max_steps=24, random_seed=2), seeds, params))
+    assert all(np.array_equal(x, y) for x, y in zip(*sols))
+
+
 def test_mimic_joints():
     """a joint that follows a gene and a joint that follows a joint outside every goal chain (MoveIt mimic joints,
     forward_kinematics.h:230-246, 623-636): function level, and whole solves bit for bit"""
@@ -738,6 +757,30 @@ def test_wall_clock_timeout(gpus, templates):
     p1 = abi.default_solve_params(population=128, max_steps=24, random_seed=4, timeout=3600.0)
     a, b = h.solve_batch(p0, seeds, params), h.solve_batch(p1, seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # the timeout counts from the call's SUBMISSION (ik_parallel.h:160, 200), not from the moment its launch reaches the chip: three chip-filling solves
+    # queued on one stream at (nearly) the same time -- each is past its deadline when the one before it ends, runs its one obligatory step and leaves
+    import torch
+    dev = torch.device("cuda", 0)
+    ds, dp = torch.from_numpy(seeds).to(dev), torch.from_numpy(far).to(dev)
+    outs = [(torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)) for _ in range(3)]
+    s = torch.cuda.Stream(dev)
+    pt = abi.default_solve_params(population=128, max_steps=1000000, random_seed=1, timeout=0.02)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    h.solve_batch_device(abi.default_solve_params(population=128, max_steps=2, random_seed=1), n, ds.data_ptr(), dp.data_ptr(), *[x.data_ptr() for x in outs[0]], s.cuda_stream)
+    s.synchronize()
+    with torch.cuda.stream(s):
+        ev[0].record(s)
+        for k in range(3):
+            h.solve_batch_device(pt, n, ds.data_ptr(), dp.data_ptr(), *[x.data_ptr() for x in outs[k]], s.cuda_stream)
+            ev[k + 1].record(s)
+    s.synchronize()
+    ends = [ev[0].elapsed_time(ev[k + 1]) for k in range(3)]  # ms from the first submission to the end of solve k
+    assert 15.0 < ends[0] < 40.0, ends
+    assert ends[2] < ends[0] + 15.0, ends          # (60 ms and more if every solve's clock started with its launch)
+    for k in range(3):
+        assert outs[k][3].min().item() >= 1 and not outs[k][2].any().item()
+    assert outs[2][3].max().item() <= 4            # the third solve: the obligatory step (and what fits before the verdict crosses the workgroup)
 
 
 def test_error_conventions(pr2):

@@ -191,6 +191,25 @@ def test_mimic_joints(hostsim_lib):
     pc.trajectory(h2, o2, t2, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
 
 
+def test_mimic_of_a_mimic(hostsim_lib):
+    """a joint that follows a joint that itself follows a gene (the reference never meets one: MoveIt's RobotModel::buildMimic resolves such chains before
+    bio_ik sees the model; this library does the same wherever a model is built or handed in): the oracle's trajectories, and the same bits as the robot
+    with the resolution written out by hand"""
+    from bio_ik_amd import PoseGoal
+    from conftest import mimic_robot
+    sols = []
+    for chain in ("chain", "resolved"):
+        m = mimic_robot(chain)
+        t = ProblemTemplate(m, "arm", [PoseGoal("tool")])
+        h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+        assert h.D == o.D == 4  # s1 s2 e1 w2
+        pc.function_level(h, o, m, np.random.default_rng(6), n=40, exact_bits=True)
+        pc.trajectory(h, o, t, n=2, pop=16, steps_list=(3,))
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=8)
+        sols.append(h.solve_batch(abi.default_solve_params(population=32, max_steps=4, random_seed=2), seeds, params))
+    assert all(np.array_equal(x, y) for x, y in zip(*sols))
+
+
 def test_no_active_variable(hostsim_lib, pr2):
     """every joint of the group fixed (BioIKKinematicsQueryOptions::fixed_joints, problem.cpp:104-114): D = 0, the solve runs its
     budget and returns the seed, as the oracle does"""

@@ -32,7 +32,7 @@ def extract_example(path):
     return code
 
 
-def build_and_run(libdir, libname, tmp_path, max_steps):
+def build_and_run(libdir, libname, tmp_path, max_steps, islands=None):
     cpp = os.path.join(ROOT, "bio_ik_amd", "cpp")
     lib = str(tmp_path / "libbio_ik.so")
     subprocess.run(["make", "-s", "-C", cpp, "SOLVER_DIR=" + libdir, "SOLVER=" + libname, "OUT=" + lib], check=True)
@@ -40,7 +40,7 @@ def build_and_run(libdir, libname, tmp_path, max_steps):
     code = extract_example(snippet)
     assert "tf::Vector3" in code and "ik_options.goals.emplace_back" in code and "LookAtGoal" in code
     exe = str(tmp_path / "test_readme_example")
-    cmd = ["g++", "-std=c++17", "-O1", "-DEXAMPLE_FILE=\"%s\"" % snippet, "-DEXAMPLE_MAX_STEPS=%d" % max_steps,
+    cmd = ["g++", "-std=c++17", "-O1", "-DEXAMPLE_FILE=\"%s\"" % snippet, "-DEXAMPLE_MAX_STEPS=%d" % max_steps] + (["-DTEST_ISLANDS=%d" % islands] if islands else []) + [
            "-I", cpp, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(cpp, "standin"), os.path.join(ROOT, "tests", "cpp", "test_readme_example.cpp"),
            "-L", str(tmp_path), "-lbio_ik", "-Wl,-rpath," + str(tmp_path), "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread", "-o", exe]
     subprocess.run(cmd, check=True)
@@ -50,4 +50,4 @@ def build_and_run(libdir, libname, tmp_path, max_steps):
 
 @pytest.mark.skipif(not os.path.exists(README), reason="the reference tree is not on this machine")
 def test_readme_valve_example_compiles_unchanged_and_runs(hostsim_lib, tmp_path):
-    build_and_run(os.path.join(ROOT, "tests", "hostsim"), "bioik_hostsim", tmp_path, max_steps=12)
+    build_and_run(os.path.join(ROOT, "tests", "hostsim"), "bioik_hostsim", tmp_path, max_steps=12, islands=2)
