@@ -267,18 +267,16 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         op.src = base_src;
         op.load_slot = op.save_slot = -1;
         op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
-        op.val_first = op.joint_op = -1;
+        op.val_first = op.joint_op = -1, op.multi_slot = -1;
         bool multi = op.type >= BIOIK_OP_FLOATING;
+        op.multi_slot = -1;
         if (multi) {
-            // The joint's variables are value ops of their own (below).  Its frame is applied in front of the chain walk by
-            // one out-of-line call and parked in an LDS slot; inside the walk the op only fetches that slot (zero constants).
-            if (base_src >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "a floating / planar joint behind a moving joint has no device implementation in this version");
-            if (dev.multi_op >= 0) throw Error(BIOIK_ERR_UNSUPPORTED, "more than one floating / planar joint on the goal chains");
+            // A floating / planar joint, anywhere on the chains and any number of them (forward_kinematics.h:120-135, 331-354 take them wherever they are).  Its
+            // variables are value ops of their own (below).  Its joint frame J(values) does not depend on the frames in front of it: an out-of-line call
+            // computes it in front of a chain walk and parks it in an LDS slot; inside the walk the op applies its constant frame like any other
+            // (F_src o C, cb = 0) and then the parked joint frame: (F_src o C) o J, the association of the reference's three-frame concat.
             op.gene = -1;
-            dev.multi_op = (int)ops.size();
-            for (int c = 0; c < 3; c++) dev.multi_c[c] = C.p[c];
-            for (int c = 0; c < 4; c++) dev.multi_c[3 + c] = C.q[c];
-            C = identity();
+            if (dev.multi_op < 0) dev.multi_op = (int)ops.size();
         }
         if (L.mimic >= 0) {  // resolved to an op index below, once every op exists
             op.gene = -1;
@@ -345,7 +343,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             op.gene = gene_of_var[op.var];
             op.src = op.load_slot = op.save_slot = -1;
             op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
-            op.val_first = -1, op.joint_op = k;
+            op.val_first = -1, op.joint_op = k, op.multi_slot = -1;
             var_has_op[op.var] = 1;
             ops.push_back(op);
         }
@@ -370,7 +368,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         op.gene = i;
         op.src = op.load_slot = op.save_slot = -1;
         op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
-        op.val_first = op.joint_op = -1;
+        op.val_first = op.joint_op = -1, op.multi_slot = -1;
         var_has_op[v] = 1;
         ops.push_back(op);
     }
@@ -392,7 +390,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             op.gene = gene_of_var[sv];
             op.src = op.load_slot = op.save_slot = -1;
             op.mimic_src = -1, op.mimic_factor = 1.0, op.mimic_offset = 0.0;
-            op.val_first = op.joint_op = -1;
+            op.val_first = op.joint_op = -1, op.multi_slot = -1;
             if (op.gene >= 0) {
                 const HostModel::Var& vi = m->vars[sv];
                 op.clip_min = vi.clip_min, op.clip_max = vi.clip_max, op.span = vi.span, op.vmin = vi.vmin, op.vmax = vi.vmax;
@@ -418,7 +416,8 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     }
     // branch frames: an op whose parent frame is not the running frame fetches it from an LDS slot
     int n_slots = 0;
-    if (dev.multi_op >= 0) ops[dev.multi_op].load_slot = n_slots++;
+    for (int k = 0; k < n_chain; k++)
+        if (ops[k].type >= BIOIK_OP_FLOATING) ops[k].multi_slot = n_slots++;
     for (int k = 0; k < n_chain; k++) {
         int s = ops[k].src;
         if (s >= 0 && s != k - 1) {

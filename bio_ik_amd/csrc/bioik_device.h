@@ -596,20 +596,28 @@ BIOIK_DEV F7 multi_joint_frame(int type, const F7& v) {
     p_sincos(v.p.z * 0.5, &sn, &cs);  // planar: Translation(x, y, 0) * AngleAxis(theta, Z)
     return F7{{v.p.x, v.p.y, 0.0}, {0.0, 0.0, sn, cs}};
 }
-// constant o joint frame
-BIOIK_CALL F7 multi_joint_apply(int type, F7 c, F7 values) { return f7_concat(c, multi_joint_frame(type, values)); }
-// In front of a chain walk: the frame behind the root-level floating / planar joint of individual x goes to this lane's slot
-// (the op itself then only fetches it: load_slot, zero constants -- nothing of this is inside the joint loop).
+// the joint frame J(values) of a floating / planar joint (one out-of-line copy: a square root and a division, or a sincos)
+BIOIK_CALL F7 multi_joint_local(int type, F7 values) { return multi_joint_frame(type, values); }
+// In front of a chain walk: the joint frames of the floating / planar joints of individual x go to this lane's slots (ops[k].multi_slot); the op
+// itself then applies its constant frame and fetches the joint frame -- nothing of the joint-frame arithmetic is inside the joint loop.
 BIOIK_DEV void multi_joint_prologue(ProbPtr pb, const XV& x, double* slots_of_child) {
     const int mo = pb->multi_op;
     if (mo < 0) return;
     const int tid = p_tid(), nth = p_nthreads();
-    const int type = pb->ops[mo].type;
-    const F7 c = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
-    const F7 f = multi_joint_apply(type, c, multi_joint_values(type, x, pb->ops[mo].val_first));
-    double* sl = slots_of_child + (size_t)pb->ops[mo].load_slot * 7 * nth + tid;
-    sl[0] = f.p.x, sl[(size_t)nth] = f.p.y, sl[(size_t)2 * nth] = f.p.z;
-    sl[(size_t)3 * nth] = f.q.x, sl[(size_t)4 * nth] = f.q.y, sl[(size_t)5 * nth] = f.q.z, sl[(size_t)6 * nth] = f.q.w;
+    const int n_chain = pb->n_chain_ops;
+    for (int k = mo; k < n_chain; k++) {
+        const int type = pb->ops[k].type;
+        if (type < BIOIK_OP_FLOATING) continue;
+        const F7 f = multi_joint_local(type, multi_joint_values(type, x, pb->ops[k].val_first));
+        double* sl = slots_of_child + (size_t)pb->ops[k].multi_slot * 7 * nth + tid;
+        sl[0] = f.p.x, sl[(size_t)nth] = f.p.y, sl[(size_t)2 * nth] = f.p.z;
+        sl[(size_t)3 * nth] = f.q.x, sl[(size_t)4 * nth] = f.q.y, sl[(size_t)5 * nth] = f.q.z, sl[(size_t)6 * nth] = f.q.w;
+    }
+}
+// ... and inside the walk: F = (F_src o C) o J with J from the slot (the caller has applied C)
+BIOIK_DEV F7 multi_joint_fetch(const F7& f, const double* slots_of_child, int multi_slot, int nth, int tid) {
+    const double* s = slots_of_child + (size_t)multi_slot * 7 * nth + tid;
+    return f7_concat(f, F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}});
 }
 
 // value of the joint of op k in the individual x: its own entry, or for a mimic joint factor * (entry of the joint it
@@ -691,6 +699,8 @@ BIOIK_DEV void fk_walk(PB pb, const XA& x, double* slots, double* frames_out, Ti
             const V3 lp = v3(BK_FMA(xv, cb0, cp0), BK_FMA(xv, cb1, cp1), BK_FMA(xv, cb2, cp2));
             f.p = f.p + qrot(f.q, lp);
             f.q = qmul(f.q, Q4{ca0, ca1, ca2, ca3});
+            if constexpr (pb_flavour<PB>::general)
+                if (type >= BIOIK_OP_FLOATING) f = multi_joint_fetch(f, slots, pb->ops[k].multi_slot, nth, p_tid_fresh());
         }
         if (ss >= 0) {
             double* sl = slots + (size_t)ss * 7 * nth + p_tid_fresh();
@@ -829,6 +839,12 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
                 f[j].p = f[j].p + qrot(f[j].q, lp);
                 f[j].q = qmul(f[j].q, Q4{ca0, ca1, ca2, ca3});
             }
+            if constexpr (pb_flavour<PB>::general)
+                if (type >= BIOIK_OP_FLOATING) {
+                    const int tid = p_tid_fresh();
+#pragma unroll
+                    for (int j = 0; j < N; j++) f[j] = multi_joint_fetch(f[j], slots + (size_t)j * slot_set_stride, pb->ops[k].multi_slot, nth, tid);
+                }
         }
         if (ss >= 0) {
             const int tid = p_tid_fresh();
@@ -1007,6 +1023,15 @@ BIOIK_CALL Twist6 jacobian_numeric(int type, F7 parent_c, F7 values_2, F7 link_f
     t.v[3] = ang.x * inv_step_size, t.v[4] = ang.y * inv_step_size, t.v[5] = ang.z * inv_step_size;
     return t;
 }
+// (frame of the op in front of chain op jop) o (its constant frame): what a floating / planar joint's frame is applied to -- the arithmetic of the walk
+// (frames: the published per-joint chain; prefix: the frame behind the leading non-gene joints, whose own frames are not published)
+template <class PB>
+BIOIK_DEV F7 multi_joint_parent_c(PB pb, int jop, const double* frames, const double* prefix) {
+    const int src = pb->ops[jop].src;
+    F7 f = f7_identity();
+    if (src >= 0) f = (prefix != nullptr && src < pb->n_prefix) ? f7_load(prefix) : f7_load(frames + src * 7);
+    return f7_concat(f, F7{{pb->ops[jop].cpos[0], pb->ops[jop].cpos[1], pb->ops[jop].cpos[2]}, {pb->ops[jop].ca[0], pb->ops[jop].ca[1], pb->ops[jop].ca[2], pb->ops[jop].ca[3]}});
+}
 //   base   LDS, [n_ops]: the op values of the configuration the frames were published for
 //   prefix LDS or null: see fk_walk (the frames of ops[0..n_prefix) are then not published; their last one is *prefix)
 template <class PB>
@@ -1022,8 +1047,8 @@ BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, con
             for (int c = 0; c < 7; c++) out7[c] = 0.0;
             return;
         }
-        const int type = pb->ops[jop].type, vf = pb->ops[jop].val_first;  // root-level joint: the parent frame is the model root
-        const F7 cf = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
+        const int type = pb->ops[jop].type, vf = pb->ops[jop].val_first;
+        const F7 cf = multi_joint_parent_c(pb, jop, frames, prefix);
         const F7 tf = f7_load(tips + t * 7);
         F7 values_2 = multi_joint_values(type, XV{base, 1}, vf);
         multi_joint_bump(values_2, k - vf, 0.00001);
@@ -1067,7 +1092,7 @@ BIOIK_DEV void approximator_entry(PB pb, int t, int k, const double* frames, con
 // angular velocity, the six numbers the `jac` solver stacks into its least-squares system (ik_gradient.cpp:97-113).  Same frames, same
 // arithmetic as approximator_entry up to the point where that one turns the column into a world-frame delta.
 template <class PB>
-BIOIK_DEV void jacobian_entry6(PB pb, int t, int k, const double* frames, const double* tips, double* out6, const double* base) {
+BIOIK_DEV void jacobian_entry6(PB pb, int t, int k, const double* frames, const double* tips, double* out6, const double* base, const double* prefix = nullptr) {
     BIOIK_FP_STRICT
     const uint64_t dep_mask = pb->tips[t].dep_mask;
     const int n_chain = pb->n_chain_ops;
@@ -1077,7 +1102,7 @@ BIOIK_DEV void jacobian_entry6(PB pb, int t, int k, const double* frames, const 
     if (jop >= 0) {
         if (!gene || ((dep_mask >> jop) & 1ull) == 0) return;
         const int type = pb->ops[jop].type, vf = pb->ops[jop].val_first;
-        const F7 cf = F7{{pb->multi_c[0], pb->multi_c[1], pb->multi_c[2]}, {pb->multi_c[3], pb->multi_c[4], pb->multi_c[5], pb->multi_c[6]}};
+        const F7 cf = multi_joint_parent_c(pb, jop, frames, prefix);
         F7 values_2 = multi_joint_values(type, XV{base, 1}, vf);
         multi_joint_bump(values_2, k - vf, 0.00001);
         const Twist6 tw = jacobian_numeric(type, cf, values_2, f7_load(frames + jop * 7), f7_load(tips + t * 7));

@@ -259,7 +259,7 @@ BIOIK_DEV void point_body(const SolveArgs& a, uint64_t unit, double* lds) {
             for (int idx = tid; idx < T * D; idx += nth) {  // Jacobian columns (:97), [6 * public tip + c][gene]
                 const int t = idx / D, gidx = idx - t * D;
                 double o6[6];
-                jacobian_entry6(pb, t, pb->op_of_gene[gidx], s_frames, s_tips, o6, s_sol);
+                jacobian_entry6(pb, t, pb->op_of_gene[gidx], s_frames, s_tips, o6, s_sol, s_prefix);
                 for (int c = 0; c < 6; c++) s_jac[(pb->tips[t].out_index * 6 + c) * D + gidx] = o6[c];
             }
             p_wave_sync();

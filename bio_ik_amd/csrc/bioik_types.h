@@ -48,6 +48,7 @@ struct DevOp {
     int32_t mimic_src;               // op whose value this joint mimics, -1: the joint has its own value x(k)
     int32_t val_first;               // FLOATING / PLANAR chain op: first of its 7 / 3 consecutive value ops (type NONE), else -1
     int32_t joint_op;                // value op of a FLOATING / PLANAR joint: the chain op it belongs to, else -1
+    int32_t multi_slot;              // FLOATING / PLANAR chain op: the LDS slot its joint frame J(values) is parked in before a walk (multi_joint_prologue); else -1
 };
 
 struct DevTip {
@@ -85,8 +86,9 @@ struct DevProblem {
     int32_t n_chain_ops;
     int32_t n_prefix;     // ops[0..n_prefix): a straight run of joints at the root that are not genes and carry no tip and no
                           // branch: their frame is the same for every individual of a query (the seed's), computed once
-    int32_t multi_op;     // chain op of the (single, root-level) floating / planar joint, -1 none: its frame is computed in
-                          // front of the walk and parked in LDS slot ops[multi_op].load_slot; inside the walk the op is a no-op
+    int32_t multi_op;     // FIRST chain op that is a floating / planar joint (any depth, any number since round 5), -1 none: the joint frames J(values) of
+                          // all such ops are computed in front of a walk and parked in their LDS slots (ops[k].multi_slot); inside the walk
+                          // such an op is F_out = (F_src o C) o J with J fetched from the slot
     int32_t n_root_tips;  // tips[0..n_root_tips) hang off the model root without any moving joint
     int32_t T;            // Problem::tip_link_indices.size()
     int32_t V;            // robot variables
@@ -105,7 +107,7 @@ struct DevProblem {
                              //    a branch frame, none is a mimic joint: the walk of the dense kernels then carries its frames in place
     int32_t reserved0;
     uint64_t active_mask;  // bit k: op k is an active gene (ops[k].gene >= 0)
-    double multi_c[7];     // constant frame in front of the floating / planar joint
+    double multi_c[7];     // (unused since round 5: the constant frame in front of a floating / planar joint lies in its op's cpos / ca)
     int32_t quat_op[4];    // op index of the first of the four orientation value ops
     uint64_t mimic_followers[BIOIK_MAX_OPS];  // bit m: chain op m is a mimic joint following op k
     int32_t op_of_gene[BIOIK_MAX_OPS];

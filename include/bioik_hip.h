@@ -148,7 +148,7 @@ typedef struct bioik_model_desc {
     const int32_t* joint_type;           /* [n_links] BIOIK_JOINT_*                                      */
     const double* joint_axis;            /* [n_links*3] Revolute/PrismaticJointModel::getAxis()          */
     const int32_t* joint_first_variable; /* [n_links] JointModel::getFirstVariableIndex(), -1 if none   */
-    const int32_t* joint_mimic;          /* [n_links] link index whose joint this joint mimics, -1 (a mimic of a mimic: UNSUPPORTED) */
+    const int32_t* joint_mimic;          /* [n_links] link index whose joint this joint mimics, -1 (a mimic of a mimic is resolved to the joint at the end of the chain with the composed factor and offset, as MoveIt's RobotModel::buildMimic does) */
     const double* joint_mimic_factor;    /* [n_links] getMimicFactor()                                   */
     const double* joint_mimic_offset;    /* [n_links] getMimicOffset()                                   */
     const double* var_min;               /* [n_variables] VariableBounds::min_position_                  */

@@ -98,6 +98,32 @@ def mobile_robot(base="floating", reach=1.0):
     return m
 
 
+def stage_robot(mid="planar", with_base=False):
+    """Test fixture only: an arm with a multi-variable joint in the MIDDLE of its chain -- a planar stage (x, y, theta) or a floating coupling (translation +
+    quaternion) between the shoulder and the elbow --, optionally on a planar base as well (two such joints on one chain).  The reference's FK takes such
+    joints wherever they are (forward_kinematics.h:120-135, 331-354); until round 5 the device took one, directly behind the root."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("stage_" + mid + ("_on_base" if with_base else ""))
+    m.add_link("world")
+    parent = "world"
+    if with_base:
+        m.add_link("base", "world", "base_joint", "planar", xyz=(0.0, 0.0, 0.05), velocity=1.0)
+        parent = "base"
+    m.add_link("l1", parent, "j1", "revolute", xyz=(0.0, 0.0, 0.2), axis=(0, 0, 1), lower=-2.5, upper=2.5, velocity=2.0)
+    m.add_link("l2", "l1", "j2", "revolute", xyz=(0.0, 0.1, 0.1), axis=(0, 1, 0), lower=-1.8, upper=1.8, velocity=2.0)
+    m.add_link("stage", "l2", "stage_joint", mid, xyz=(0.3, 0.0, 0.0), velocity=1.0)
+    m.add_link("l3", "stage", "j3", "revolute", xyz=(0.1, 0.0, 0.0), axis=(0, 1, 0), lower=-2.2, upper=2.2, velocity=2.5)
+    m.add_link("l4", "l3", "j4", "revolute", xyz=(0.25, 0.0, 0.0), axis=(1, 0, 0), lower=-3.0, upper=3.0, velocity=3.0)
+    m.add_link("tool", "l4", "tool_joint", "fixed", xyz=(0.15, 0.0, 0.0))
+    m.add_group("whole", joints=(["base_joint"] if with_base else []) + ["j1", "j2", "stage_joint", "j3", "j4"], tips=["tool", "stage"])
+    for i, name in enumerate(m.variable_names):
+        j, _, v = name.partition("/")
+        if j in ("stage_joint", "base_joint") and v in ("trans_x", "trans_y", "trans_z", "x", "y"):
+            m.var_min[i], m.var_max[i], m.var_bounded[i] = (-0.2, 0.2, 1) if j == "stage_joint" else (-1.0, 1.0, 1)
+    m._keep = None
+    return m
+
+
 def mimic_robot(chain=None):
     """Axis-aligned 6-joint arm (test fixture only) with two mimic joints (MoveIt JointModel::getMimic): the second elbow
     follows the shoulder pitch (a gene), and a finger on the tip's chain follows a finger that is on no goal chain (so the

@@ -194,6 +194,31 @@ def test_more_than_32_joints():
         HipSolver(ProblemTemplate(snake(64), "snake", [PoseGoal("tip")]))
 
 
+@pytest.mark.parametrize("mid,with_base", [("planar", False), ("floating", False), ("planar", True)])
+def test_floating_and_planar_joints_anywhere(mid, with_base):
+    """a planar stage / a floating coupling in the MIDDLE of the chain, and two multi-variable joints on one chain (round 5: forward_kinematics.h:120-135,
+    331-354 take them wherever they are).  As for the free base below: the forward-difference Jacobian columns go through acos / sqrt, which the device
+    library and libm round differently -- tables to 1e-9, plain `bio2` solves bit for bit, memetic solves at result level."""
+    from bio_ik_amd import PoseGoal, PositionGoal
+    from bio_ik_amd.solver import HipSolver
+    from conftest import stage_robot
+    m = stage_robot(mid, with_base)
+    t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("stage", weight=0.2)])
+    h, o = HipSolver(t), orc.Oracle(t)
+    assert h.D == o.D == 4 + (7 if mid == "floating" else 3) + (3 if with_base else 0)
+    pc.function_level(h, o, m, np.random.default_rng(9), n=500, frame_tol=1e-9, fit_rtol=1e-9)
+    pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 5), mode="bio2")
+    t1 = ProblemTemplate(m, "whole", [PoseGoal("tool")])
+    h1, o1 = HipSolver(t1), orc.Oracle(t1)
+    seeds, params, _ = make_queries(t1, o1.active_variables, o1.fk_genes, 256, seed=22)
+    p = abi.default_solve_params(population=64, max_steps=48, random_seed=3)
+    sol, fit, suc, steps = h1.solve_batch(p, seeds, params)
+    so = o1.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=8)
+    assert suc.mean() >= so[2].mean() - 0.03 and suc.mean() > 0.7  # (the oracle's own rate on this fixture at 48 steps: 0.79 ... 0.9)
+    perr, rerr = pc.pose_errors(o1, sol, params, tip=0, off=0)
+    assert perr[suc == 1].max() < POS_TOL and rerr[suc == 1].max() < ROT_TOL
+
+
 @pytest.mark.parametrize("base", ["floating", "planar"])
 def test_floating_and_planar_joints(base):
     """a free base in front of the arm (forward_kinematics.h:120-135, 695-726; ik_evolution_2.cpp:203-215, 320-324).  The Jacobian
@@ -321,7 +346,7 @@ def test_full_batch_c2_result_level(gpus, oracles, templates):
 
 def test_full_batch_c3_c4_result_level(gpus, oracles, templates):
     """configs[2] (two tips + MinimalDisplacement) and configs[3] (31-DOF snake + AvoidJointLimits, pop=512)"""
-    for cfg, pop, n, max_steps, min_rate in (("c3", 128, 4096, 64, 0.3), ("c4", 512, 4096, 64, 0.99)):
+    for cfg, pop, n, max_steps, min_rate in (("c3", 128, 4096, 128, 0.55), ("c4", 512, 4096, 64, 0.99)):  # (C3 on the device: 0.32 ... 0.34 within 64 steps, 0.60 ... 0.62 within 128, profiles/r05_c3_rates.log)
         h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
         with pc.oracle_arithmetic(0):
             seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, n, seed=0xB101C)
@@ -787,14 +812,18 @@ def test_error_conventions(pr2):
     """status codes instead of exceptions/aborts (include/bioik_hip.h)"""
     from bio_ik_amd import PoseGoal, RobotModel
     from bio_ik_amd.solver import BioIKError, HipSolver
-    m = RobotModel("float")  # a floating joint behind a moving joint: only the root-level virtual joint runs on the device
+    m = RobotModel("float")  # a planar joint that mimics another joint: what the device still has no form for (a floating joint behind a moving joint runs since round 5)
     m.add_link("base")
     m.add_link("turret", "base", "yaw", "revolute", axis=(0, 0, 1), lower=-1.0, upper=1.0, velocity=1.0)
     m.add_link("body", "turret", "fj", "floating")
-    m.add_group("g", joints=["yaw", "fj"], tips=["body"])
+    m.add_link("sled", "body", "pj", "planar", mimic=("yaw", 1.0, 0.0))
+    m.add_group("g", joints=["yaw", "fj", "pj"], tips=["sled"])
     with pytest.raises(BioIKError) as e:
-        HipSolver(ProblemTemplate(m, "g", [PoseGoal("body")]))
+        HipSolver(ProblemTemplate(m, "g", [PoseGoal("sled")]))
     assert e.value.code == abi.ERR_UNSUPPORTED
+    m.add_group("g2", joints=["yaw", "fj"], tips=["body"])
+    m._keep = None
+    assert HipSolver(ProblemTemplate(m, "g2", [PoseGoal("body")])).D == 8
     with pytest.raises(BioIKError) as e:
         HipSolver(ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")]), device=99)
     assert e.value.code == abi.ERR_NO_DEVICE

@@ -281,6 +281,24 @@ def test_floating_and_planar_joints(hostsim_lib, base):
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("mid,with_base", [("planar", False), ("floating", False), ("planar", True)])
+def test_floating_and_planar_joints_anywhere(hostsim_lib, mid, with_base):
+    """a planar stage / a floating coupling in the MIDDLE of the chain, and two multi-variable joints on one chain (round 5: forward_kinematics.h:120-135,
+    331-354 take them wherever they are): (F_src o C) o J with the joint frame parked per individual, forward-difference Jacobian columns against the
+    frame of the op in front; function level against the oracle, whole solves, the gradient family"""
+    from bio_ik_amd import PoseGoal, PositionGoal
+    from conftest import stage_robot
+    m = stage_robot(mid, with_base)
+    t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("stage", weight=0.2)])
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    assert h.D == o.D == 4 + (7 if mid == "floating" else 3) + (3 if with_base else 0)
+    pc.function_level(h, o, m, np.random.default_rng(9), n=60, exact_bits=True)
+    pc.trajectory(h, o, t, n=2, pop=16, steps_list=(1, 3))
+    pc.trajectory(h, o, t, n=1, pop=70, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+    pc.trajectory(h, o, t, n=2, pop=8, steps_list=(6,), mode="gd_c")
+    pc.trajectory(h, o, t, n=2, pop=8, steps_list=(4,), mode="jac")
+
+
 def test_wall_clock_timeout(sims, oracles, templates):
     """the caller's timeout (ik_parallel.h:160): every query runs at least one step, then stops when the launch's clock passes the
     budget; a generous timeout changes nothing"""
