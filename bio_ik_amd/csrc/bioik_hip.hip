@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "bioik_compile.h"
@@ -143,6 +144,27 @@ static unsigned long long be_device_clock_now() {
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(cs));
     return *(volatile unsigned long long*)word;
+}
+// wall time of what `enqueue` puts on stream s, in ms (two events and a wait for the second): the launcher's measured mapping choice (solve_dispatch)
+static bool be_can_time() { return true; }
+template <class F>
+static double be_time_ms(stream_t s, F&& enqueue) {
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    float ms = 0.0f;
+    try {
+        HIP_CHECK(hipEventRecord(e0, s));
+        enqueue();
+        HIP_CHECK(hipEventRecord(e1, s));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } catch (...) {
+        (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+        throw;
+    }
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    return (double)ms;
 }
 static void be_zero_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0, s); }
 static void be_fill_ff_async(void* p, size_t bytes, stream_t s) { be_fill_async(p, bytes, 0xff, s); }
@@ -326,6 +348,13 @@ struct bioik_problem {
         bool pinned = false;
     };
     std::map<std::pair<stream_t, int>, Scratch> scratch;
+    // The launcher's MEASURED mapping choice (solve_dispatch): per kind of call -- (children per species, FK mode, islands or not) under the latency schedule --
+    // the preset that ran a chip-filling call fastest, and what each eligible preset took (ms; < 0: not eligible)
+    struct Tuned {
+        int preset = -1;
+        double ms[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    };
+    std::map<std::tuple<int, int, int>, Tuned> tuned;
     std::vector<void*> retired_scratch;  // pinned buffers that eager solves have moved away from: captured graphs may still replay into them
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
@@ -370,6 +399,8 @@ struct SolveSwitches {
     bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
+    int autotune = 1;  // BIOIK_SOLVE_AUTOTUNE: 1 (default) = the host-pointer entries time the eligible lane mappings on a handle's first chip-filling call of a kind and keep
+                       // the fastest (solve_dispatch); 2 = the device-pointer entry does so too (it then waits for its stream once); 0 = the rules alone
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
     bool capture_one_launch = false;  // BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: a call on a stream that is being captured gets a one-launch mapping (round 4's rule)
     int sort_key_drop = 10;     // BIOIK_SOLVE_SORT_KEY_DROP=b (parity suites, 10 ... 52): the pre-selection's sort keys give up b low bits of a fitness, so that the exact path runs often
@@ -404,6 +435,7 @@ static SolveSwitches parse_switches() {
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
     w.capture_one_launch = geti("BIOIK_SOLVE_CAPTURE_ONE_LAUNCH", 0) != 0;
     w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
+    w.autotune = geti("BIOIK_SOLVE_AUTOTUNE", 1);
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -516,11 +548,10 @@ static void set_deadline(bioik_problem* p, const DevSolveParams& sp, stream_t st
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
-                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream) {
+                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream, const SolveSwitches& sw) {
     if (n == 0) return;
     DevSolveParams sp = sp_in;
     const DevProblem& dp = p->host.dev;
-    const SolveSwitches sw = switches();  // (the diagnostic switches as last parsed: no environment access on the launch path)
     const size_t kLds = p->model->dev.lds_cu;  // LDS of a CU (160 KiB on MI355X)
     const uint64_t kCus = (uint64_t)p->model->dev.cus;
     if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
@@ -896,6 +927,73 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The launcher's rules (launch_solve) were fitted to the three robots of BASELINE.json.  For a handle's FIRST chip-filling call of a kind under the latency
+// schedule the entry points that may wait for their stream (the host-pointer ones; the device-pointer one under BIOIK_SOLVE_AUTOTUNE=2) run the call once
+// per ELIGIBLE lane mapping -- every mapping returns the same bits, so each run is the caller's solve -- time it with events, keep the fastest in the handle
+// and use it from then on (BIOIK_SOLVE_REPORT prints the table).  The presets are what the BIOIK_SOLVE_* switches can force; a preset the problem has no
+// room or no kernel for is skipped.  Not for captured streams, solves with a timeout (their time is the caller's), the gradient family, or the throughput
+// schedule (a lone call says nothing about a stream of ten: its dense mapping is the measured choice of profiles/r03_inflight_and_schedule.log).
+// ------------------------------------------------------------------------------------------------------------
+static const int kPresets = 5;
+static const char* preset_name(int i) {
+    static const char* names[kPresets] = {"the rules", "128 lanes, computed children in pairs (128-register build where it exists)", "64 lanes, species on the halves, computed children in pairs",
+                                          "128 lanes, children kept in columns", "128 lanes, computed children one at a time"};
+    return names[i];
+}
+static SolveSwitches preset_switches(const SolveSwitches& base, int i) {
+    SolveSwitches w = base;
+    if (i == 1) w.threads = 128, w.columnless = 2, w.four_waves = true;
+    if (i == 2) w.threads = 64, w.species_parallel = 1, w.columnless = 2;
+    if (i == 3) w.threads = 128;
+    if (i == 4) w.threads = 128, w.columnless = 1;
+    return w;
+}
+static void solve_dispatch(bioik_problem* p, const DevSolveParams& sp, size_t n, const double* d_seeds, const double* d_params, double* d_solutions, double* d_fitness,
+                           int32_t* d_success, int32_t* d_steps, stream_t stream, bool may_wait) {
+    const SolveSwitches sw = switches();  // (the diagnostic switches as last parsed: no environment access on the launch path)
+    auto run = [&](const SolveSwitches& w) { launch_solve(p, sp, n, d_seeds, d_params, d_solutions, d_fitness, d_success, d_steps, stream, w); };
+    const uint64_t units = (uint64_t)n * (uint64_t)sp.islands;
+    const bool kind_ok = sw.autotune > 0 && !sw.manual() && !sw.general_set && !sw.two_phase_set && sw.drain_test == 0 && sw.dense_handover == 0 && sp.solver == 0 &&
+                         sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && sp.timeout_ticks == 0 && units >= 8 * (uint64_t)p->model->dev.cus && sp.max_steps >= 8;
+    if (!kind_ok || be_stream_capturing(stream)) {
+        run(sw);
+        return;
+    }
+    const auto key = std::make_tuple((int)sp.lambda, (int)sp.fk_mode, sp.islands > 1 ? 1 : 0);
+    auto it = p->tuned.find(key);
+    if (it != p->tuned.end() && it->second.preset >= 0) {
+        run(preset_switches(sw, it->second.preset));
+        return;
+    }
+    if (!(may_wait || sw.autotune >= 2) || !be_can_time()) {
+        run(sw);
+        return;
+    }
+    bioik_problem::Tuned t;
+    int best = 0;
+    for (int i = 0; i < kPresets; i++) {
+        const SolveSwitches w = preset_switches(sw, i);
+        try {
+            t.ms[i] = be_time_ms(stream, [&]() { run(w); });
+        } catch (const Error& e) {
+            if (i == 0 || (e.code != BIOIK_ERR_UNSUPPORTED && e.code != BIOIK_ERR_INVALID_ARGUMENT)) throw;  // (a preset this problem has no room for: skipped)
+            t.ms[i] = -1.0;
+        }
+        if (t.ms[i] >= 0.0 && t.ms[i] < t.ms[best]) best = i;
+    }
+    if (best != 0 && t.ms[best] > 0.97 * t.ms[0]) best = 0;  // (the rules stand unless something beats them by more than the run-to-run spread)
+    t.preset = best;
+    p->tuned[key] = t;
+    if (sw.report) {
+        std::fprintf(stderr, "[bioik] measured mapping choice (population %d, fk %d, islands %s; %llu units):\n", (int)sp.lambda, (int)sp.fk_mode, sp.islands > 1 ? "yes" : "no", (unsigned long long)units);
+        for (int i = 0; i < kPresets; i++)
+            if (t.ms[i] >= 0.0) std::fprintf(stderr, "[bioik]   %c %-90s %9.3f ms\n", i == best ? '*' : ' ', preset_name(i), t.ms[i]);
+            else std::fprintf(stderr, "[bioik]     %-90s   not eligible\n", preset_name(i));
+    }
+    // (the caller's arrays hold the last eligible run's results: every mapping's are the same bits, nothing to redo)
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1009,7 +1107,7 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
     std::lock_guard<std::mutex> lock(p->mtx);
     DeviceGuard on_device(p->model->device);
     DevSolveParams sp = bioik::normalize_params(*params, p->first_query, n, 8 * (size_t)p->model->dev.cus);
-    launch_solve(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream);
+    solve_dispatch(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream, false);
     API_END
 }
 
@@ -1067,8 +1165,8 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     // written once per query).  A transfer out enqueued behind the solve would sit at the head of a DMA queue until the solve is over -- 12 ms
     // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
     // (profiles/r03_inflight_and_schedule.log, host pipeline).
-    launch_solve(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
-                 (int32_t*)(hd + o_steps), st);
+    solve_dispatch(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
+                   (int32_t*)(hd + o_steps), st, true);
     sl.pending = true, sl.ticket = ticket, sl.n = n;
     sl.o_sol = o_sol, sl.o_fit = o_fit, sl.o_suc = o_suc, sl.o_steps = o_steps;
     sl.solutions = solutions, sl.fitness = fitness, sl.success = success, sl.steps = steps;

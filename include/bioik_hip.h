@@ -238,6 +238,12 @@ int bioik_device_count(void);
  * hand-overs, the mapping report) from the environment ONCE, when it is loaded; this call reads them again.  The test-suite uses it to run every
  * lane mapping in one process; nothing on the solve path touches the environment. */
 int bioik_debug_reload_switches(void);
+/* The launcher's lane mappings are chosen by rules fitted to the robots of BASELINE.json -- and, since round 5, checked by measurement: the FIRST
+ * chip-filling call (2048 (query, island) units and more) of a kind -- (population, fk_mode, islands or not) under the latency schedule, no timeout -- that a
+ * handle sees through a host-pointer entry (bioik_solve_batch, bioik_solve_batch_submit, bioik_solve_batch_multi) is run once per eligible mapping (each
+ * run IS the caller's solve: every mapping returns the same bits), timed with events, and the fastest is kept for the handle; bioik_solve_batch_device uses
+ * a handle's choice but never waits for its stream to make one (BIOIK_SOLVE_AUTOTUNE=2: it does; =0: the rules alone).  That first call takes about five
+ * times as long as the ones after it.  BIOIK_SOLVE_REPORT=1 prints the table (profiles/r05_measured_mapping_choice.log). */
 
 /* replaces RobotFK/RobotInfo construction from a RobotModel (ik_base.h:144-151) */
 int bioik_model_create(const bioik_model_desc* desc, int device, bioik_model** out);

@@ -13,6 +13,12 @@ unsigned long long sim_wall_clock() {
     return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
 }
 static unsigned long long be_device_clock_now() { return sim_wall_clock(); }
+static bool be_can_time() { return false; }  // (the simulator's times say nothing about the device: the launcher's measured mapping choice stays off)
+template <class F>
+static double be_time_ms(void*, F&& enqueue) {
+    enqueue();
+    return 0.0;
+}
 static void be_zero_async(void* p, size_t bytes, void*) { std::memset(p, 0, bytes); }
 static void be_fill_ff_async(void* p, size_t bytes, void*) { std::memset(p, 0xff, bytes); }
 typedef void* stream_t;

@@ -543,6 +543,26 @@ def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeyp
     assert all(np.array_equal(x, y) for x, y in zip(a, c))
 
 
+def test_measured_mapping_choice_changes_no_result(templates, monkeypatch):
+    """bioik_hip.hip: solve_dispatch -- a handle's first chip-filling call under the latency schedule runs once per eligible lane mapping and keeps the fastest;
+    whatever it keeps, the answers are those of the rules alone (BIOIK_SOLVE_AUTOTUNE=0), for a problem of BASELINE.json and for one outside every fitted
+    threshold (a 12-joint chain, 64 children per species); the device-pointer entry then uses the handle's choice without waiting"""
+    from bio_ik_amd import PoseGoal, snake
+    from bio_ik_amd.solver import HipSolver
+    for t, pop in ((templates["c2"], 128), (ProblemTemplate(snake(12), "snake", [PoseGoal("tip")]), 64)):
+        p = abi.default_solve_params(population=pop, max_steps=32, random_seed=4)
+        monkeypatch.setenv("BIOIK_SOLVE_AUTOTUNE", "0")
+        h0 = HipSolver(t)
+        seeds, params, _ = make_queries(t, h0.active_variables, h0.fk_genes, 4096, seed=51)
+        a = h0.solve_batch(p, seeds, params)
+        monkeypatch.setenv("BIOIK_SOLVE_AUTOTUNE", "1")
+        h1 = HipSolver(t)
+        b = h1.solve_batch(p, seeds, params)   # (times the presets)
+        c = h1.solve_batch(p, seeds, params)   # (runs the one it kept)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and all(np.array_equal(x, y) for x, y in zip(a, c))
+        monkeypatch.delenv("BIOIK_SOLVE_AUTOTUNE")
+
+
 def test_stragglers_that_leave_when_the_chip_runs_empty(gpus, oracles, templates, monkeypatch):
     """SolveArgs::resident on the device: a chip-filling call of the latency schedule starts under the dense kernel and hands its stragglers to
     k_solve_lean_cl4 when fewer than BIOIK_SOLVE_DRAIN_BELOW wavefronts are left -- which query leaves at which step is a matter of timing, the results
