@@ -494,6 +494,72 @@ int orc_solver_check(void* solver, int32_t* success, double* fitness) {
     return 0;
 }
 
+// Analysis vehicle (tools/fork_simulation.py; nothing of the product): bio2 solves in which a query still unsolved after `fork_step` steps continues as
+// `fork_islands` COPIES of its solver state that differ in their random streams from then on (copy 0 keeps the query's stream) and stop when one of them passes.
+// out_steps[k]: steps until the first copy passed (max_steps: none did); out_plain[k]: the same query without forking.
+int orc_fork_simulation(void* problem, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, int fork_step, int fork_islands,
+                        int32_t* out_steps, int32_t* out_plain, int n_threads, uint64_t first_query_index) {
+    try {
+        const Problem& p = ((OrcProblem*)problem)->problem;
+        const size_t V = p.model->vars.size(), P = (size_t)p.param_count;
+        std::atomic<size_t> next(0);
+        auto worker = [&]() {
+            Problem local = p;
+            std::vector<double> zero_params(1, 0.0);
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n) break;
+                Query q{seeds + k * V, P ? goal_params + k * P : zero_params.data()};
+                CounterRandom r;
+                r.key = query_key(params->random_seed, first_query_index + k, 0u);
+                Evolution2<CounterRandom> ik(&local, r, *params);
+                ik.initialize(q);
+                int steps = 0;
+                bool ok = false;
+                double f;
+                std::vector<Evolution2<CounterRandom>> copies;
+                int plain = params->max_steps;
+                while (steps < params->max_steps) {
+                    if (steps == fork_step && copies.empty() && fork_islands > 1) {
+                        for (int i = 1; i < fork_islands; i++) {
+                            copies.push_back(ik);
+                            copies.back().rng.key = query_key(params->random_seed, first_query_index + k, (uint32_t)i);
+                        }
+                    }
+                    ik.step();
+                    steps++;
+                    ik.check(ok, f);
+                    if (ok && plain == params->max_steps) plain = steps;
+                    bool any = ok;
+                    for (auto& c : copies) {
+                        c.step();
+                        bool ok2;
+                        double f2;
+                        c.check(ok2, f2);
+                        any = any || ok2;
+                    }
+                    if (any) break;
+                }
+                out_steps[k] = steps;
+                // the plain run, continued if a copy ended the forked one first
+                while (plain == params->max_steps && steps < params->max_steps) {
+                    ik.step();
+                    steps++;
+                    ik.check(ok, f);
+                    if (ok) plain = steps;
+                }
+                out_plain[k] = plain;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < (n_threads > 1 ? n_threads : 1); i++) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+        return 0;
+    } catch (const std::exception& e) {
+        return fail(e);
+    }
+}
+
 int orc_solve_batch(void* problem, const bioik_solve_params* params, int rng_mode, size_t n, const double* seeds,
                     const double* goal_params, double* solutions, double* fitness, int32_t* success, int32_t* steps, int n_threads,
                     double timeout_s, uint64_t first_query_index) {

@@ -4,6 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(ROOT, "gpurun_out"); p = os.path.join(ROOT, "profiles"); rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 shutil.copy(os.path.join(g, "prof_" + rnd, rnd + "_kernel_stats.csv"), os.path.join(p, rnd + "_kernel_stats.csv"))
 shutil.copy(os.path.join(g, "bench_" + rnd + ".json"), os.path.join(p, rnd + "_bench.json"))
+# registers, spilled registers and scratch bytes of every kernel of the library the session ran, from its code object (no GPU needed: regenerated here so that the
+# file always belongs to the tree the profile was taken on)
+import subprocess
+with open(os.path.join(p, rnd + "_kernel_metadata.txt"), "w") as fh:
+    subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_metadata.sh")], stdout=fh, check=False, cwd=ROOT)
 out = {}
 for f in ("pmc_fetch/fetch_counter_collection.csv", "pmc_write/write_counter_collection.csv", "pmc_sq/sq_counter_collection.csv", "pmc_mem/mem_counter_collection.csv", "pmc_ic/ic_counter_collection.csv"):
     if not os.path.exists(os.path.join(g, f)): continue

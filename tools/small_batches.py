@@ -10,6 +10,7 @@ from bio_ik_amd.workload import make_queries
 
 SIZES = [int(x) for x in os.environ.get("SMALL_SIZES", "1,16,64,256,1024").split(",")]
 REPS = int(os.environ.get("SMALL_REPS", "24"))
+POP, STEPS, FK = int(os.environ.get("SMALL_POP", "128")), int(os.environ.get("SMALL_STEPS", "64")), os.environ.get("SMALL_FK", "exact")  # (SMALL_POP=16 SMALL_FK=linear SMALL_STEPS=512: the reference's own parameters)
 
 
 def run(h, t, name, env, islands):
@@ -19,7 +20,7 @@ def run(h, t, name, env, islands):
     dev = torch.device("cuda", 0)
     out = []
     for n in SIZES:
-        p = abi.default_solve_params(population=128, max_steps=64, random_seed=1, islands=islands if islands > 0 else max(1, min(-islands, 4096 // max(n, 1))), island_sync=1 if islands != 1 else 0)
+        p = abi.default_solve_params(population=POP, max_steps=STEPS, fk_mode=abi.FK_LINEAR if FK == "linear" else abi.FK_EXACT, random_seed=1, islands=islands if islands > 0 else max(1, min(-islands, 4096 // max(n, 1))), island_sync=1 if islands != 1 else 0)
         reps = REPS if n <= 256 else max(6, REPS // 4)
         sets = []
         for r in range(reps):
