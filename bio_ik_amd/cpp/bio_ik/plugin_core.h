@@ -216,7 +216,7 @@ public:
         // goals without a device implementation (the hybrid path): every query was searched `replicas` times with independent random streams over
         // the device-capable goals; wait() scores the candidates with the host goals added and keeps the best
         size_t replicas = 1;
-        std::vector<const Goal*> host_goals;
+        std::vector<const Goal*> host_goals, device_goals;  // goals without / with a device implementation (the latter: what the device's fitness figures hold)
         double dmax_sq = 0.0;  // min(dpos, dtwist)^2: what a primary goal of a class the success test does not know must stay below (problem.cpp:327-334)
         Ticket() {}
         Ticket(const Ticket&) = delete;
@@ -274,6 +274,7 @@ public:
         // shaping them -- documented in DESIGN.md section 7.
         std::vector<const Goal*> device_goals;
         for (const Goal* g : rq.goals) (g->gpuOpcode() >= 0 ? device_goals : tk->host_goals).push_back(g);
+        tk->device_goals = device_goals;
         if (!tk->host_goals.empty()) {
             if (device_goals.empty())
                 throw std::runtime_error("bio_ik (MI355X): every goal of this request is a host callback (JointFunctionGoal, LinkFunctionGoal or a user-defined Goal): the "
@@ -370,8 +371,9 @@ public:
         bool all_ok = true;
         std::unique_ptr<HostGoalProblem> host;  // the goals the device did not see, evaluated through their own describe() / evaluate()
         std::vector<double> positions(V);
+        std::unique_ptr<HostGoalProblem> host_dev;  // the device-capable goals on the host: only for candidates the device accepted and the host rejects (below)
+        HostGoalProblem::Model hm;
         if (!tk.host_goals.empty() && n) {
-            HostGoalProblem::Model hm;
             for (size_t v = 0; v < V; v++)
                 hm.info.addVariable(mv_.var_min[v], mv_.var_max[v], mv_.var_bounded[v] != 0, mv_.var_max_velocity[v], mv_.var_revolute[v] != 0,
                                     v < mv_.var_prismatic.size() && mv_.var_prismatic[v] != 0);
@@ -411,8 +413,18 @@ public:
                         }
                     }
                     // (the device's fitness of an accepted candidate already holds its secondary goals, of a rejected one the primary goals only;
-                    // a candidate the host rejects is compared on primary fitness, like one the device rejected)
-                    const double total = tk.fit[r] + prim + (pass ? sec : 0.0);
+                    // a candidate the host rejects is compared on PRIMARY fitness, like one the device rejected: if the device had accepted it, its figure
+                    // is replaced by the primary goals of the device-capable list evaluated here -- the same closed forms, tests/cpp/test_goal_eval.cpp)
+                    double device_part = tk.fit[r];
+                    if (!pass && tk.suc[r] != 0) {
+                        if (!host_dev) host_dev.reset(new HostGoalProblem(hm, tk.device_goals, std::vector<int>(tk.active.begin(), tk.active.end()), std::vector<double>(&tk.seeds[0], &tk.seeds[0] + V)));
+                        host_dev->setInitialGuess(std::vector<double>(&tk.seeds[k * K * V], &tk.seeds[k * K * V] + V));
+                        const std::vector<double> ed = host_dev->evaluateGoals(positions);
+                        device_part = 0.0;
+                        for (size_t g = 0; g < ed.size(); g++)
+                            if (!host_dev->isSecondary(g)) device_part += ed[g] * host_dev->weightSq(g);
+                    }
+                    const double total = device_part + prim + (pass ? sec : 0.0);
                     tk.suc[r] = pass ? 1 : 0, tk.fit[r] = total;
                     if ((pass && !best_ok) || (pass == best_ok && total < best_fit)) best = r, best_fit = total, best_ok = pass;
                 }
