@@ -205,6 +205,15 @@ __global__ void __launch_bounds__(128, 4) k_solve_lean_cl4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, false, true, 2>(a, blockIdx.x, lds);
 }
+// k_solve_lean_cl4 with two HELPER wavefronts (solve_body<.., FIXED = 5>), for launches that leave most of the chip idle -- a single pose of the plugin, a few
+// hundred queries, the stragglers a chip-filling call hands over when the chip runs empty: wavefronts 0 and 1 are k_solve_lean_cl4's (a species each), wavefronts
+// 2 and 3 walk half of every generation's children for them, so that a generation's walks take a wavefront half the instructions.  A lone wavefront issues one
+// instruction per ~4.3 cycles whatever it does and k_solve_lean_cl4 keeps two of a CU's four SIMDs busy: this keeps four.  Hand-overs between the wavefronts
+// are words in LDS, the helpers reach no barrier (profiles/r05_helped_kernel.log)
+__global__ void __launch_bounds__(256, 4) k_solve_lean_cl4h(SolveArgs a) {
+    extern __shared__ double lds[];
+    solve_body<true, true, false, true, 5>(a, blockIdx.x, lds);
+}
 // The computed-children kernel for BIOIK_SCHEDULE_THROUGHPUT: ONE wavefront per query (both species on its halves; the compiler knows it and drops the
 // barriers) under the register budget of four wavefronts per SIMD
 // (solve_body<.., DENSE>: what the launcher guarantees for this kernel -- 64 lanes, the species on the halves of the wavefront, exact FK, children in
@@ -285,6 +294,7 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_lin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 #endif
 
@@ -399,6 +409,8 @@ struct SolveSwitches {
     bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
+    int helped = 1024;  // BIOIK_SOLVE_HELPED=N: launches of up to N (query, island) units of a problem k_solve_lean_cl4 covers without a secondary goal run its helped
+                        // build (k_solve_lean_cl4h: four wavefronts per unit), as do the stragglers a chip-filling call hands over; 0: never
     int autotune = 1;  // BIOIK_SOLVE_AUTOTUNE: 1 (default) = the host-pointer entries time the eligible lane mappings on a handle's first chip-filling call of a kind and keep
                        // the fastest (solve_dispatch); 2 = the device-pointer entry does so too (it then waits for its stream once); 0 = the rules alone
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
@@ -436,6 +448,7 @@ static SolveSwitches parse_switches() {
     w.capture_one_launch = geti("BIOIK_SOLVE_CAPTURE_ONE_LAUNCH", 0) != 0;
     w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
     w.autotune = geti("BIOIK_SOLVE_AUTOTUNE", 1);
+    w.helped = geti("BIOIK_SOLVE_HELPED", 1024);
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -517,9 +530,9 @@ struct DevBuf {
 #ifndef BIOIK_SOLVE_WAVES_PER_SIMD
 #define BIOIK_SOLVE_WAVES_PER_SIMD 3  // register budget of k_solve: wavefronts per SIMD (its __launch_bounds__)
 #endif
-static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false) {
+static size_t lds_bytes(const bioik_problem* p, int nthreads, int lambda, int child_cols = 1, int groups = 1, int slot_sets = 1, bool exact = false, bool fit_park = false, bool helped = false) {
     const DevProblem& d = p->host.dev;
-    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
+    return (size_t)make_layout(d.n_ops, d.V, d.P, d.T, d.n_slots, nthreads, lambda, d.n_secondary > 0 ? (exact ? 2 : 1) : 0, child_cols, groups, slot_sets, fit_park ? 1 : 0, lambda > 0 ? 1 : 0, helped ? 1 : 0).total * 8;  // (lambda > 0: a solve's layout; the function-level kernels keep their own)
 }
 
 // the timeout of a solve on the device clock (bioik_problem: clock_*)
@@ -798,6 +811,19 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const bool joint4 = joint && !sw.three_waves && (kLds / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
+        // k_solve_lean_cl4's helped build: launches that leave most of the chip idle (every unit gets four wavefronts instead of two), and the stragglers of a
+        // chip-filling call (the list is a fraction of the grid)
+        const bool helped_launch = lean && four_waves && prefer_cl4 && args.sp.columnless && dp.n_secondary == 0 && sw.helped > 0 &&
+                                   (units <= (uint64_t)sw.helped || (args.unit_list != nullptr && args.resident != nullptr));
+        if (helped_launch) {
+            const size_t lds_h = lds_bytes(p, 128, args.sp.lambda, 0, 2, 2, true, true, true);
+            if (lds_h > 64 * 1024) be_allow_lds(lds_h);
+            if (sw.report)
+                std::fprintf(stderr, "[bioik] launch: k_solve_lean_cl4h, 256 lanes (two of the four wavefronts are helpers), %zu B of LDS, steps [%d, %d)\n", lds_h, (int)args.step_begin,
+                             (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
+            LAUNCH(k_solve_lean_cl4h, (solve_body<true, true, false, true, 5>(args, b_, l_)), units, 256, lds_h, stream, args);
+            return;
+        }
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
                          !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? (joint4 ? "k_solve_lean_clj4" : "k_solve_lean_clj") : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",

@@ -26,9 +26,11 @@ struct LdsLayout {  // offsets in doubles; "g_" regions exist once per species g
     int xn, gv, frames, tips, delta, base, grad, red, sec, order, bc;  // offsets inside a group region
     int xm, xp, dv, fc;  // memetic phase (per group): support points x -+ g, gene displacements [4][m], tip-frame components [4][T*8]
     int fitp;            // fit_park: the children's fitness values of one generation [lambda], on the space of the memetic phase's vectors
+    int help;            // the helped kernel (solve_body<.., FIXED = 5>): sixteen 32-bit words -- the two main wavefronts' barrier counts, "go" and "done" per species,
+                         // a four-word mailbox per species (offsets of the parent's genes and of the momentum table, the stream's counter, the children to walk)
 };
 BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int nthreads, int lambda, int has_secondary, int child_cols = 1,
-                               int groups = 1, int slot_sets = 1, int fit_park = 0, int fc_in_pop = 0) {
+                               int groups = 1, int slot_sets = 1, int fit_park = 0, int fc_in_pop = 0, int helped = 0) {
     LdsLayout L;
     const int m = n_ops > 0 ? n_ops : 1;
     int o = 0;
@@ -39,6 +41,7 @@ BIOIK_HD LdsLayout make_layout(int n_ops, int V, int P, int T, int n_slots, int 
     L.prefix = o, o += 8;               // frame behind the leading non-gene joints (DevProblem::n_prefix), per query
     L.state = o, o += 2 * 8 + 4 + 4;    // species bookkeeping [2][8], workgroup broadcast slots [4], fitness / success flag of the solution [2] (+2 spare)
     L.clip = o, o += 2 * m;             // RobotInfo clip_min | clip_max per op (robot_info.h:109-113), staged once per query
+    L.help = o, o += helped ? 8 : 0;
     L.xcol = o, o += m * nthreads * (child_cols >= 0 ? child_cols : 1);  // genotype columns: [col][op][lane]; none when children are computed where they are read
     L.slots = o, o += n_slots * 7 * nthreads * (slot_sets > 0 ? slot_sets : 1);  // parked branch frames, one set per child a lane walks at once
     int g = 0;  // per species group: line-search vectors, linear model, reduction and pre-selection scratch
@@ -432,7 +435,7 @@ struct SpeciesState {
 // secondary goals, the pre-selected children of both species walked as one list (JOINT; k_solve_lean_clj4)
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
-    constexpr bool DENSE = FIXED == 1, WAVE2 = FIXED == 2, LIN = FIXED == 3, JH = FIXED == 4, HALVES = DENSE || LIN || JH;
+    constexpr bool DENSE = FIXED == 1, HELPED = FIXED == 5, WAVE2 = FIXED == 2 || HELPED, LIN = FIXED == 3, JH = FIXED == 4, HALVES = DENSE || LIN || JH;
     static_assert(FIXED != 4 || JOINT, "FIXED = 4 is the joint walk of both species' children (64 lanes, halves, exact FK, secondary goals: k_solve_lean_clj4)");
     static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
@@ -450,13 +453,13 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     // (counted in wavefronts: the launches that share the words differ in theirs.  One word per XCD, 128 bytes apart, each touched by the workgroups of
     // ITS XCD only: a word all eight L2s fight over cost 15 % of a stream's throughput, profiles/r04_drain_handover.log)
     auto my_resident = [&]() { return a.resident + 32 * p_xcc_id(); };  // (computed where it is used: no register carries it through the kernel)
-    if (a.resident && tid0 == 0) p_atomic_add(my_resident(), (unsigned int)(nth >> 6));
+    if (a.resident && tid0 == 0) p_atomic_add(my_resident(), (unsigned int)(HELPED ? 4 : nth >> 6));
     const int V = pb->V, P = pb->P, T = pb->T, n_ops = pb->n_ops, D = pb->D;
     const int lambda = sp.lambda;
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
-    const bool has_sec = DENSE ? false : (JH ? true : pb->n_secondary > 0);
+    const bool has_sec = (DENSE || HELPED) ? false : (JH ? true : pb->n_secondary > 0);
     const bool exact = LIN ? false : (FIXED ? true : sp.fk_mode == FK_EXACT);
     const bool child_pairs = LIN ? false : (FIXED ? true : sp.child_pairs != 0);
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
@@ -466,7 +469,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     const int groups = FIXED ? 2 : (sp.species_parallel ? 2 : 1);
     const int G = HALVES ? 32 : (WAVE2 ? 64 : nth / groups);        // lanes per species group (a multiple of 64, or half a wavefront)
     const int g_shift = HALVES ? 5 : (WAVE2 ? 6 : ((G & (G - 1)) == 0 ? 31 - __builtin_clz((unsigned)G) : -1));  // the group sizes the launcher produces are powers of two: no integer division
-    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0, 1);
+    const LdsLayout L = make_layout(n_ops, V, P, T, pb->n_slots, nth, lambda, has_sec ? (exact ? 2 : 1) : 0, columnless ? 0 : n_cols, groups, child_pairs ? 2 : 1, (CL && exact) ? 1 : 0, 1, HELPED ? 1 : 0);
     double* s_seed = lds + L.seed;
     double* s_par = lds + L.par;
     double* s_pop = lds + L.pop;
@@ -483,11 +486,59 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     PHASE_DECL;
     const uint64_t q = unit / (uint64_t)sp.islands;
     const uint32_t island = (uint32_t)(unit % (uint64_t)sp.islands);
-    for (int i = tid; i < V; i += nth) s_seed[i] = a.seeds[q * V + i];
-    for (int i = tid; i < P; i += nth) s_par[i] = a.params[q * P + i];
-    p_barrier();
+    const bool is_helper = HELPED && tid0 >= 128;  // (the helped kernel's wavefronts 2 and 3: they walk half of a generation's children for wavefronts 0 and 1 and do nothing else)
+    if (!is_helper) {
+        for (int i = tid; i < V; i += nth) s_seed[i] = a.seeds[q * V + i];
+        for (int i = tid; i < P; i += nth) s_par[i] = a.params[q * P + i];
+        if constexpr (HELPED)
+            if (tid < 16) ((unsigned int*)(lds + L.help))[tid] = 0u;
+    }
+    p_barrier();  // (the ONE hardware barrier of the helped kernel: its helper wavefronts never reach another, so from here on its two main wavefronts meet at wg_barrier's words)
     const QueryCtx qc{s_seed, s_par};
     const uint32_t key = rng_query_key(sp.random_seed, sp.first_query + q, island);
+    if constexpr (HELPED) {
+        if (is_helper) {
+            // A helper wavefront: for the species of main wavefront `hs`, generation after generation, the children 64 ... 127 (+ 128 j) of what that wavefront
+            // published -- the same accessor, the same walk, the same sum as the main wavefront's own share -- into the species' parked fitness values.
+            // Hand-overs are words in LDS (p_flag_*): "go" carries the generation's number, 0xffffffff means leave.
+            const int hs = p_wave_index() - 2;
+            unsigned int* const hw = (unsigned int*)(lds + L.help);
+            double* const s_fit = lds + L.g_first + hs * L.g_stride + L.fitp;
+            for (unsigned int expect = 1u;; expect++) {
+                if (p_flag_wait_ge(hw + 2 + hs, expect) == 0xffffffffu) break;
+                const int off_p0g = (int)hw[6 + 4 * hs], off_pgt = (int)hw[7 + 4 * hs], n_walk = (int)hw[9 + 4 * hs];
+                const uint32_t hctr1 = hw[8 + 4 * hs];
+                for (int r0 = 64; r0 < n_walk; r0 += 128) {
+                    const int r = r0 + p_lane_fresh(), ra = r < n_walk ? r : r0;  // (a lane without a child walks a copy and drops it)
+                    const double* const hp0 = lds + off_p0g;
+                    const ChildT<PB> cx[1] = {make_child_t(pb, key, hctr1, (uint32_t)ra + 2u, hp0, lds + off_pgt, M)};
+                    double f[1];
+                    eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
+                    if (pb->n_link_primary < pb->n_primary) f[0] += nonlink_primary(pb, make_child_x(pb, key, hctr1, (uint32_t)ra + 2u, hp0, hp0 + M, hp0 + 3 * M), qc);
+                    else f[0] += 0.0;
+                    f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
+                    if (r < n_walk) s_fit[r] = f[0];
+                }
+                p_wave_sync();
+                p_flag_store(hw + 4 + hs, expect);
+            }
+            return;
+        }
+    }
+    // the rendezvous of the workgroup: the hardware barrier, or (helped kernel: its helpers are elsewhere) a count per main wavefront in LDS that the other one waits for
+    unsigned int bar_count = 0u, gen_count = 0u;  // (gen_count: generations this main wavefront has published to its helper)
+    auto wg_barrier = [&]() {
+        if constexpr (HELPED) {
+            unsigned int* const hw = (unsigned int*)(lds + L.help);
+            const int w = p_wave_index();
+            p_wave_sync();
+            bar_count++;
+            p_flag_store(hw + w, bar_count);
+            (void)p_flag_wait_ge(hw + (w ^ 1), bar_count);
+        } else {
+            p_barrier();
+        }
+    };
     // Values every lane needs but one wavefront can compute (fitness of an elite, of the solution ...): the leading
     // wavefront of the species group / of the workgroup evaluates and publishes through LDS; the other wavefronts sleep
     // at the barrier instead of spending issue slots of their SIMDs on identical copies.
@@ -498,9 +549,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         if (glead) v = fn();
         if (G > 64) {
             if (gtid == 0) s_bc[0] = v;
-            p_barrier();
+            wg_barrier();
             v = s_bc[0];
-            p_barrier();
+            wg_barrier();
         }
         return v;
     };
@@ -513,10 +564,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
         if (G > 64) {
             if (gtid == 0) s_bc[0] = fc.fitness, s_bc[2] = (double)fc.ok;
-            p_barrier();
+            wg_barrier();
             fc.fitness = s_bc[0];
             fc.ok = (int)s_bc[2];
-            p_barrier();
+            wg_barrier();
         }
         return fc;
     };
@@ -525,10 +576,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         if (wlead) fc = exact_fitness_check<BIOIK_COOP_WALKS ? 64 : 0>(pb, x, qc, s_slots, dpos, drot, dtwist, do_check, s_prefix);  // (a vector of the whole workgroup)
         if (nth > 64) {
             if (tid == 0) s_wbc[0] = fc.fitness, s_wbc[1] = (double)fc.ok;
-            p_barrier();
+            wg_barrier();
             fc.fitness = s_wbc[0];
             fc.ok = (int)s_wbc[1];
-            p_barrier();
+            wg_barrier();
         }
         return fc;
     };
@@ -561,10 +612,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         }
     }
     for (int k = tid; k < n_ops; k += nth) s_clip[k] = pb->ops[k].clip_min, s_clip[M + k] = pb->ops[k].clip_max;
-    p_barrier();
+    wg_barrier();
     if (pb->n_prefix > 0) {  // the joints in front of the first gene see the seed in every individual: walk them once per query
         if (tid == 0) f7_store(s_prefix, fk_prefix(pb, XV{s_sol, 1}));
-        p_barrier();
+        wg_barrier();
     }
     // the seed is the first solution; whether it already satisfies the goals is what the first success test will find
     FitCheck fc0{0.0, 0};
@@ -587,7 +638,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         species_store(1, SpeciesState{P_INF, sol_fit, sol_fit, 1, 1, 0, 0, 0});
         s_solst[0] = sol_fit, s_solst[1] = (double)fc0.ok;
     }
-    p_barrier();
+    wg_barrier();
     // (species-parallel: a lane group runs the species of its own number; its loop below is one trip with a per-lane index)
     PHASE_MARK(PH_INIT);
 
@@ -901,7 +952,59 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     }
                 } else if (!JOINT && columnless && child_pairs && exact) {
                     // two children per trip, both computed where they are read: two independent dependency chains per lane
-                    if constexpr (SLIM) {
+                    if constexpr (HELPED) {
+                        // The helped kernel: this wavefront walks the children 0 ... 63 (+ 128 j) ONE at a time, its helper wavefront the children 64 ... 127
+                        // (+ 128 j) -- half the instructions of the pair walk per wavefront, on SIMDs a launch that cannot fill the chip leaves idle.  The
+                        // generation is published in the species' mailbox and "go" raised before the own walk starts; "done" is waited for behind it.
+                        unsigned int* const hw = (unsigned int*)(lds + L.help);
+                        {
+                            BIOIK_LANE_SCOPE;
+                            const int w = p_wave_index();
+                            if (gtid == 0) {
+                                hw[6 + 4 * w] = (unsigned int)(int)(p0g - lds), hw[7 + 4 * w] = (unsigned int)(int)(popS + (S.cur ^ 1) * BF - lds);
+                                hw[8 + 4 * w] = ctr1, hw[9 + 4 * w] = (unsigned int)n_eval;
+                            }
+                            p_wave_sync();
+                            gen_count++;
+                            p_flag_store(hw + 2 + w, gen_count);
+                        }
+                        for (int r0 = 0; r0 < n_eval; r0 += 128) {
+                            double f[1];
+                            {
+                                BIOIK_LANE_SCOPE;
+                                const int r = r0 + gtid, ra = r < n_eval ? r : 0;
+                                const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);
+                                const double* const pgt = popS + (S.cur ^ 1) * BF;
+                                const ChildT<PB> cx[1] = {make_child_t(pb, key, ctr1t, (uint32_t)ra + 2u, p0g, pgt, M)};
+                                PHASE_MARK(PH_REPRODUCE);
+                                eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
+                            }
+                            BIOIK_LANE_SCOPE;
+                            const int r = r0 + gtid;
+                            if (pb->n_link_primary < pb->n_primary) {
+                                const SpeciesState S2 = species_load(rank_now());
+                                const double* cb2 = s_pop + S2.slot * SP + S2.cur * BF;
+                                const uint32_t ctr2 = rng_ctr1(gctr, (uint32_t)S2.id, RNG_REPRODUCE);
+                                f[0] += nonlink_primary(pb, make_child_x(pb, key, ctr2, (uint32_t)(r < n_eval ? r : 0) + 2u, cb2, cb2 + M, cb2 + 3 * M), qc);
+                            } else {
+                                f[0] += 0.0;
+                            }
+                            f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
+                            PHASE_MARK(PH_FITNESS);
+                            double* const s_fit = gbase + L.fitp;
+                            if (r < n_eval) s_fit[r] = f[0];
+                        }
+                        {
+                            BIOIK_LANE_SCOPE;
+                            p_wave_sync();
+                            (void)p_flag_wait_ge(hw + 4 + p_wave_index(), gen_count);  // the helper's share of the fitness values is parked
+                        }
+                        {
+                            BIOIK_LANE_SCOPE;
+                            const double* const s_fit2 = gbase + L.fitp;
+                            for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);
+                        }
+                    } else if constexpr (SLIM) {
                         // the fitness values go to LDS (fit_park) and come back when the walks are over: nothing but the lane number lives across a walk
                         // (so the trip counter is uniform, and what follows a walk -- the goals that read no link, rarely present -- starts from the lane number again)
                         for (int r0 = 0; r0 < n_eval; r0 += 2 * G) {
@@ -1318,7 +1421,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 if (gtid == 0) species_store(rank_now(), S);
             }
         }
-        p_barrier();  // both species are ranked and their bookkeeping is in LDS
+        wg_barrier();  // both species are ranked and their bookkeeping is in LDS
         BIOIK_LANE_SCOPE;  // species management and the checks at the end of the step
 
         // species management (:617-645)
@@ -1338,7 +1441,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 BIOIK_FP_STRICT
                 const uint32_t wc1 = rng_ctr1((uint32_t)step * 16u, (uint32_t)B.id, RNG_WIPEOUT_GENE);
                 double* cb = s_pop + B.slot * SP + B.cur * BF;
-                p_barrier();
+                wg_barrier();
                 for (int k = tid; k < n_ops; k += nth) {
                     double v = cb[k];
                     if (pb->ops[k].gene >= 0) {
@@ -1348,7 +1451,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     cb[k] = v, cb[M + k] = 0.0;
                     cb[2 * M + k] = v, cb[3 * M + k] = 0.0;
                 }
-                p_barrier();
+                wg_barrier();
                 if (exact) B.pf0 = B.pf1 = wg_check(wlead, tid, XV{cb, 1}, 0.0, 0.0, 0.0, 0).fitness;
             }
         }
@@ -1358,15 +1461,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         const bool better = A.fit < s_solst[0];
         if (better) {
             const double* cb = s_pop + A.slot * SP + A.cur * BF;
-            p_barrier();
+            wg_barrier();
             for (int k = tid; k < n_ops; k += nth) s_sol[k] = cb[k];
         }
-        p_barrier();  // every lane has read the bookkeeping; lane 0 files the new ranking (and the new solution's figures) for the next step
+        wg_barrier();  // every lane has read the bookkeeping; lane 0 files the new ranking (and the new solution's figures) for the next step
         if (tid == 0) {
             species_store(0, A), species_store(1, B);
             if (better) s_solst[0] = A.fit, s_solst[1] = (double)A.ok;
         }
-        p_barrier();
+        wg_barrier();
         // ik_parallel.h:173-181: fitness and success test of the solution = those of the elite it was copied from (or of the seed)
         final_fit = s_solst[0];
         success = s_solst[1] != 0.0;
@@ -1394,11 +1497,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 s_wbc[2] = stop ? 1.0 : 0.0;
                 s_wbc[3] = overtaken ? 1.0 : 0.0;
             }
-            p_barrier();
+            wg_barrier();
             expired = s_wbc[2] != 0.0;
             const bool overtaken = s_wbc[3] != 0.0;
             drained = s_wbc[0] != 0.0;
-            p_barrier();
+            wg_barrier();
             if (overtaken) overtaken_out = true;
             if (expired || overtaken) break;
             if (drained) break;
@@ -1406,7 +1509,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     }
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
-    if (a.resident && tid == 0) p_atomic_sub(my_resident(), (unsigned int)(nth >> 6));
+    if (a.resident && tid == 0) p_atomic_sub(my_resident(), (unsigned int)(HELPED ? 4 : nth >> 6));
     const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && (step_end < sp.max_steps || drained);  // neither solved nor out of time: the next launch goes on
     if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;
@@ -1425,7 +1528,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     double* out = a.solutions + unit * (uint64_t)V;
     if (!handed_over)  // (a handed-over unit's results are written by the launch that finishes it)
         for (int i = tid; i < V; i += nth) out[i] = s_seed[i];
-    p_barrier();
+    wg_barrier();
     if (steps > 0 && !handed_over)
         for (int k = tid; k < n_ops; k += nth)
             if (pb->ops[k].gene >= 0) out[pb->ops[k].var] = s_sol[k];
@@ -1434,6 +1537,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         a.success[unit] = success ? 1 : 0;
         a.steps[unit] = steps;
     }
+    if constexpr (HELPED) p_flag_store((unsigned int*)(lds + L.help) + 2 + p_wave_index(), 0xffffffffu);  // this wavefront's helper may leave
     BIOIK_EPILOGUE_SCOPE_END
 }
 

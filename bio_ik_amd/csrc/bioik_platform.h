@@ -158,6 +158,28 @@ BIOIK_DEV T p_load_device(const T* p) { return __hip_atomic_load(p, __ATOMIC_REL
 template <class T>
 BIOIK_DEV void p_store_device(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
+// Hand-overs between WAVEFRONTS of one workgroup through 32-bit words in LDS, without s_barrier (the helped kernel, solve_body<.., FIXED = 5>: its helper
+// wavefronts never reach the workgroup's barriers).  A wavefront's LDS instructions execute in program order, so "data, then the word" on the writer's side and
+// "the word, then data" on the reader's is all the ordering there is to keep; the fences keep the COMPILER from moving accesses across.
+// p_flag_store: every lane stores the same value (one broadcast write).  p_flag_wait_ge: spins until *word >= value (s_sleep between the reads) and returns
+// what it read; it gives up after ~2^22 reads and returns 0xffffffff -- the "leave" value of the protocol -- so that a wavefront whose partner died ends too.
+BIOIK_DEV void p_flag_store(unsigned int* word, unsigned int value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *(volatile unsigned int*)word = value;
+}
+BIOIK_DEV unsigned int p_flag_wait_ge(const unsigned int* word, unsigned int value) {
+    unsigned int v = 0xffffffffu;
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        const unsigned int r = *(const volatile unsigned int*)word;
+        if (r >= value) {
+            v = r;
+            break;
+        }
+        if (spin >= 128) __builtin_amdgcn_s_sleep(1);  // (the first polls back to back: a partner that is about to arrive is met within one LDS round trip)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
 #define P_INF (__builtin_inf())
 #define BIOIK_FP_STRICT _Pragma("clang fp contract(off)")
 #define BIOIK_HD __host__ __device__ inline

@@ -543,6 +543,24 @@ def test_throughput_schedule_changes_no_result(gpus, oracles, templates, monkeyp
     assert all(np.array_equal(x, y) for x, y in zip(a, c))
 
 
+def test_helper_wavefronts(gpus, oracles, templates, monkeypatch):
+    """k_solve_lean_cl4h on the device: k_solve_lean_cl4's two wavefronts plus two helpers that walk half of every generation's children, handing over through
+    words in LDS -- the oracle's trajectories; small launches and the stragglers of a chip-filling call equal to what k_solve_lean_cl4 itself returns
+    (BIOIK_SOLVE_HELPED=0), bit for bit"""
+    h, o, t = gpus["c2"], oracles["c2"], templates["c2"]
+    pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 6))
+    pc.trajectory(h, o, t, n=8, pop=200, steps_list=(4,), islands=2, island_sync=1)
+    for n, kw in ((1, {}), (300, {}), (64, {"islands": 16, "island_sync": 1}), (1024, {}), (4096, {})):
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=61)
+        p = abi.default_solve_params(population=128, max_steps=64, random_seed=7, **kw)
+        monkeypatch.setenv("BIOIK_SOLVE_HELPED", "0")
+        a = h.solve_batch(p, seeds, params)
+        monkeypatch.setenv("BIOIK_SOLVE_HELPED", "1024")
+        b = h.solve_batch(p, seeds, params)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), n
+    monkeypatch.delenv("BIOIK_SOLVE_HELPED")
+
+
 def test_measured_mapping_choice_changes_no_result(templates, monkeypatch):
     """bioik_hip.hip: solve_dispatch -- a handle's first chip-filling call under the latency schedule runs once per eligible lane mapping and keeps the fastest;
     whatever it keeps, the answers are those of the rules alone (BIOIK_SOLVE_AUTOTUNE=0), for a problem of BASELINE.json and for one outside every fitted

@@ -427,6 +427,24 @@ def test_kernels_compiled_for_one_mapping(sims, oracles, templates, monkeypatch)
     pc.trajectory(sims["c3"], oracles["c3"], templates["c3"], n=2, pop=128, steps_list=(3,))
 
 
+def test_helper_wavefronts(sims, oracles, templates, monkeypatch):
+    """k_solve_lean_cl4h (solve_body<.., FIXED = 5>): k_solve_lean_cl4's two wavefronts plus two HELPERS that walk half of every generation's children; the
+    wavefronts hand over through words in LDS and the helpers reach no barrier.  What the launcher picks for launches of up to 1024 units of a PoseGoal-class
+    problem: populations of one and two trips per wavefront, an odd one, islands that stop each other, a solve resumed from a hand-over -- the oracle's
+    trajectories bit for bit; with BIOIK_SOLVE_HELPED=0 the same launches run k_solve_lean_cl4 itself."""
+    for helped in ("1024", "0"):
+        monkeypatch.setenv("BIOIK_SOLVE_HELPED", helped)
+        pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(1, 3))
+        pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=200, steps_list=(2,), islands=2, island_sync=1)
+        pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=131, steps_list=(2,), no_wipeout=1)
+    monkeypatch.setenv("BIOIK_SOLVE_HELPED", "1024")
+    monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "1,3")  # (the helped kernel as the second and third launch of a solve)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(5,))
+    monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE")
+    monkeypatch.setenv("BIOIK_SOLVE_DRAIN_TEST", "4")   # (... and as the consumer of units that leave their first launch at their own step)
+    pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=3, pop=128, steps_list=(6,))
+
+
 def test_joint_walk_under_the_small_register_budget(sims, oracles, templates, monkeypatch):
     """k_solve_lean_clj4 (solve_body<.., JOINT, SLIM, FIXED = 4>): both species of a query on the halves of one wavefront, secondary goals, the
     pre-selected children of both species walked as ONE list whose fitness values are parked per species in LDS -- what the launcher picks for

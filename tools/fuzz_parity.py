@@ -80,6 +80,8 @@ def main():
             env["BIOIK_SOLVE_TWO_PHASE"] = str(rng.choice(["1", "2", "3", "1,2", "2,4,6", "init"]))
         elif rng.random() < 0.2:  # every unit leaves its first launch at its own step (round 4: the hand-over when the chip runs empty, as its test pattern)
             env["BIOIK_SOLVE_DRAIN_TEST"] = str(rng.choice(["2", "5", "9"]))
+        if rng.random() < 0.4:  # round 5: small launches of PoseGoal-class problems run k_solve_lean_cl4's helped build by default: half of the draws keep the plain one
+            env["BIOIK_SOLVE_HELPED"] = "0"
         if rng.random() < 0.15:  # the pre-selection's sort keys give up so many bits that its exact path runs in most generations (round 4)
             env["BIOIK_SOLVE_SORT_KEY_DROP"] = str(rng.choice(["30", "44", "51"]))
         kw = {"no_wipeout": int(rng.random() < 0.2), "schedule": int(rng.random() < 0.25)}  # (schedule: BIOIK_SCHEDULE_THROUGHPUT where its mapping exists)

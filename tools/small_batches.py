@@ -20,7 +20,7 @@ def run(h, t, name, env, islands):
     dev = torch.device("cuda", 0)
     out = []
     for n in SIZES:
-        p = abi.default_solve_params(population=POP, max_steps=STEPS, fk_mode=abi.FK_LINEAR if FK == "linear" else abi.FK_EXACT, random_seed=1, islands=islands if islands > 0 else max(1, min(-islands, 4096 // max(n, 1))), island_sync=1 if islands != 1 else 0)
+        p = abi.default_solve_params(population=POP, max_steps=STEPS, fk_mode=abi.FK_LINEAR if FK == "linear" else abi.FK_EXACT, random_seed=1, islands=islands if islands >= 0 else max(1, min(-islands, 4096 // max(n, 1))), island_sync=1 if islands not in (0, 1) else 0)  # (islands=0: BIOIK_ISLANDS_AUTO, the library's own rule)
         reps = REPS if n <= 256 else max(6, REPS // 4)
         sets = []
         for r in range(reps):
@@ -38,7 +38,7 @@ def run(h, t, name, env, islands):
             st = o[3].cpu().numpy(); steps.append((st.mean(), st.max())); suc.append(o[2].cpu().numpy().mean())
         ms = 1e3 * np.mean(ts)
         out.append((n, ms))
-        print("%-28s n %5d islands %2d: %.3f ms per call (min %.3f max %.3f)  %.0f solves/s  steps mean %.1f, mean of max %.1f  success %.4f" % (name, n, p.islands, ms, 1e3 * min(ts), 1e3 * max(ts), n / np.mean(ts) * np.mean(suc), np.mean([a for a, b in steps]), np.mean([b for a, b in steps]), np.mean(suc)), flush=True)
+        print("%-28s n %5d islands %2d (0: auto): %.3f ms per call (min %.3f max %.3f)  %.0f solves/s  steps mean %.1f, mean of max %.1f  success %.4f" % (name, n, p.islands, ms, 1e3 * min(ts), 1e3 * max(ts), n / np.mean(ts) * np.mean(suc), np.mean([a for a, b in steps]), np.mean([b for a, b in steps]), np.mean(suc)), flush=True)
     return out
 
 
