@@ -43,7 +43,10 @@ _shims = {}
 
 def load_shim(path=None):
     """libbio_ik_shim.so (make -C bio_ik_amd/cpp shim; __graft_entry__.build() does).  No fallback: without it the class cannot solve."""
+    from_env = path is None and "BIOIK_PLUGIN_SHIM" in os.environ
     path = path or os.environ.get("BIOIK_PLUGIN_SHIM", SHIM_PATH)
+    if from_env and "hostsim" in os.path.basename(path):  # (the test-suite's shim over the host simulator is handed over explicitly, `lib=`: never through the environment)
+        raise ImportError("BIOIK_PLUGIN_SHIM names the test-suite's host-simulator shim (%s): bio_ik_amd has no CPU compute path" % path)
     if path in _shims:
         return _shims[path]
     if path == SHIM_PATH:

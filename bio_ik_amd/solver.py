@@ -101,7 +101,12 @@ def load_library(path=None):
         path = os.environ.get("BIOIK_HIP_LIBRARY", LIB_PATH)  # deployment override: another build of the same library
         if path != LIB_PATH:
             _share_hip_runtime_with_torch()
-            _lib = _declare(C.CDLL(path))
+            L = C.CDLL(path)
+            # (the override is for other BUILDS of the product library -- A/B variants, a profiling build; the test-suite's host simulator of the kernels is
+            # handed to HipSolver explicitly, `lib=`, and must never stand behind the product classes through the environment)
+            if hasattr(L, "hostsim_divergent_collectives"):
+                raise ImportError("BIOIK_HIP_LIBRARY names the test-suite's host simulator (%s): bio_ik_amd has no CPU compute path" % path)
+            _lib = _declare(L)
             return _lib
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

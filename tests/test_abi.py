@@ -63,3 +63,18 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text and "orc_" not in text, f
+
+
+def test_the_environment_cannot_put_the_simulator_behind_the_product_classes(hostsim_lib, monkeypatch):
+    """BIOIK_HIP_LIBRARY / BIOIK_PLUGIN_SHIM select other BUILDS of the product libraries (A/B variants, a profiling build); the test-suite's host simulator is
+    refused there -- it reaches HipSolver / BioIKKinematicsPlugin only as an explicit `lib=` argument of a test"""
+    import pytest
+    from bio_ik_amd import plugin, solver
+    monkeypatch.setenv("BIOIK_HIP_LIBRARY", os.path.join(ROOT, "tests", "hostsim", "libbioik_hostsim.so"))
+    monkeypatch.setattr(solver, "_lib", None)
+    with pytest.raises(ImportError):
+        solver.load_library()
+    monkeypatch.setattr(solver, "_lib", None)
+    monkeypatch.setenv("BIOIK_PLUGIN_SHIM", os.path.join(ROOT, "tests", "hostsim", "libbio_ik_shim_hostsim.so"))
+    with pytest.raises(ImportError):
+        plugin.load_shim()
