@@ -406,7 +406,9 @@ struct SolveSwitches {
     int dense_handover = 0;     // BIOIK_SOLVE_DENSE_HANDOVER=K: a throughput solve hands the queries that pass K steps over to the latency mapping (0: never)
     int drain_below = 1024;     // BIOIK_SOLVE_DRAIN_BELOW=N: the dense kernel's stragglers leave for the latency mapping when fewer than N wavefronts of the handle's launches
                                 // are left on the chip (0: never): isolated chip-filling calls of the latency schedule (launch_solve: latency_drain)
-    bool drain_throughput = false;  // BIOIK_SOLVE_DRAIN_THROUGHPUT=1: ... and the throughput schedule's solves too
+    bool drain_throughput = true;   // BIOIK_SOLVE_DRAIN_THROUGHPUT=0: the throughput schedule's solves do NOT hand their stragglers over (round 5: they do -- with k_solve_lean_cl4h as the
+                                    // stragglers' kernel a stream's tail gains more than the bookkeeping costs: 20 timed steps +3.5 %, 60 steps +-0, profiles/r05_drain_throughput.log)
+    int drain_below_throughput = 512;  // BIOIK_SOLVE_DRAIN_BELOW_THROUGHPUT=N: ... when fewer than N wavefronts are left (a stream keeps the chip fuller than an isolated call: later)
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
     int helped = 1024;  // BIOIK_SOLVE_HELPED=N: launches of up to N (query, island) units of a problem k_solve_lean_cl4 covers without a secondary goal run its helped
@@ -441,7 +443,8 @@ static SolveSwitches parse_switches() {
     w.no_joint = std::getenv("BIOIK_SOLVE_NO_JOINT") != nullptr;
     w.dense_handover = geti("BIOIK_SOLVE_DENSE_HANDOVER", 0);
     w.drain_below = geti("BIOIK_SOLVE_DRAIN_BELOW", 1024);
-    w.drain_throughput = geti("BIOIK_SOLVE_DRAIN_THROUGHPUT", 0) != 0;
+    w.drain_throughput = geti("BIOIK_SOLVE_DRAIN_THROUGHPUT", 1) != 0;
+    w.drain_below_throughput = geti("BIOIK_SOLVE_DRAIN_BELOW_THROUGHPUT", 512);
     w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
     w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
@@ -869,7 +872,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     } else if (throughput) {
         // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
         if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
-        else if (dense && sw.drain_throughput && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing) when_draining = true, handovers.push_back(sp.max_steps);
+        else if (dense && prefer_cl4 && units >= 8 * kCus && sw.drain_throughput && sw.drain_below > 0 && sw.drain_below_throughput > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing)
+            when_draining = true, handovers.push_back(sp.max_steps);
     } else if (latency_drain) {
         when_draining = true, handovers.push_back(sp.max_steps);
     } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 8 * kCus && sp.max_steps >= 24 && !capturing) {
@@ -920,7 +924,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                 aj.resident = p->d_resident;
                 {  // (per XCD -- eight on MI355X --, the threshold itself scaled to the chip's CUs: BIOIK_SOLVE_DRAIN_BELOW names it for 256 of them)
                     const int xcds = p->model->dev.xcds > 0 ? p->model->dev.xcds : 1;
-                    const long long below = (long long)sw.drain_below * (long long)kCus / 256;
+                    const long long below = (long long)(throughput ? sw.drain_below_throughput : sw.drain_below) * (long long)kCus / 256;
                     aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (int32_t)((below + xcds - 1) / xcds);
                 }
                 aj.drain_min_steps = sw.drain_min_steps;

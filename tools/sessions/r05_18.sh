@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5, GPU session 18: the throughput schedule with the hand-over when the chip runs empty (stragglers on to k_solve_lean_cl4h) at the driver's 20 steps and at 60
+O=gpurun_out/r05s18; mkdir -p $O
+export TMPDIR=/tmp
+for rep in 1 2; do for d in 0 1; do for st in 20 60; do
+  echo -n "BIOIK_SOLVE_DRAIN_THROUGHPUT=$d, $st steps: "; BIOIK_SOLVE_DRAIN_THROUGHPUT=$d python bench.py --no-cpu-baseline --timed-only --steps $st --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f solves/s  %.3f ms/batch chip %.3f' % (d['value'], d['ms_per_step'], d['roofline']['chip_level_frac']))"
+done; done; done 2>&1 | tee $O/drain_throughput.log
