@@ -408,6 +408,9 @@ struct SolveSwitches {
                                 // are left on the chip (0: never): isolated chip-filling calls of the latency schedule (launch_solve: latency_drain)
     bool drain_throughput = true;   // BIOIK_SOLVE_DRAIN_THROUGHPUT=0: the throughput schedule's solves do NOT hand their stragglers over (round 5: they do -- with k_solve_lean_cl4h as the
                                     // stragglers' kernel a stream's tail gains more than the bookkeeping costs: 20 timed steps +3.5 %, 60 steps +-0, profiles/r05_drain_throughput.log)
+    int drain_min_units = 1025;  // BIOIK_SOLVE_DRAIN_MIN_UNITS=N: the latency schedule starts a call of N units and more (on 256 CUs; scaled to the chip) under the dense kernel and hands the
+                                 // stragglers over; smaller calls run k_solve_lean_cl4 (or its helped build) from the start.  (With four and more islands per query, which stop
+                                 // each other after a few steps, the dense kernel's long steps cost more than they bring below 3072 units: profiles/r05_drain_min_units.log)
     int drain_below_throughput = 512;  // BIOIK_SOLVE_DRAIN_BELOW_THROUGHPUT=N: ... when fewer than N wavefronts are left (a stream keeps the chip fuller than an isolated call: later)
     int drain_min_steps = 4;    // BIOIK_SOLVE_DRAIN_MIN_STEPS: ... and have run this many steps
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
@@ -445,6 +448,7 @@ static SolveSwitches parse_switches() {
     w.drain_below = geti("BIOIK_SOLVE_DRAIN_BELOW", 1024);
     w.drain_throughput = geti("BIOIK_SOLVE_DRAIN_THROUGHPUT", 1) != 0;
     w.drain_below_throughput = geti("BIOIK_SOLVE_DRAIN_BELOW_THROUGHPUT", 512);
+    w.drain_min_units = geti("BIOIK_SOLVE_DRAIN_MIN_UNITS", 1025);
     w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
     w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
@@ -752,7 +756,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // its first replay and wrong (unit 0 continued from a state nobody wrote) or aborting from its second on, whatever the resident words do; eager calls, back
     // to back on one stream or not, are right; unexplained, DESIGN.md section 8 -- so captured calls get a one-launch mapping, which replays correctly)
     const bool capturing = sw.capture_one_launch && be_stream_capturing(stream);
-    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= 12 * kCus && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
+    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= (uint64_t)(sp.islands <= 2 ? sw.drain_min_units : 3072) * kCus / 256 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set && !capturing;
     const bool dense = (throughput || latency_drain) && dense_ok;
     if (sw.columnless > 0 && can_columnless) {
