@@ -672,7 +672,13 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // 5.74 ms, profiles/r04_small_batches.log)
     if (cl4_eligible && nth == 256) nth = 128;
     const bool prefer_cl4 = cl4_eligible && nth == 128;
-    if (prefer_cl4) {
+    // ... and, for launches small enough for its helped build (k_solve_lean_cl4h), the same mapping for serial chains WITH secondary goals (a 7-joint arm with a
+    // MinimalDisplacementGoal, the 31-joint chain with AvoidJointLimitsGoal: the usual MoveIt configurations of bio_ik): the kernel pre-selects, the helper takes
+    // half of the survivors' walks.  Chip-filling batches of such problems keep the mappings chosen below (the joint walk, the 128-register build by residency).
+    const bool small_sec_cl4 = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary > 0 && sp.lambda >= 128 &&
+                               sw.helped > 0 && units <= (uint64_t)sw.helped && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
+    if (small_sec_cl4) nth = 128;
+    if (prefer_cl4 || small_sec_cl4) {
         sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
     } else if (!manual && nth == 128) {
         struct Cand {
@@ -808,7 +814,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
         // (k_solve_lean_cl4 is compiled for exactly this mapping -- solve_body<.., FIXED = 2> --: 128 lanes, a wavefront per species, exact FK, children in pairs)
         const bool cl4_mapping = lanes == 128 && args.sp.species_parallel && args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_EXACT && dp.serial_chain != 0;
-        const bool four_waves = cl4_mapping && (((kLds / lds_b) * (size_t)(lanes / 64) >= 16 && (args.sp.lambda >= 8 * group_lanes || prefer_cl4) && !sw.three_waves) ||
+        const bool four_waves = cl4_mapping && (((kLds / lds_b) * (size_t)(lanes / 64) >= 16 && (args.sp.lambda >= 8 * group_lanes || prefer_cl4 || small_sec_cl4) && !sw.three_waves) ||
                                                 sw.four_waves);  // (diagnostic: the 128-register build wherever its mapping is the one in use)
         // both species on one wavefront, secondary goals, exact FK, children in pairs: the joint walk of the two species' children
         // (with a wavefront per species -- 128 lanes, C4 -- the same walk gains nothing: a wavefront that waits at a barrier costs no issue slots,
@@ -820,10 +826,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
         // k_solve_lean_cl4's helped build: launches that leave most of the chip idle (every unit gets four wavefronts instead of two), and the stragglers of a
         // chip-filling call (the list is a fraction of the grid)
-        const bool helped_launch = lean && four_waves && prefer_cl4 && args.sp.columnless && dp.n_secondary == 0 && sw.helped > 0 &&
+        // (since its second version also for problems with secondary goals -- the 31-joint chain with AvoidJointLimitsGoal --: the helper takes the upper half of the
+        // pre-selected children's walks)
+        const bool helped_launch = lean && four_waves && !manual && !sw.four_waves && args.sp.columnless && sw.helped > 0 &&
                                    (units <= (uint64_t)sw.helped || (args.unit_list != nullptr && args.resident != nullptr));
         if (helped_launch) {
-            const size_t lds_h = lds_bytes(p, 128, args.sp.lambda, 0, 2, 2, true, true, true);
+            const size_t lds_h = lds_b + 64;  // (make_layout: the sixteen words of the hand-overs)
             if (lds_h > 64 * 1024) be_allow_lds(lds_h);
             if (sw.report)
                 std::fprintf(stderr, "[bioik] launch: k_solve_lean_cl4h, 256 lanes (two of the four wavefronts are helpers), %zu B of LDS, steps [%d, %d)\n", lds_h, (int)args.step_begin,

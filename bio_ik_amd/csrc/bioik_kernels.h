@@ -459,7 +459,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     int n_sort = 2;  // pre-selection sorts lambda children: next power of two
     while (n_sort < lambda) n_sort <<= 1;
     const uint64_t active_mask = pb->active_mask;  // bit k: op k is a gene
-    const bool has_sec = (DENSE || HELPED) ? false : (JH ? true : pb->n_secondary > 0);
+    const bool has_sec = DENSE ? false : (JH ? true : pb->n_secondary > 0);
     const bool exact = LIN ? false : (FIXED ? true : sp.fk_mode == FK_EXACT);
     const bool child_pairs = LIN ? false : (FIXED ? true : sp.child_pairs != 0);
     const int n_cols = sp.child_cols > 0 ? sp.child_cols : 1;
@@ -508,13 +508,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 if (p_flag_wait_ge(hw + 2 + hs, expect) == 0xffffffffu) break;
                 const int off_p0g = (int)hw[6 + 4 * hs], off_pgt = (int)hw[7 + 4 * hs], n_walk = (int)hw[9 + 4 * hs];
                 const uint32_t hctr1 = hw[8 + 4 * hs];
+                const int32_t* const h_order = (const int32_t*)(lds + L.g_first + hs * L.g_stride + L.order);  // (secondary goals: the species' children in pre-selected order)
                 for (int r0 = 64; r0 < n_walk; r0 += 128) {
                     const int r = r0 + p_lane_fresh(), ra = r < n_walk ? r : r0;  // (a lane without a child walks a copy and drops it)
+                    const int c = has_sec ? h_order[ra] : ra;
                     const double* const hp0 = lds + off_p0g;
-                    const ChildT<PB> cx[1] = {make_child_t(pb, key, hctr1, (uint32_t)ra + 2u, hp0, lds + off_pgt, M)};
+                    const ChildT<PB> cx[1] = {make_child_t(pb, key, hctr1, (uint32_t)c + 2u, hp0, lds + off_pgt, M)};
                     double f[1];
                     eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
-                    if (pb->n_link_primary < pb->n_primary) f[0] += nonlink_primary(pb, make_child_x(pb, key, hctr1, (uint32_t)ra + 2u, hp0, hp0 + M, hp0 + 3 * M), qc);
+                    if (pb->n_link_primary < pb->n_primary) f[0] += nonlink_primary(pb, make_child_x(pb, key, hctr1, (uint32_t)c + 2u, hp0, hp0 + M, hp0 + 3 * M), qc);
                     else f[0] += 0.0;
                     f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
                     if (r < n_walk) s_fit[r] = f[0];
@@ -973,9 +975,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             {
                                 BIOIK_LANE_SCOPE;
                                 const int r = r0 + gtid, ra = r < n_eval ? r : 0;
+                                const int c = has_sec ? s_order[ra] : ra;
                                 const uint32_t ctr1t = rng_ctr1(gctr, (uint32_t)species_load(rank_now()).id, RNG_REPRODUCE);
                                 const double* const pgt = popS + (S.cur ^ 1) * BF;
-                                const ChildT<PB> cx[1] = {make_child_t(pb, key, ctr1t, (uint32_t)ra + 2u, p0g, pgt, M)};
+                                const ChildT<PB> cx[1] = {make_child_t(pb, key, ctr1t, (uint32_t)c + 2u, p0g, pgt, M)};
                                 PHASE_MARK(PH_REPRODUCE);
                                 eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
                             }
@@ -985,7 +988,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const SpeciesState S2 = species_load(rank_now());
                                 const double* cb2 = s_pop + S2.slot * SP + S2.cur * BF;
                                 const uint32_t ctr2 = rng_ctr1(gctr, (uint32_t)S2.id, RNG_REPRODUCE);
-                                f[0] += nonlink_primary(pb, make_child_x(pb, key, ctr2, (uint32_t)(r < n_eval ? r : 0) + 2u, cb2, cb2 + M, cb2 + 3 * M), qc);
+                                const int ra2 = r < n_eval ? r : 0;
+                                f[0] += nonlink_primary(pb, make_child_x(pb, key, ctr2, (uint32_t)(has_sec ? s_order[ra2] : ra2) + 2u, cb2, cb2 + M, cb2 + 3 * M), qc);
                             } else {
                                 f[0] += 0.0;
                             }

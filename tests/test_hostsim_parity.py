@@ -438,6 +438,15 @@ def test_helper_wavefronts(sims, oracles, templates, monkeypatch):
         pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=200, steps_list=(2,), islands=2, island_sync=1)
         pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=1, pop=131, steps_list=(2,), no_wipeout=1)
     monkeypatch.setenv("BIOIK_SOLVE_HELPED", "1024")
+    # ... with secondary goals (the main wavefront pre-selects, the helper takes the upper half of the survivors' walks): the 31-joint chain at 512 and at an odd
+    # number of children, a 7-joint arm with a MinimalDisplacementGoal at one and two trips per wavefront
+    from bio_ik_amd import MinimalDisplacementGoal, PoseGoal
+    pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=512, steps_list=(2,))
+    pc.trajectory(sims["c4"], oracles["c4"], templates["c4"], n=1, pop=150, steps_list=(2,), islands=2)
+    ts = ProblemTemplate(templates["c2"].model, "right_arm", [PoseGoal("r_wrist_roll_link"), MinimalDisplacementGoal()])
+    hs, os_ = HipSolver(ts, lib=sims["c2"].L), orc.Oracle(ts)
+    pc.trajectory(hs, os_, ts, n=2, pop=128, steps_list=(3,))
+    pc.trajectory(hs, os_, ts, n=1, pop=200, steps_list=(2,))
     monkeypatch.setenv("BIOIK_SOLVE_TWO_PHASE", "1,3")  # (the helped kernel as the second and third launch of a solve)
     pc.trajectory(sims["c2"], oracles["c2"], templates["c2"], n=2, pop=128, steps_list=(5,))
     monkeypatch.delenv("BIOIK_SOLVE_TWO_PHASE")

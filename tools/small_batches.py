@@ -43,7 +43,15 @@ def run(h, t, name, env, islands):
 
 
 def main():
-    t = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
+    prob = os.environ.get("SMALL_PROBLEM", "c2")  # c2: the bench workload; c2sec: the same arm with a MinimalDisplacementGoal; c4: the 31-joint chain with AvoidJointLimitsGoal (SMALL_POP=512)
+    if prob == "c2sec":
+        from bio_ik_amd import MinimalDisplacementGoal
+        t = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link"), MinimalDisplacementGoal()])
+    elif prob == "c4":
+        from bio_ik_amd import AvoidJointLimitsGoal, snake
+        t = ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()])
+    else:
+        t = ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link")])
     h = HipSolver(t, device=0)
     variants = sys.argv[1:] or ["default:"]
     for v in variants:
