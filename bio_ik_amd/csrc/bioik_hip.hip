@@ -1218,7 +1218,15 @@ static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint6
     if (n == 0) return;
     std::lock_guard<std::mutex> lock(p->mtx);
     const uint64_t ticket = p->next_ticket++;
-    bioik_problem::IoSlot& sl = p->io[ticket % bioik_problem::kIoSlots];
+    // (a synchronous call needs no slot of its own: an idle one whose stream and arenas exist already, so that a loop of searchPositionIK calls does not pay for
+    // six streams and six pairs of arenas -- 10 ms each -- during its first six calls)
+    size_t pick = ticket % bioik_problem::kIoSlots;
+    for (size_t i = 0; i < (size_t)bioik_problem::kIoSlots; i++)
+        if (!p->io[i].pending && p->io[i].stream_made) {
+            pick = i;
+            break;
+        }
+    bioik_problem::IoSlot& sl = p->io[pick];
     io_begin(p, sl, ticket, params, first_query, n, seeds, goal_params, solutions, fitness, success, steps);
     io_finish(p, sl);
 }
