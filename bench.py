@@ -268,7 +268,7 @@ def small_batches(h, template, dev, seeds, params, cpu=True):
             if key == "gpu_ms":
                 e["gpu_solves_per_s"] = suc / float(np.sum(ts))
                 e["gpu_success_rate"] = suc / (reps * n)
-                e["gpu_islands"] = max(1, min(16, 2048 // n))
+                e["gpu_islands"] = max(4, min(16, 2048 // n)) if n <= 1024 else 1
                 e["gpu_max_steps_of_a_call"] = float(np.mean(st))
         if r is not None:
             ts = []

@@ -590,7 +590,13 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
     // BIOIK_ISLANDS_AUTO: the islands the idle part of the chip carries (`resident_units` workgroups of the latency schedule's kernel are resident at once: 2048 on MI355X), at most
     // sixteen per query; they stop each other (profiles/r05_small_batches.log)
     const bool auto_islands = p.islands <= 0 && o.solver == 0 && n_queries > 0;
-    if (auto_islands) o.islands = (int32_t)std::max<size_t>(1, std::min<size_t>(16, resident_units / n_queries));
+    if (auto_islands) {
+        // (measured, profiles/r05_small_batches.log: sixteen at most; the resident workgroups shared out down to four per query -- calls of up to half the resident
+        // workgroups still gain from four, 896 queries 6.1 -> 5.1 ms --; beyond that one)
+        size_t isl = std::min<size_t>(16, resident_units / n_queries);
+        if (n_queries <= resident_units / 2) isl = std::max<size_t>(isl, 4);
+        o.islands = (int32_t)std::max<size_t>(1, isl);
+    }
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;
     if (p.timeout > 0.0 && std::isfinite(p.timeout)) {  // seconds -> ticks of the 100 MHz constant device clock, at least one
         const double ticks = p.timeout * 1e8;

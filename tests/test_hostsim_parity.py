@@ -527,7 +527,7 @@ def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
 
 
 def test_islands_sized_to_the_idle_chip(sims, templates):
-    """bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): max(1, min(16, 2048 / n)) islands per query that stop each other -- the same solve as that count
+    """bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): min(16, 2048 / n) islands per query (at least four up to 1024 queries, one beyond) that stop each other -- the same solve as that count
     given explicitly with island_sync = 1; the gradient family keeps one island (an island count there names another solver)"""
     h, t = sims["c2"], templates["c2"]
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=21)
