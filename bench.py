@@ -547,15 +547,17 @@ def main():
         "roofline": {"bound": "fp64_valu", "achieved": alg_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,  # chip level: the flops of all timed solves over the timed region's wall time
                      "frac_per_solve": alg_flops / (kernel_ms * 1e-3) / FP64_PEAK if kernel_ms > 0 else 0.0, "traffic": traffic, "traffic_provenance": traffic_note,
-                     "kernel": "k_solve_lean_cl64w4" if args.schedule == "throughput" else "k_solve_lean_cl + k_solve_lean", "kernel_ms": kernel_ms,
+                     "kernel": "k_solve_lean_cl64w4 + k_solve_lean_cl4h" if args.schedule == "throughput" else "k_solve_lean_cl64w4 + k_solve_lean_cl4h (latency schedule)",
+                     "kernel_trace_name": "k_solve_lean_cl64w4",  # (the launch that does the bulk of a solve; its stragglers continue under k_solve_lean_cl4h when the chip runs empty)
+                     "kernel_ms": kernel_ms,
                      "algorithmic_flops_per_launch": alg_flops,
                      "flops_per_evaluation": fpe, "evaluations_per_launch": evaluations,
                      "chip_level_achieved": alg_flops * args.steps / elapsed / 1e12 if elapsed > 0 else 0.0,
                      "chip_level_frac": alg_flops * args.steps / elapsed / FP64_PEAK if elapsed > 0 else 0.0,
                      "note": "FP64 vector arithmetic binds this kernel (no MFMA: chains of 3-vector / quaternion products); flops = SURVEY.md section 8(d) "
-                             "formula x fitness evaluations counted on the device; under BIOIK_SCHEDULE_THROUGHPUT a solve is ONE launch of k_solve_lean_cl64w4 (both "
-                             "species of a query on one wavefront), under BIOIK_SCHEDULE_LATENCY one of k_solve_lean_cl4 (a wavefront per species) or, for a batch beyond what the "
-                             "chip holds of its workgroups, k_solve_lean_cl64w4 first and k_solve_lean_cl4 for the stragglers it hands over when the chip runs empty; kernel_ms is the event-bracketed duration of a solve while %d solves "
+                             "formula x fitness evaluations counted on the device; under either schedule a chip-filling solve is a launch of k_solve_lean_cl64w4 (both "
+                             "species of a query on one wavefront) whose stragglers continue under k_solve_lean_cl4h (k_solve_lean_cl4 with two helper wavefronts) when the chip runs empty "
+                             "(round 5; the schedules differ in the threshold); kernel_ms is the event-bracketed duration of a solve -- both launches -- while %d solves "
                              "share the chip, so `frac_per_solve` is per solve and `frac` = `chip_level_frac` is all solves over the wall time; `traffic` = measured HBM "
                              "bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/)" % nfl,
                      "hbm": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,

@@ -85,7 +85,7 @@ tr = os.path.join(g, "prof_" + rnd, rnd + "_kernel_trace.csv")
 pl = os.path.join(g, "prof_bench.log")
 if os.path.exists(tr) and os.path.exists(pl):
     line = json.loads([l for l in open(pl) if l.startswith("{")][-1])
-    kern, k_timed = line["roofline"]["kernel"], line["steps"]
+    kern, k_timed = line["roofline"].get("kernel_trace_name", line["roofline"]["kernel"]), line["steps"]
     rows = sorted((r for r in csv.DictReader(open(tr)) if r["Kernel_Name"].startswith(kern + "(")), key=lambda r: int(r["Start_Timestamp"]))
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows]
     rec = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --timed-only", "kernel": kern, "launches": len(dur),
@@ -94,6 +94,7 @@ if os.path.exists(tr) and os.path.exists(pl):
            "roofline.kernel_ms printed by the profiled process (HIP events around the same launches)": line["roofline"]["kernel_ms"],
            "value printed by the profiled process": line["value"], "batches_in_flight": line["config"]["batches_in_flight"],
            "note": "launches overlap (batches_in_flight of them share the chip), so a launch lasts batches_in_flight x ms_per_step; the launches "
-                   "before the timed region start on an emptier chip and are shorter"}
+                   "before the timed region start on an emptier chip and are shorter.  Round 5: a solve is this launch PLUS the launch of k_solve_lean_cl4h that takes its "
+                   "stragglers over when the chip runs empty -- the events bracket both, the trace figure is this kernel alone"}
     json.dump(rec, open(os.path.join(p, rnd + "_kernel_stats_timed_region.json"), "w"), indent=1)
     print("kernel trace: all %.2f ms, timed %.2f ms, events %.2f ms" % (sum(dur) / len(dur), sum(dur[-k_timed:]) / k_timed, line["roofline"]["kernel_ms"]))
