@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BIOIK_ABI_VERSION 4
+#define BIOIK_ABI_VERSION 5 /* 5 (round 5): bioik_solve_params::islands = 0 means BIOIK_ISLANDS_AUTO (versions up to 4 took 0 as 1); `timeout` counts from the call; no new entry point */
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
