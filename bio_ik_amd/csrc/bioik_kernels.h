@@ -1280,7 +1280,9 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     };
                     auto frame_of = [&](const double* fc, int t) { return f7_load(fc + t * 8); };
                     // goal fitness of the lane's frames `fc` (+ its gene's delta * step): (primary, all goals); x: what joint-value goals read
-                    auto goals_on = [&](const double* fc, int dop, double dstep, const PerturbX& x, double& prim, double& all) {
+                    // (want_all: the sum over the secondary goals is wanted too -- the gradient and the support points; the candidate of round 2 is accepted on
+                    // its PRIMARY fitness alone (:527-538), and its secondary sum, a loop over every gene for a MinimalDisplacementGoal, was computed and dropped)
+                    auto goals_on = [&](const double* fc, int dop, double dstep, const PerturbX& x, double& prim, double& all, bool want_all) {
 #if !defined(BIOIK_NO_POSE_ONLY)
                         if (pb->pose_only) {  // one PoseGoal on one tip and nothing else: the same operations without the goal tables (0 + w² e = w² e)
                             F7 f = frame_of(fc, 0);
@@ -1318,7 +1320,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         acc += nonlink_primary(pb, x, qc);
                         acc += balance_cost(pb, bal, qc);
                         prim = acc;
-                        all = acc + secondary_fitness(pb, x, qc);
+                        all = want_all ? acc + secondary_fitness(pb, x, qc) : acc;
                     };
                     for (int k = gtid; k < n_ops; k += Gw) s_gop[k] = 0.0;
                     const bool odd = gtid & 1;
@@ -1376,7 +1378,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             // what joint-value goals read: the lane's own vector -- in the gradient round the elite with its gene advanced by dp
                             // (computed where it is read, no column), else the shared support point / candidate
                             const PerturbX xq{round == 0 ? el : (round == 2 ? s_x4 : (odd ? s_xp : s_xm)), round == 0 ? my_op : -1, round == 0 ? dp : 0.0};
-                            goals_on(fc0 + ((round == 1 && odd) ? FB : 0), round == 0 ? my_op : -1, round == 0 ? dp : 0.0, xq, vprim, vall);
+                            goals_on(fc0 + ((round == 1 && odd) ? FB : 0), round == 0 ? my_op : -1, round == 0 ? dp : 0.0, xq, vprim, vall, round != 2);
                             PHASE_MARK(PH_MEM_SUPPORT_EVAL);
                             if (round == 0) {
                                 if (gtid == D) s_ex[0] = vprim, s_ex[1] = vall;
