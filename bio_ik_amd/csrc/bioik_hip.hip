@@ -421,6 +421,8 @@ struct SolveSwitches {
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
     bool capture_one_launch = false;  // BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: a call on a stream that is being captured gets a one-launch mapping (round 4's rule)
     int sort_key_drop = 10;     // BIOIK_SOLVE_SORT_KEY_DROP=b (parity suites, 10 ... 52): the pre-selection's sort keys give up b low bits of a fitness, so that the exact path runs often
+    int preselect = 1;          // BIOIK_SOLVE_PRESELECT: 1 (default) = the pre-selection's survivors by selection of the k-th key (select_threshold), 0 = by the sort of all children
+    int tie_test_bits = 0;      // BIOIK_SOLVE_TIE_TEST_BITS=b (parity suites, 0 ... 52): the children's fitness loses b low bits before the selection, so that children tie
     bool two_phase_set = false, two_phase_init = false;
     std::vector<long> two_phase;  // BIOIK_SOLVE_TWO_PHASE: K or K1,K2,... (hand-overs after those steps), "init", 0 = never
     std::string phase_dump;       // BIOIK_PHASE_DUMP (profiling builds)
@@ -452,6 +454,9 @@ static SolveSwitches parse_switches() {
     w.drain_min_steps = geti("BIOIK_SOLVE_DRAIN_MIN_STEPS", 4);
     w.drain_test = geti("BIOIK_SOLVE_DRAIN_TEST", 0);
     w.sort_key_drop = geti("BIOIK_SOLVE_SORT_KEY_DROP", 10);
+    w.preselect = geti("BIOIK_SOLVE_PRESELECT", 1) != 0 ? 1 : 0;
+    w.tie_test_bits = geti("BIOIK_SOLVE_TIE_TEST_BITS", 0);
+    if (w.tie_test_bits < 0 || w.tie_test_bits > 52) w.tie_test_bits = 0;
     w.capture_one_launch = geti("BIOIK_SOLVE_CAPTURE_ONE_LAUNCH", 0) != 0;
     w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
     w.autotune = geti("BIOIK_SOLVE_AUTOTUNE", 1);
@@ -801,6 +806,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.params = d_params;
     a.phase_cycles = nullptr;
     a.sort_key_drop = sw.sort_key_drop;
+    a.preselect = sw.preselect | (sw.tie_test_bits << 8);
     set_deadline(p, sp, stream, a);
 #if defined(BIOIK_PHASE_TIMING)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));

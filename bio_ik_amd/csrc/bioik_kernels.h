@@ -275,6 +275,46 @@ BIOIK_DEV unsigned long long half_min_u64(unsigned long long k) {
     o = p_quad_xor<1>(k), k = o < k ? o : k;
     return k;
 }
+// the least key of a lane group of 32 or 64 lanes (half a wavefront or a whole one), known to all of its lanes
+BIOIK_DEV unsigned long long group_min_u64(unsigned long long k, int G) {
+    if (G >= 64) {
+        const unsigned long long o = p_shfl_xor(k, 32);
+        k = o < k ? o : k;
+    }
+    return half_min_u64(k);
+}
+// The survivors of the pre-selection WITHOUT the sort.  ik_evolution_2.cpp:366-378 scores every child on the secondary goals, sorts the children and keeps a
+// prefix whose length was drawn before the sort: WHICH children survive is a question to the k-th order statistic of the keys, and their order among
+// themselves reaches the result only where two of them tie on their whole fitness (the selection takes the earlier one; solve_body settles those ties
+// where it finds them).  The threshold comes from a bisection of the VALUE range [least key, greatest key]: a round counts the keys <= mid -- a compare,
+// a ballot and a population count per register -- and the search is over as soon as exactly k are, because mid then lies in the gap behind the k-th key.
+// Keys spread like a generation's reach that after about log2(n) + 2 rounds (unique keys: 64 at most), against the log2(n)(log2(n)+1)/2 = 28 / 45 rounds
+// of permutes and compare-exchanges of the network (128 / 512 keys).  Returns the threshold: the survivors are the keys <= it.
+// n_mine: this lane's first n_mine keys belong to children (the rest is padding: +inf); gmask: the lanes of the caller's group inside its wavefront.
+template <int E>
+BIOIK_DEV unsigned long long select_threshold(const unsigned long long (&key)[E], int n_mine, int k, int G, unsigned long long gmask) {
+    unsigned long long lo = ~0ull, nhi = ~0ull;  // (nhi: the complement of the greatest key, so that both ends are minima)
+#pragma unroll
+    for (int i = 0; i < E; i++)
+        if (i < n_mine) lo = key[i] < lo ? key[i] : lo, nhi = ~key[i] < nhi ? ~key[i] : nhi;
+    lo = group_min_u64(lo, G);
+    unsigned long long hi = ~group_min_u64(nhi, G);
+    unsigned long long T = hi;
+    bool done = false;
+    for (;;) {  // (the halves of a wavefront that carries two species search side by side: the loop ends when both have found theirs)
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < E; i++) cnt += p_popc64(p_ballot(key[i] <= mid) & gmask);
+        if (!done) {
+            if (cnt == k) T = mid, done = true;
+            else if (cnt < k) lo = mid + 1ull;
+            else hi = mid;
+        }
+        if (p_ballot(!done) == 0ull) break;
+    }
+    return T;
+}
 // A non-negative double orders like its bit pattern.  The key keeps the upper 54 bits of the pattern and carries the child index (< 1024) in the lower ten:
 // keys order like (fitness, index) wherever two fitness values differ above their lowest ten mantissa bits or not at all.  Pairs that differ ONLY there
 // (relative difference below 2.3e-13) are ordered by index, possibly wrongly -- the caller finds them among the sorted neighbours and sorts exactly then.
@@ -371,6 +411,7 @@ struct SolveArgs {
     // the faster lone step) whatever step it is at, its step count travelling with its state; that launch has step_begin < 0 and reads it there.
     // Which units leave when depends on timing; their results do not (every mapping computes the same trajectory).
     int32_t sort_key_drop = 10;                    // the pre-selection's sort keys give up this many low bits of a fitness for the child index (sort_key)
+    int32_t preselect = 1;                         // bit 0: the pre-selection's survivors by selection (select_threshold) instead of the sort; bits 8...: parity suites -- the parked fitness values lose that many low bits, so that children tie
     unsigned int* resident = nullptr;              // [16][32]: word 32 x of XCD x
     int32_t drain_below = 0, drain_min_steps = 0;  // (wavefronts per XCD)  // (drain_below < 0: test pattern -- unit u leaves after 1 + hash(u) % -drain_below steps)
 };
@@ -436,6 +477,10 @@ struct SpeciesState {
 template <bool LEAN, bool CL = false, bool JOINT = false, bool SLIM = false, int FIXED = 0>
 BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     constexpr bool DENSE = FIXED == 1, HELPED = FIXED == 5, WAVE2 = FIXED == 2 || HELPED, LIN = FIXED == 3, JH = FIXED == 4, HALVES = DENSE || LIN || JH;
+    // The pre-selection's survivors by selection instead of the sort (select_threshold) where a lane holds eight keys -- a wavefront per species, C4's 512 children:
+    // 45 rounds of the network against ~14 of the bisection, +5 % on the 31-joint chain.  With four keys per lane on half a wavefront (the joint walk, C3's 128
+    // children) the 28-round network is the cheaper of the two (measured: -2.5 % with the selection, profiles/r05_preselect_by_selection.log), so those sort.
+    constexpr bool SELECTS = WAVE2;
     static_assert(FIXED != 4 || JOINT, "FIXED = 4 is the joint walk of both species' children (64 lanes, halves, exact FK, secondary goals: k_solve_lean_clj4)");
     static_assert(FIXED == 0 || (SLIM && CL), "the fixed mappings are builds of the computed-children kernel for the 128-register budget");
     uint64_t unit = unit_in;
@@ -709,7 +754,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     group_sync(G);
                 }
                 if (has_sec) {
-                    // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives
+                    // :366-378 pre-selection: children ordered by secondary fitness (stable), a random prefix survives.  Its length (:367) is drawn first -- here
+                    // from the counter RNG, so it is known before the children are scored and a selection can stand in for the sort
+                    {
+                        uint32_t o0, o1;
+                        philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
+                        n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
+                        if constexpr (WAVE2) n_eval = p_uniform(n_eval);  // (a group is a whole wavefront: the count is the same in all its lanes, so it can live in a scalar register)
+                    }
                     bool sorted = false;
                     if constexpr (CL) {
                         // one wavefront (or half of one) per species and four or eight children per lane: lane l scores the children l E ... l E + E - 1 and the
@@ -738,6 +790,65 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 for (int j = 0; j < 4; j++) sf[i0 + j] = gtid * E + i0 + j < lambda ? e[j] : P_INF, sc[i0 + j] = gtid * E + i0 + j;
                             }
                             PHASE_MARK(PH_SELECTION);
+                            // The survivors by selection (select_threshold): which children pass is decided by the k-th least key, not by the order of all of them.
+                            // The keys order like (fitness, index) except among values that differ in the bits the key gave up; only the class of the threshold
+                            // can put a child on the wrong side of it, and only if it lies on both sides: then its exact values must all be the same (as the
+                            // zeros of AvoidJointLimitsGoal for every child inside its free zone are -- the index order is the stable order then), else the sort
+                            // below decides.  The survivors are written in lane order, not in sorted order: a walk does not care, and the selection settles
+                            // ties of the whole fitness by the stable order where it meets them.
+                            if constexpr (SELECTS && E * 64 <= 1024) {
+                                if ((a.preselect & 1) != 0 && (G == 32 || G == 64)) {
+                                    const int drop = a.sort_key_drop, lane = tid & 63;
+                                    const unsigned long long gmask = G >= 64 ? ~0ull : 0xffffffffull << (lane & 32);
+                                    unsigned long long sk[E];
+#pragma unroll
+                                    for (int i = 0; i < E; i++) sk[i] = sort_key(sf[i], sc[i], drop), s_sec[gtid * E + i] = sf[i];
+                                    const unsigned long long T = select_threshold<E>(sk, lambda - gtid * E, n_eval, G, gmask);
+                                    bool in_s = false, in_n = false;
+#pragma unroll
+                                    for (int i = 0; i < E; i++) {
+                                        const bool cls = ((sk[i] ^ T) >> drop) == 0ull;
+                                        in_s = in_s || (cls && sk[i] <= T), in_n = in_n || (cls && sk[i] > T);
+                                    }
+                                    const unsigned long long any_s = p_ballot(in_s) & gmask, any_n = p_ballot(in_n) & gmask;  // (both asked by every lane: no short circuit)
+                                    const bool straddle = any_s != 0ull && any_n != 0ull;
+                                    bool bad = false;
+                                    if (p_ballot(straddle) != 0ull) {
+                                        // (any member's value through a word of the group's scratch: if all are the same it does not matter whose arrives)
+                                        unsigned long long mine = 0ull;
+                                        bool have = false, mixed = false;
+#pragma unroll
+                                        for (int i = 0; i < E; i++) {
+                                            if (((sk[i] ^ T) >> drop) != 0ull) continue;
+                                            unsigned long long v;
+                                            const double e = s_sec[gtid * E + i];
+                                            __builtin_memcpy(&v, &e, 8);
+                                            if (!have) mine = v, have = true;
+                                            else mixed = mixed || v != mine;
+                                        }
+                                        if (straddle && have) __builtin_memcpy(&s_bc[0], &mine, 8);
+                                        group_sync(G);
+                                        unsigned long long ref;
+                                        __builtin_memcpy(&ref, &s_bc[0], 8);
+                                        bad = straddle && have && (mixed || mine != ref);
+                                        group_sync(G);
+                                    }
+                                    if (p_ballot(bad) == 0ull) {  // (the halves of a wavefront decide together: one path through the code)
+                                        const unsigned long long below = (1ull << lane) - 1ull;
+                                        int base = 0;
+#pragma unroll
+                                        for (int i = 0; i < E; i++) {
+                                            const bool sv = sk[i] <= T;
+                                            const unsigned long long b = p_ballot(sv) & gmask;
+                                            if (sv) s_order[base + p_popc64(b & below)] = sc[i];
+                                            base += p_popc64(b);
+                                        }
+                                        group_sync(G);
+                                        sorted = true;
+                                        return;
+                                    }
+                                }
+                            }
                             // Keys first (sort_key: one compare and two dwords per exchange).  The exact values wait in LDS for the check behind the sort: sorted
                             // neighbours whose keys agree above the index bits are equal (then the index order is the stable order) or differ in their lowest
                             // ten mantissa bits only -- in that case, which a generation meets about once in a billion, the pairs are sorted again, exactly.
@@ -840,10 +951,6 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         }
                     }
                     PHASE_MARK(PH_MEMETICS);
-                    uint32_t o0, o1;
-                    philox2x32_10(key, rng_ctr0(0, 0), rng_ctr1(gctr, (uint32_t)S.id, RNG_PRESELECT), o0, o1);
-                    n_eval = (int)(o0 % (uint32_t)(lambda - 1)) + 1;
-                    if constexpr (WAVE2) n_eval = p_uniform(n_eval);  // (a group is a whole wavefront: the count is the same in all its lanes, so it can live in a scalar register)
                     PHASE_MARK(PH_PRESELECT);
                 }
                 // genotype -> phenotype -> fitness (:391-407): lane r of the group scores the child at sorted position r
@@ -853,6 +960,21 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 // gene before its renormalisation (:299 vs :320-324), so those winners are re-derived from the RNG
                 const bool stored = !columnless && n_cols * G >= lambda && (LEAN || pb->n_quat == 0);
                 auto offer = [&](double f, int pos) { top2_insert(b1f, b1p, b2f, b2p, f, pos); };  // the lane's best two so far
+                // (parity suites, SolveArgs::preselect: the parked fitness values made coarse where the walks are over, so that children tie and the tie order is exercised)
+                auto coarse_parked = [&](int gt) {
+                    if constexpr (SLIM && CL) {
+                        if (const int tie_bits = a.preselect >> 8) {
+                            double* const s_fq = gbase + L.fitp;
+                            for (int r = gt; r < n_eval; r += G) {
+                                unsigned long long v;
+                                __builtin_memcpy(&v, &s_fq[r], 8);
+                                v &= ~((1ull << tie_bits) - 1ull);
+                                __builtin_memcpy(&s_fq[r], &v, 8);
+                            }
+                            group_sync(G);
+                        }
+                    }
+                };
                 if (!JOINT && stored && child_pairs && exact) {
                     // two children per trip: columns j and j+1 of this lane (an odd tail repeats the first child and drops it)
                     for (int r = gtid, j = 0; r < n_eval; r += 2 * G, j += 2) {
@@ -1006,6 +1128,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         {
                             BIOIK_LANE_SCOPE;
                             const double* const s_fit2 = gbase + L.fitp;
+                            coarse_parked(gtid);
                             for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);
                         }
                     } else if constexpr (SLIM) {
@@ -1056,6 +1179,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         if constexpr (!DENSE) {  // (DENSE: the selection below reads the parked values itself, as keys)
                             BIOIK_LANE_SCOPE;
                             const double* const s_fit2 = gbase + L.fitp;
+                            coarse_parked(gtid);
                             for (int r = gtid; r < n_eval; r += G) offer(s_fit2[r], r + 2);  // (its own entries: a lane's LDS accesses stay in program order)
                         }
                     } else
@@ -1099,6 +1223,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 BIOIK_LANE_SCOPE;
                 if constexpr (SLIM) S = species_load(rank_now()), popS = s_pop + S.slot * SP, cb = popS + S.cur * BF, p0g = cb, p0d = cb + M, p1d = cb + 3 * M;
                 const uint32_t ctr1w = SLIM ? rng_ctr1((uint32_t)step * 16u + (uint32_t)gen, (uint32_t)S.id, RNG_REPRODUCE) : ctr1;  // (the winners' stream: not carried through the walks under SLIM)
+                if constexpr (DENSE || JH) coarse_parked(gtid);  // (the other kernels: in front of their lanes' offers)
                 // (the joint walk has reduced over the whole wavefront already; under SLIM it parks its values like the other walks, and the reduction
                 // inside the half stands here, between the lanes' reads of the species record above and its update below)
                 if constexpr (DENSE || JH) {
@@ -1136,6 +1261,67 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                 PHASE_MARK(PH_SEL_TOP2);
                 top2_xwave(b1f, b1p, b2f, b2p, s_red, gtid, G);  // now the two best children of the whole generation
                 PHASE_MARK(PH_SEL_XWAVE);
+                if constexpr (SELECTS) {
+                    // The reference's selection takes, of two children with the same fitness, the one the pre-selection's stable sort put first, and its swap
+                    // of the first winner with parent 0 puts that parent at the winner's POSITION for the second pass (:410-423).  The survivors of
+                    // select_threshold stand in lane order, so a position does not say which came first.  It matters where a winner's fitness is shared by
+                    // another child, or the runner-up's by parent 0 -- children with the same genes, which a generation all but never has --: then the
+                    // candidates' secondary fitness is computed again, the stable order (secondary fitness, child index) picks among them, and the two
+                    // winners change places in the list if their positions say the opposite of it.  (After a sort the positions say the same: no word needed
+                    // on which of the two it was.)
+                    if (has_sec) {
+                        double* const s_fv = gbase + L.fitp;
+                        int t1 = 0, t2 = 0;
+                        for (int r = gtid; r < n_eval; r += G) {
+                            const double v = s_fv[r];
+                            t1 += v == b1f ? 1 : 0, t2 += v == b2f ? 1 : 0;
+                        }
+                        const unsigned long long gm = G >= 64 ? ~0ull : 0xffffffffull << (tid & 32);
+                        const unsigned long long o1 = p_ballot(t1 > 0) & gm, o2 = p_ballot(t2 > 0) & gm;
+                        const bool tie = (p_ballot(t1 > 1 || t2 > 1) & gm) != 0ull || (o1 & (o1 - 1ull)) != 0ull || (o2 & (o2 - 1ull)) != 0ull || (b2p != 0x7fffffff && b2f == S.pf0);
+                        if (p_ballot(tie) != 0ull) {  // (both halves of a wavefront take the path when one of them must)
+                            // the position of the candidate with this fitness that the stable order puts first, its secondary fitness and its child index
+                            auto stable_first = [&](double fwant, int skip, double& wf, int& wc) -> int {
+                                double bs = P_INF;
+                                int bc = 0x7fffffff, br = 0x7fffffff;
+                                for (int r = gtid; r < n_eval; r += G) {
+                                    if (!(s_fv[r] == fwant) || r == skip) continue;
+                                    const int c = s_order[r];
+                                    const double sec = secondary_fitness<true>(pb, make_child_x(pb, key, ctr1w, (uint32_t)c + 2u, p0g, p0d, p1d), qc);
+                                    if (sec < bs || (sec == bs && c < bc)) bs = sec, bc = c, br = r;
+                                }
+                                double w2f = P_INF;
+                                int w2c = 0x7fffffff;
+                                wf = bs, wc = bc;
+                                top2_wave(wf, wc, w2f, w2c, G);  // (wf, wc): the least (secondary fitness, child) of the group
+                                const unsigned long long own = p_ballot(bc == wc && bc != 0x7fffffff) & gm;
+                                const int src = own != 0ull ? __builtin_ctzll(own) : (tid & 63);
+                                const int rr = p_shfl(br, src);
+                                return own != 0ull ? rr : 0x7fffffff;
+                            };
+                            double e1, e2;
+                            int c1, c2;
+                            const int r1 = stable_first(b1f, -1, e1, c1);
+                            const int r2 = stable_first(b2f, r1, e2, c2);
+                            if (tie && r1 != 0x7fffffff) {
+                                b1p = r1 + 2;
+                                if (b2p != 0x7fffffff && r2 != 0x7fffffff) {
+                                    b2p = r2 + 2;
+                                    const bool first_is_first = e1 < e2 || (e1 == e2 && c1 < c2);
+                                    if (first_is_first != (r1 < r2)) {  // the two change places: their positions then say what the stable order says
+                                        if (gtid == 0) {
+                                            const int ca = s_order[r1], cb2 = s_order[r2];
+                                            const double fa = s_fv[r1], fb = s_fv[r2];
+                                            s_order[r1] = cb2, s_order[r2] = ca, s_fv[r1] = fb, s_fv[r2] = fa;
+                                        }
+                                        b1p = r2 + 2, b2p = r1 + 2;
+                                    }
+                                }
+                            }
+                            group_sync(G);
+                        }
+                    }
+                }
                 Cand first{S.pf0, 0, 0};
                 if (cand_better(S.pf1, 1, first.f, first.pos)) first = Cand{S.pf1, 1, 1};
                 if (cand_better(b1f, b1p, first.f, first.pos)) first = Cand{b1f, b1p, b1p};

@@ -492,6 +492,33 @@ def test_selection_ties_are_decided_by_position(monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_preselection_by_selection_gives_what_the_sort_gives(gpus, oracles, templates, monkeypatch):
+    """The pre-selection's survivors by selection of the k-th least key (select_threshold: the kernels with a wavefront per species, k_solve_lean_cl4 / cl4h) against the sort of all
+    children (BIOIK_SOLVE_PRESELECT=0): the oracle's trajectories both ways, and whole batches of the two-armed problem and of the 31-joint chain bit for bit
+    the same -- also with the children's fitness made coarse (BIOIK_SOLVE_TIE_TEST_BITS, a test switch), when most generations have several best children and
+    the reference's stable order among them is what decides (ik_evolution_2.cpp:366-378, 410-423)"""
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BIOIK_SOLVE_PRESELECT", mode)
+        pc.trajectory(gpus["c4"], oracles["c4"], templates["c4"], n=4, pop=512, steps_list=(3,))
+        pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=8, pop=128, steps_list=(4,))
+        pc.trajectory(gpus["c3"], oracles["c3"], templates["c3"], n=300, pop=100, steps_list=(2,))
+    for name, n, pop, steps, kw in (("c4", 2048, 512, 8, {}), ("c4", 3, 512, 6, {"mode": "bio2"}), ("c4", 700, 512, 10, {"mode": "bio2"}), ("c3", 4096, 128, 24, {})):
+        h, t = gpus[name], templates[name]
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=77)
+        p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=5, **kw)
+        out = {}
+        for bits in ("0", "44", "50"):
+            monkeypatch.setenv("BIOIK_SOLVE_TIE_TEST_BITS", bits)
+            for mode in ("0", "1"):
+                monkeypatch.setenv("BIOIK_SOLVE_PRESELECT", mode)
+                out[bits, mode] = h.solve_batch(p, seeds, params)
+            assert all(np.array_equal(x, y) for x, y in zip(out[bits, "0"], out[bits, "1"])), (name, n, bits)
+        if name == "c4":  # (the joint walk of the two-armed problem -- four keys per lane on half a wavefront -- keeps the sort: the cheaper of the two there)
+            assert not np.array_equal(out["0", "1"][0], out["50", "1"][0])  # (the coarse values did take the search elsewhere)
+    monkeypatch.delenv("BIOIK_SOLVE_TIE_TEST_BITS")
+    monkeypatch.delenv("BIOIK_SOLVE_PRESELECT")
+
+
 def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
     """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
     residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""

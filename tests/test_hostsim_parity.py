@@ -492,6 +492,70 @@ def test_preselection_sort_keys_and_the_exact_path_behind_them(sims, oracles, te
             monkeypatch.delenv(k)
 
 
+def test_preselection_by_selection_and_ties_of_the_whole_fitness(sims, oracles, templates, monkeypatch):
+    """The kernels of the 128-register budget find the pre-selection's survivors by SELECTION (select_threshold: a bisection for the k-th least key, no sort)
+    and write them in lane order; the reference's stable order among them matters only where two children tie on their whole fitness, and is restored there
+    from the candidates' secondary fitness.  (i) Both ways give the oracle's trajectories bit for bit -- 512 and 300 children on a wavefront per species
+    (eight per lane, padding), the helped kernel, keys that give up 36 bits (classes of values on both sides of the threshold); the joint walk of the two-armed
+    problem (four keys per lane on half a wavefront) keeps the sort, which is the cheaper of the two there.  (ii) With the children's fitness made coarse (BIOIK_SOLVE_TIE_TEST_BITS: a test switch; most generations then have several best
+    children) the selection gives what the sort gives, bit for bit: the sort's positions ARE the stable order."""
+    c3map = {"BIOIK_SOLVE_THREADS": "64", "BIOIK_SOLVE_SPECIES_PARALLEL": "1", "BIOIK_SOLVE_COLUMNLESS": "2"}
+
+    def runs(check):
+        check("c4", 1, 512, 2, {})
+        check("c4", 1, 512, 2, {"BIOIK_SOLVE_HELPED": "0"})
+        check("c4", 1, 300, 2, {"BIOIK_SOLVE_HELPED": "0", "BIOIK_SOLVE_FOUR_WAVES": "1"})  # (the 128-register build for fewer children than the launcher gives it)
+        check("c3", 2, 128, 2, c3map)
+        check("c3", 1, 100, 2, c3map)
+
+    def against_oracle(name, n, pop, steps, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pc.trajectory(sims[name], oracles[name], templates[name], n=n, pop=pop, steps_list=(steps,))
+        for k in env:
+            monkeypatch.delenv(k)
+    for mode, drop in (("0", "10"), ("1", "10"), ("1", "36")):
+        monkeypatch.setenv("BIOIK_SOLVE_PRESELECT", mode)
+        monkeypatch.setenv("BIOIK_SOLVE_SORT_KEY_DROP", drop)
+        runs(against_oracle)
+    monkeypatch.delenv("BIOIK_SOLVE_SORT_KEY_DROP")
+    changed = []
+
+    def sort_against_selection(name, n, pop, steps, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h, t = sims[name], templates[name]
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, n, seed=7)
+        p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=11, mode="bio2")  # (no memetic phase: it is the children that improve an elite)
+        out = {}
+        for bits in ("0", "46", "50"):
+            monkeypatch.setenv("BIOIK_SOLVE_TIE_TEST_BITS", bits)
+            for mode in ("0", "1"):
+                monkeypatch.setenv("BIOIK_SOLVE_PRESELECT", mode)
+                out[bits, mode] = h.solve_batch(p, seeds, params)
+            for a, b in zip(out[bits, "0"], out[bits, "1"]):
+                assert np.array_equal(a, b), (name, pop, bits)
+        changed.append(not np.array_equal(out["0", "1"][0], out["50", "1"][0]))  # (the coarse values took the search elsewhere: ties were there to be settled)
+        monkeypatch.delenv("BIOIK_SOLVE_TIE_TEST_BITS")
+        for k in env:
+            monkeypatch.delenv(k)
+    runs(sort_against_selection)
+    assert all(changed)
+    # (a runner-up that ties with parent 0: the reference's swap has put that parent at the first winner's position, so the two winners' places in the list decide --
+    # six queries over five steps meet the case; without the selection's word on it five of thirty such runs differ)
+    monkeypatch.setenv("BIOIK_SOLVE_HELPED", "0")
+    h, t = sims["c4"], templates["c4"]
+    for bits, mode in (("48", "bio2"), ("50", "bio2_memetic")):
+        seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 6, seed=int(bits) + 512)
+        p = abi.default_solve_params(population=512, max_steps=5, random_seed=int(bits), mode=mode)
+        monkeypatch.setenv("BIOIK_SOLVE_TIE_TEST_BITS", bits)
+        out = []
+        for m in ("0", "1"):
+            monkeypatch.setenv("BIOIK_SOLVE_PRESELECT", m)
+            out.append(h.solve_batch(p, seeds, params))
+        assert all(np.array_equal(a, b) for a, b in zip(*out)), (bits, mode)
+
+
 def test_units_that_change_launch_at_their_own_step(sims, oracles, templates, monkeypatch):
     """SolveArgs::resident: the throughput schedule's stragglers leave for the launch with the faster lone step when the chip runs empty -- every
     unit from whatever step it is at, its step count travelling with its state.  Which unit leaves when is a matter of timing on the device; here

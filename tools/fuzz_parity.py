@@ -84,6 +84,8 @@ def main():
             env["BIOIK_SOLVE_HELPED"] = "0"
         if rng.random() < 0.15:  # the pre-selection's sort keys give up so many bits that its exact path runs in most generations (round 4)
             env["BIOIK_SOLVE_SORT_KEY_DROP"] = str(rng.choice(["30", "44", "51"]))
+        if rng.random() < 0.3:  # round 5: the kernels of the 128-register budget SELECT the pre-selection's survivors; a third of the draws keep the sort of all children
+            env["BIOIK_SOLVE_PRESELECT"] = "0"
         kw = {"no_wipeout": int(rng.random() < 0.2), "schedule": int(rng.random() < 0.25)}  # (schedule: BIOIK_SCHEDULE_THROUGHPUT where its mapping exists)
         if islands > 1 and rng.random() < 0.5:
             kw["island_sync"] = 1  # (round 4: the islands of a query stop once one of them has passed)
