@@ -285,51 +285,97 @@ BIOIK_CALL double goal_eval_link_rare(int type, const lds_f64* P, F7 fb) {
 // x: any "one value per op" accessor (an LDS vector / column, or a child computed where it is read)
 template <class XA>
 BIOIK_DEV double goal_eval_joint_set_x(ProbPtr pb, int type, int var_op, int var_seed, double p0, const XA& x, const lds_f64* seed) {
-    const int n_ops = pb->n_ops;
+    // The reference's sums run over the ACTIVE VARIABLES -- the genes in their order.  That is the order of the ops wherever the ops meet the genes in it
+    // (DevProblem::genes_follow_ops: every problem whose goals name no variable of their own); a JointVariableGoal puts its variable in front of the
+    // chains' (problem.cpp:139-162), and the terms are then added in that order: the same terms, another rounding.
+    const bool by_op = pb->genes_follow_ops != 0;
+    const int cnt = by_op ? pb->n_ops : pb->D;
     switch (type) {
         case G_AVOID_JOINT_LIMITS: {  // :387-401
             double sum = 0.0;
-            for (int k = 0; k < n_ops; k++)
+            for (int i = 0; i < cnt; i++) {
+                const int k = by_op ? i : pb->op_of_gene[i];
                 if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
                     double d = x(k) - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
                     d = fmax(0.0, fabs(d) * 2.0 - pb->ops[k].span * 0.5);
                     d *= pb->ops[k].vw;
                     sum += d * d;
                 }
+            }
             return sum;
         }
         case G_CENTER_JOINTS: {  // :412-425
             double sum = 0.0;
-            for (int k = 0; k < n_ops; k++)
+            for (int i = 0; i < cnt; i++) {
+                const int k = by_op ? i : pb->op_of_gene[i];
                 if (pb->ops[k].gene >= 0 && !pb->ops[k].unbounded) {
                     double d = x(k) - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
                     d *= pb->ops[k].vw;
                     sum += d * d;
                 }
+            }
             return sum;
         }
         case G_REGULARIZATION: {  // :435-444
             double sum = 0.0;
-            for (int k = 0; k < n_ops; k++)
+            for (int i = 0; i < cnt; i++) {
+                const int k = by_op ? i : pb->op_of_gene[i];
                 if (pb->ops[k].gene >= 0) {
                     double d = x(k) - seed[pb->ops[k].var];
                     sum += d * d;
                 }
+            }
             return sum;
         }
         case G_MINIMAL_DISPLACEMENT: {  // :455-465
             double sum = 0.0;
-            for (int k = 0; k < n_ops; k++)
+            for (int i = 0; i < cnt; i++) {
+                const int k = by_op ? i : pb->op_of_gene[i];
                 if (pb->ops[k].gene >= 0) {
                     double d = x(k) - seed[pb->ops[k].var];
                     d *= pb->ops[k].vw;
                     sum += d * d;
                 }
+            }
             return sum;
         }
         case G_JOINT_VARIABLE: {  // :494-498 + goal.h:70-77
             double v = var_op >= 0 ? x(var_op) : seed[var_seed];
             double d = p0 - v;
+            return d * d;
+        }
+    }
+    return 0.0;
+}
+
+// One op's term of the sums above (AvoidJointLimits, CenterJoints, Regularization, MinimalDisplacement): the operations of goal_eval_joint_set_x on the value
+// xv of op k; 0 for an op the goal passes over -- `sum += 0` leaves a non-negative sum as it is.  The memetic phase's line search evaluates these goals on
+// vectors that all of its lanes share, so lane k computes the term of op k once and every lane adds the terms up in their order (solve_body).
+BIOIK_DEV bool joint_set_is_sum(int type) { return type == G_AVOID_JOINT_LIMITS || type == G_CENTER_JOINTS || type == G_REGULARIZATION || type == G_MINIMAL_DISPLACEMENT; }
+template <class PB>
+BIOIK_DEV double joint_set_term(PB pb, int type, int k, double xv, const double* seed) {
+    if (pb->ops[k].gene < 0) return 0.0;
+    switch (type) {
+        case G_AVOID_JOINT_LIMITS: {
+            if (pb->ops[k].unbounded) return 0.0;
+            double d = xv - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
+            d = fmax(0.0, fabs(d) * 2.0 - pb->ops[k].span * 0.5);
+            d *= pb->ops[k].vw;
+            return d * d;
+        }
+        case G_CENTER_JOINTS: {
+            if (pb->ops[k].unbounded) return 0.0;
+            double d = xv - (pb->ops[k].vmin + pb->ops[k].vmax) * 0.5;
+            d *= pb->ops[k].vw;
+            return d * d;
+        }
+        case G_REGULARIZATION: {
+            const double d = xv - seed[pb->ops[k].var];
+            return d * d;
+        }
+        case G_MINIMAL_DISPLACEMENT: {
+            double d = xv - seed[pb->ops[k].var];
+            d *= pb->ops[k].vw;
             return d * d;
         }
     }
@@ -1338,6 +1384,7 @@ struct PerturbX {
     const double* el;
     int op;
     double step;
+    const double* el2 = nullptr;  // (the line search's second support point, where the lanes share the terms of both: solve_body's secondary_shared)
     BIOIK_DEV double operator()(int k) const { return k == op ? el[k] + step : el[k]; }
 };
 

@@ -763,9 +763,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
     const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
                           dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
-    // (not on a stream that is being captured: a hipGraph of a 4096-query solve in TWO launches -- this hand-over or the one after a fixed step -- is right on
-    // its first replay and wrong (unit 0 continued from a state nobody wrote) or aborting from its second on, whatever the resident words do; eager calls, back
-    // to back on one stream or not, are right; unexplained, DESIGN.md section 8 -- so captured calls get a one-launch mapping, which replays correctly)
+    // (BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: round 4's rule -- a call on a stream that is being captured gets a one-launch mapping.  The replay defect it worked around
+    // was the runtime's memset NODE in front of the kernels, not the hand-over; the library fills its words with a kernel of its own now
+    // and captured calls take the same mapping as eager ones)
     const bool capturing = sw.capture_one_launch && be_stream_capturing(stream);
     const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= (uint64_t)(sp.islands <= 2 ? sw.drain_min_units : 3072) * kCus / 256 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
                                !sw.two_phase_set && !capturing;

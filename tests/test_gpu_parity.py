@@ -519,6 +519,30 @@ def test_preselection_by_selection_gives_what_the_sort_gives(gpus, oracles, temp
     monkeypatch.delenv("BIOIK_SOLVE_PRESELECT")
 
 
+def test_secondary_goals_of_every_kind_in_whole_solves(templates):
+    """Five secondary goals at once -- MinimalDisplacementGoal, AvoidJointLimitsGoal, CenterJointsGoal, a RegularizationGoal made secondary (sums over the joint
+    values: the lanes of the line search share their terms, solve_body's secondary_shared) and a JointVariableGoal between them, which also puts its variable
+    in front of the chains' so that the genes do NOT follow the ops (the sums then run in gene order, as the reference's do: goal_eval_joint_set_x) --: the
+    oracle's trajectories bit for bit on the seven-joint arm and on both arms with the torso, and the same without the JointVariableGoal (the lean kernels)"""
+    from bio_ik_amd import AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, MinimalDisplacementGoal, PoseGoal, RegularizationGoal
+    from bio_ik_amd.solver import HipSolver
+    model = templates["c2"].model
+    reg = RegularizationGoal(weight=0.6)
+    reg.secondary_ = True
+    sec = [MinimalDisplacementGoal(weight=0.7), AvoidJointLimitsGoal(weight=0.3), JointVariableGoal("r_elbow_flex_joint", -1.0, weight=0.5, secondary=True),
+           CenterJointsGoal(weight=0.2), reg]
+    for goals in (sec, [g for g in sec if not isinstance(g, JointVariableGoal)]):
+        t = ProblemTemplate(model, "right_arm", [PoseGoal("r_wrist_roll_link")] + goals)
+        h, o = HipSolver(t), orc.Oracle(t)
+        pc.function_level(h, o, model, np.random.default_rng(5), n=500, exact_bits=True)
+        pc.trajectory(h, o, t, n=24, pop=16, steps_list=(6,))
+        pc.trajectory(h, o, t, n=8, pop=128, steps_list=(4,))
+        pc.trajectory(h, o, t, n=8, pop=40, steps_list=(5,), fk_mode=abi.FK_LINEAR)
+        pc.trajectory(h, o, t, n=8, pop=16, steps_list=(6,), mode="bio2_memetic_l")
+        t2 = ProblemTemplate(model, "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link")] + goals)
+        pc.trajectory(HipSolver(t2), orc.Oracle(t2), t2, n=16, pop=128, steps_list=(4,))
+
+
 def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
     """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
     residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""

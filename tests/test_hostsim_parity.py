@@ -172,6 +172,28 @@ def test_edge_cases(sims, oracles, templates):
 
 
 
+def test_secondary_goals_of_every_kind_in_whole_solves(hostsim_lib, templates):
+    """Whole solves with five secondary goals at once -- MinimalDisplacementGoal, AvoidJointLimitsGoal, CenterJointsGoal and a RegularizationGoal made secondary
+    (sums over the joint values, whose terms the lanes of the line search share: solve_body's secondary_shared) and, between them in the goals' order, a
+    JointVariableGoal (evaluated lane by lane) -- on the seven-joint arm and on both arms with the torso: the oracle's trajectories bit for bit, pre-selection
+    and memetic phase included, exact and linearised phenotypes, the quadratic and the linear line search"""
+    from bio_ik_amd import AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, MinimalDisplacementGoal, RegularizationGoal
+    model = templates["c2"].model
+    reg = RegularizationGoal(weight=0.6)
+    reg.secondary_ = True
+    sec = [MinimalDisplacementGoal(weight=0.7), AvoidJointLimitsGoal(weight=0.3), JointVariableGoal("r_elbow_flex_joint", -1.0, weight=0.5, secondary=True),
+           CenterJointsGoal(weight=0.2), reg]
+    t = ProblemTemplate(model, "right_arm", [PoseGoal("r_wrist_roll_link")] + sec)
+    h, o = HipSolver(t, lib=hostsim_lib), orc.Oracle(t)
+    pc.trajectory(h, o, t, n=2, pop=16, steps_list=(3,))
+    pc.trajectory(h, o, t, n=1, pop=128, steps_list=(2,))
+    pc.trajectory(h, o, t, n=1, pop=40, steps_list=(2,), fk_mode=abi.FK_LINEAR)
+    pc.trajectory(h, o, t, n=1, pop=16, steps_list=(3,), mode="bio2_memetic_l")
+    t2 = ProblemTemplate(model, "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link")] + sec)
+    h2, o2 = HipSolver(t2, lib=hostsim_lib), orc.Oracle(t2)
+    pc.trajectory(h2, o2, t2, n=2, pop=128, steps_list=(2,))
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal

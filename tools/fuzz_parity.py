@@ -10,7 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, PositionGoal, ProblemTemplate, abi, pr2_like, snake  # noqa: E402
+from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, MinimalDisplacementGoal, PoseGoal, PositionGoal, ProblemTemplate, abi, pr2_like,  # noqa: E402
+                        snake)
 from bio_ik_amd.solver import HipSolver  # noqa: E402
 from bio_ik_amd.workload import make_queries  # noqa: E402
 from conftest import mimic_robot, mobile_robot  # noqa: E402
@@ -23,6 +24,10 @@ def templates():
         "c2": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link")]),
         "c2+pos": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), PositionGoal("r_elbow_flex_link", weight=0.1)]),
         "c3": ProblemTemplate(pr2, "all", [PoseGoal("r_wrist_roll_link"), PoseGoal("l_wrist_roll_link"), MinimalDisplacementGoal()]),
+        # (round 5: several secondary goals at once; the JointVariableGoal puts its variable in front of the chain's, so the genes do not follow the ops)
+        "c2+sec": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), MinimalDisplacementGoal(weight=0.7), AvoidJointLimitsGoal(weight=0.3),
+                                                     JointVariableGoal("r_elbow_flex_joint", -1.0, weight=0.5, secondary=True), CenterJointsGoal(weight=0.2)]),
+        "c2+sec2": ProblemTemplate(pr2, "right_arm", [PoseGoal("r_wrist_roll_link"), MinimalDisplacementGoal(weight=0.7), AvoidJointLimitsGoal(weight=0.3), CenterJointsGoal(weight=0.2)]),
         "c4": ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]),
         "snake12": ProblemTemplate(snake(12), "snake", [PoseGoal("tip")]),
         "mimic": ProblemTemplate(mimic_robot(), "arm", [PoseGoal("tool"), MinimalDisplacementGoal(weight=0.5)]),
