@@ -510,13 +510,15 @@ BIOIK_DEV double goal_eval(ProbPtr pb, int type, int var_op, int var_seed, const
 }
 
 // Σ weight² · e over the primary link goals of one tip (problem.cpp:244-257, grouped by tip)
+// (sum: the fitness so far.  The reference adds goal after goal to ONE running sum (problem.cpp:244-257); a tip's goals continue the caller's sum instead of
+// forming one of their own, so that (s + a) + b is what is computed, not s + (a + b) -- the same for every evaluation path of the device, and the reference's
+// bits wherever the goals are listed in the order the walk completes their tips, gene-only goals behind them)
 template <class XA>
-BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XA& x, const QueryCtx& qc) {
+BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XA& x, const QueryCtx& qc, double sum) {
 #if !defined(BIOIK_NO_POSE_ONLY)
-    // the usual tip: one PoseGoal (DevTip::pose_off).  0 + w² e = w² e: the sum below without the goal table's dependent scalar loads
-    if (pb->tips[t].pose_off >= 0) return pose_goal_cost(qc.par + pb->tips[t].pose_off, f) * pb->tips[t].pose_weight_sq;
+    // the usual tip: one PoseGoal (DevTip::pose_off): the sum below without the goal table's dependent scalar loads
+    if (pb->tips[t].pose_off >= 0) return sum + pose_goal_cost(qc.par + pb->tips[t].pose_off, f) * pb->tips[t].pose_weight_sq;
 #endif
-    double sum = 0.0;
     const int g0 = pb->tips[t].goal_first, g1 = g0 + pb->tips[t].goal_count;
     for (int g = g0; g < g1; g++)
         sum += goal_eval<false, XA>(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, f, x, qc) *
@@ -525,8 +527,7 @@ BIOIK_DEV double tip_goals(ProbPtr pb, int t, const F7& f, const XA& x, const Qu
 }
 // primary goals that read no link
 template <class XA>
-BIOIK_DEV double nonlink_primary(ProbPtr pb, const XA& x, const QueryCtx& qc) {
-    double sum = 0.0;
+BIOIK_DEV double nonlink_primary(ProbPtr pb, const XA& x, const QueryCtx& qc, double sum) {
     const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     for (int g = pb->n_link_primary; g < pb->n_primary; g++)
         sum += goal_eval<false, XA>(pb, pb->primary[g].type, pb->primary[g].var_op, pb->primary[g].var_seed, qc.par + pb->primary[g].param_off, zero, x, qc) *
@@ -798,10 +799,10 @@ BIOIK_DEV double eval_exact_primary(PB pb, const XA& x, const QueryCtx& qc, doub
     double sum = 0.0;
     V3 bal = v3(0.0, 0.0, 0.0);
     fk_walk(pb, x, slots, nullptr, [&](int t, const F7& f) {
-        sum += tip_goals(pb, t, f, x, qc);
+        sum = tip_goals(pb, t, f, x, qc, sum);
         balance_tip(pb, t, f, bal);
     }, prefix);
-    sum += nonlink_primary(pb, x, qc);
+    sum = nonlink_primary(pb, x, qc, sum);
     sum += balance_cost(pb, bal, qc);
     return sum;
 }
@@ -949,7 +950,7 @@ BIOIK_DEV void eval_exact_primary_n(PB pb, const XA (&x)[N], const QueryCtx& qc,
     }, prefix);
     if constexpr (!LINKS_ONLY) {
 #pragma unroll
-        for (int j = 0; j < N; j++) out[j] += nonlink_primary(pb, x[j], qc), out[j] += balance_cost(pb, bal[j], qc);
+        for (int j = 0; j < N; j++) out[j] = nonlink_primary(pb, x[j], qc, out[j]), out[j] += balance_cost(pb, bal[j], qc);
     }
 }
 
@@ -1011,10 +1012,10 @@ BIOIK_DEV double eval_linear_primary(PB pb, const XA& x, const QueryCtx& qc, con
     V3 bal = v3(0.0, 0.0, 0.0);
     for (int t = 0; t < T; t++) {
         const F7 f = linear_tip(pb, t, x, lm);
-        sum += tip_goals(pb, t, f, x, qc);
+        sum = tip_goals(pb, t, f, x, qc, sum);
         balance_tip(pb, t, f, bal);
     }
-    sum += nonlink_primary(pb, x, qc);
+    sum = nonlink_primary(pb, x, qc, sum);
     sum += balance_cost(pb, bal, qc);
     return sum;
 }
@@ -1541,7 +1542,7 @@ BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* sl
     double sum = 0.0;
     V3 bal = v3(0.0, 0.0, 0.0);
     fk_walk<COOP>(pb, x, slots, nullptr, [&](int t, const F7& f) {
-        sum += tip_goals(pb, t, f, x, qc);
+        sum = tip_goals(pb, t, f, x, qc, sum);
         balance_tip(pb, t, f, bal);
 #if !defined(BIOIK_NO_POSE_ONLY)
         if (do_check && pb->tips[t].pose_off >= 0) {
@@ -1553,7 +1554,7 @@ BIOIK_NOINLINE FitCheck exact_fitness_check(PB pb, XV x, QueryCtx qc, double* sl
             for (int g = g0; g < g1; g++) good = check_goal(pb, g, f, x, qc, dpos, drot, dtwist) && good;
         }
     }, prefix);
-    sum += nonlink_primary(pb, x, qc);
+    sum = nonlink_primary(pb, x, qc, sum);
     sum += balance_cost(pb, bal, qc);
     if (do_check) {
         const F7 zero = F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};

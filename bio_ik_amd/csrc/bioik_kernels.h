@@ -561,7 +561,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     const ChildT<PB> cx[1] = {make_child_t(pb, key, hctr1, (uint32_t)c + 2u, hp0, lds + off_pgt, M)};
                     double f[1];
                     eval_exact_primary_n<1, true, true>(pb, cx, qc, s_slots, 0, f, s_prefix);
-                    if (pb->n_link_primary < pb->n_primary) f[0] += nonlink_primary(pb, make_child_x(pb, key, hctr1, (uint32_t)c + 2u, hp0, hp0 + M, hp0 + 3 * M), qc);
+                    if (pb->n_link_primary < pb->n_primary) f[0] = nonlink_primary(pb, make_child_x(pb, key, hctr1, (uint32_t)c + 2u, hp0, hp0 + M, hp0 + 3 * M), qc, f[0]);
                     else f[0] += 0.0;
                     f[0] += balance_cost(pb, v3(0.0, 0.0, 0.0), qc);
                     if (r < n_walk) s_fit[r] = f[0];
@@ -1039,7 +1039,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                     const double *pa = lds + (sp0 ? cbo[1] : cbo[0]), *pc = lds + (sp1 ? cbo[1] : cbo[0]);
                                     const ChildX<PB> cx[2] = {make_child_x(pb, key, (uint32_t)(sp0 ? ct[1] : ct[0]), (uint32_t)c0 + 2u, pa, pa + M, pa + 3 * M),
                                                               make_child_x(pb, key, (uint32_t)(sp1 ? ct[1] : ct[0]), (uint32_t)c1 + 2u, pc, pc + M, pc + 3 * M)};
-                                    f[0] += nonlink_primary(pb, cx[0], qc), f[1] += nonlink_primary(pb, cx[1], qc);
+                                    f[0] = nonlink_primary(pb, cx[0], qc, f[0]), f[1] = nonlink_primary(pb, cx[1], qc, f[1]);
                                 } else {
                                     f[0] += 0.0, f[1] += 0.0;
                                 }
@@ -1111,7 +1111,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const double* cb2 = s_pop + S2.slot * SP + S2.cur * BF;
                                 const uint32_t ctr2 = rng_ctr1(gctr, (uint32_t)S2.id, RNG_REPRODUCE);
                                 const int ra2 = r < n_eval ? r : 0;
-                                f[0] += nonlink_primary(pb, make_child_x(pb, key, ctr2, (uint32_t)(has_sec ? s_order[ra2] : ra2) + 2u, cb2, cb2 + M, cb2 + 3 * M), qc);
+                                f[0] = nonlink_primary(pb, make_child_x(pb, key, ctr2, (uint32_t)(has_sec ? s_order[ra2] : ra2) + 2u, cb2, cb2 + M, cb2 + 3 * M), qc, f[0]);
                             } else {
                                 f[0] += 0.0;
                             }
@@ -1166,7 +1166,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 const int c0 = has_sec ? s_order[ra] : ra, c1 = has_sec ? s_order[rb] : rb;
                                 const ChildX<PB> cx[2] = {make_child_x(pb, key, ctr2, (uint32_t)c0 + 2u, cb2, cb2 + M, cb2 + 3 * M),
                                                           make_child_x(pb, key, ctr2, (uint32_t)c1 + 2u, cb2, cb2 + M, cb2 + 3 * M)};
-                                f[0] += nonlink_primary(pb, cx[0], qc), f[1] += nonlink_primary(pb, cx[1], qc);
+                                f[0] = nonlink_primary(pb, cx[0], qc, f[0]), f[1] = nonlink_primary(pb, cx[1], qc, f[1]);
                             } else {
                                 f[0] += 0.0, f[1] += 0.0;  // (nonlink_primary of no goal: the sum it returns)
                             }
@@ -1536,10 +1536,10 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 f = F7{{BK_FMA(d[0], dstep, f.p.x), BK_FMA(d[1], dstep, f.p.y), BK_FMA(d[2], dstep, f.p.z)},
                                        {BK_FMA(d[3], dstep, f.q.x), BK_FMA(d[4], dstep, f.q.y), BK_FMA(d[5], dstep, f.q.z), BK_FMA(d[6], dstep, f.q.w)}};
                             }
-                            acc += tip_goals(pb, t, f, x, qc);
+                            acc = tip_goals(pb, t, f, x, qc, acc);
                             balance_tip(pb, t, f, bal);
                         }
-                        acc += nonlink_primary(pb, x, qc);
+                        acc = nonlink_primary(pb, x, qc, acc);
                         acc += balance_cost(pb, bal, qc);
                         prim = acc;
                         if constexpr (DENSE) all = acc + 0.0;  // (the launcher gives the dense kernel problems without secondary goals only: the empty sum)

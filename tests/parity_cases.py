@@ -175,3 +175,34 @@ def point_solvers(h, o, template, n=8, exact_jac=True):
         c = h.solve_batch(p, seeds, params)
         assert all(np.array_equal(x, y) for x, y in zip(a, c)), (mode, islands, st, np.abs(a[0] - c[0]).max())
     return b
+
+
+def goal_sets_beyond_one_goal_per_tip(model, make_solver, whole_solves=True):
+    """Several goals on one tip, goals on a link in the middle of the chain, several gene-only primary goals, goals that name variables of their own (a
+    JointVariableGoal puts its variable in FRONT of the chains' among the active variables, problem.cpp:103-125: the genes then do not follow the ops) -- the
+    reference adds goal after goal to one running sum (problem.cpp:244-257) and its sums over the joint values run over the genes in their order.  The device
+    evaluates a tip's goals when the walk completes the tip: listed in that order (the links from the root outwards, gene-only goals behind them) the goals give
+    the oracle's fitness and trajectories bit for bit; listed otherwise the same terms are added in another order -- the last bit of a fitness may differ."""
+    from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, MinimalDisplacementGoal, PoseGoal, PositionGoal, ProblemTemplate,
+                            RegularizationGoal)
+    elbow = [PositionGoal("r_elbow_flex_link", weight=0.3), PositionGoal("r_elbow_flex_link", (0.1, 0.2, 0.3), weight=0.2)]
+    tail = [RegularizationGoal(weight=0.2), CenterJointsGoal(weight=0.1, secondary=False), MinimalDisplacementGoal(weight=0.3)]
+    in_order = {
+        "two goals on a tip, gene-only goals": elbow + [PoseGoal("r_wrist_roll_link")] + tail,
+        "variables of their own": [PoseGoal("r_wrist_roll_link"), JointVariableGoal("r_forearm_roll_joint", 0.3, weight=0.4), RegularizationGoal(weight=0.2),
+                                   MinimalDisplacementGoal(weight=0.3, secondary=False), AvoidJointLimitsGoal(weight=0.5, secondary=False),
+                                   CenterJointsGoal(weight=0.1, secondary=False)],
+        "two of them": [PositionGoal("r_wrist_roll_link"), JointVariableGoal("r_wrist_flex_joint", -0.3, weight=0.4),
+                        JointVariableGoal("r_shoulder_lift_joint", 0.2, weight=0.6, secondary=True), CenterJointsGoal(weight=0.3)],
+    }
+    for name, goals in in_order.items():
+        for group in ("right_arm", "all"):
+            t = ProblemTemplate(model, group, goals)
+            h, o = make_solver(t), orc.Oracle(t)
+            function_level(h, o, model, np.random.default_rng(3), n=40, exact_bits=True)
+            if whole_solves:
+                for mode in ("bio2", "bio2_memetic", "bio2_memetic_l"):
+                    trajectory(h, o, t, n=2, pop=16, steps_list=(3,), mode=mode)
+                trajectory(h, o, t, n=1, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
+    t = ProblemTemplate(model, "right_arm", [PoseGoal("r_wrist_roll_link")] + elbow + tail)  # (the wrist's goal first: the walk completes the elbow first)
+    function_level(make_solver(t), orc.Oracle(t), model, np.random.default_rng(3), n=40, fit_rtol=1e-15)

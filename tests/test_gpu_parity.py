@@ -543,6 +543,12 @@ def test_secondary_goals_of_every_kind_in_whole_solves(templates):
         pc.trajectory(HipSolver(t2), orc.Oracle(t2), t2, n=16, pop=128, steps_list=(4,))
 
 
+def test_goal_sets_beyond_one_goal_per_tip(templates):
+    """parity_cases.goal_sets_beyond_one_goal_per_tip on the device"""
+    from bio_ik_amd.solver import HipSolver
+    pc.goal_sets_beyond_one_goal_per_tip(templates["c2"].model, lambda t: HipSolver(t))
+
+
 def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
     """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
     residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""

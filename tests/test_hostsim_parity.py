@@ -194,6 +194,11 @@ def test_secondary_goals_of_every_kind_in_whole_solves(hostsim_lib, templates):
     pc.trajectory(h2, o2, t2, n=2, pop=128, steps_list=(2,))
 
 
+def test_goal_sets_beyond_one_goal_per_tip(hostsim_lib, templates):
+    """parity_cases.goal_sets_beyond_one_goal_per_tip on the host simulator"""
+    pc.goal_sets_beyond_one_goal_per_tip(templates["c2"].model, lambda t: HipSolver(t, lib=hostsim_lib))
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
