@@ -291,8 +291,10 @@ BIOIK_DEV unsigned long long group_min_u64(unsigned long long k, int G) {
 // Keys spread like a generation's reach that after about log2(n) + 2 rounds (unique keys: 64 at most), against the log2(n)(log2(n)+1)/2 = 28 / 45 rounds
 // of permutes and compare-exchanges of the network (128 / 512 keys).  Returns the threshold: the survivors are the keys <= it.
 // n_mine: this lane's first n_mine keys belong to children (the rest is padding: +inf); gmask: the lanes of the caller's group inside its wavefront.
+// found: false if 66 rounds have not produced the threshold -- with distinct keys and 1 <= k < the number of children the interval shrinks by at least one
+// key value per round and that cannot happen; the bound is there so that no input, whatever it is, can keep a wavefront in the loop (the caller sorts then).
 template <int E>
-BIOIK_DEV unsigned long long select_threshold(const unsigned long long (&key)[E], int n_mine, int k, int G, unsigned long long gmask) {
+BIOIK_DEV unsigned long long select_threshold(const unsigned long long (&key)[E], int n_mine, int k, int G, unsigned long long gmask, bool& found) {
     unsigned long long lo = ~0ull, nhi = ~0ull;  // (nhi: the complement of the greatest key, so that both ends are minima)
 #pragma unroll
     for (int i = 0; i < E; i++)
@@ -301,7 +303,7 @@ BIOIK_DEV unsigned long long select_threshold(const unsigned long long (&key)[E]
     unsigned long long hi = ~group_min_u64(nhi, G);
     unsigned long long T = hi;
     bool done = false;
-    for (;;) {  // (the halves of a wavefront that carries two species search side by side: the loop ends when both have found theirs)
+    for (int round = 0; round < 66; round++) {  // (the halves of a wavefront that carries two species search side by side: the loop ends when both have found theirs)
         const unsigned long long mid = lo + ((hi - lo) >> 1);
         int cnt = 0;
 #pragma unroll
@@ -313,6 +315,7 @@ BIOIK_DEV unsigned long long select_threshold(const unsigned long long (&key)[E]
         }
         if (p_ballot(!done) == 0ull) break;
     }
+    found = done;
     return T;
 }
 // A non-negative double orders like its bit pattern.  The key keeps the upper 54 bits of the pattern and carries the child index (< 1024) in the lower ten:
@@ -803,7 +806,8 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                     unsigned long long sk[E];
 #pragma unroll
                                     for (int i = 0; i < E; i++) sk[i] = sort_key(sf[i], sc[i], drop), s_sec[gtid * E + i] = sf[i];
-                                    const unsigned long long T = select_threshold<E>(sk, lambda - gtid * E, n_eval, G, gmask);
+                                    bool found;
+                                    const unsigned long long T = select_threshold<E>(sk, lambda - gtid * E, n_eval, G, gmask, found);
                                     bool in_s = false, in_n = false;
 #pragma unroll
                                     for (int i = 0; i < E; i++) {
@@ -812,7 +816,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                     }
                                     const unsigned long long any_s = p_ballot(in_s) & gmask, any_n = p_ballot(in_n) & gmask;  // (both asked by every lane: no short circuit)
                                     const bool straddle = any_s != 0ull && any_n != 0ull;
-                                    bool bad = false;
+                                    bool bad = !found;
                                     if (p_ballot(straddle) != 0ull) {
                                         // (any member's value through a word of the group's scratch: if all are the same it does not matter whose arrives)
                                         unsigned long long mine = 0ull;
@@ -830,7 +834,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                         group_sync(G);
                                         unsigned long long ref;
                                         __builtin_memcpy(&ref, &s_bc[0], 8);
-                                        bad = straddle && have && (mixed || mine != ref);
+                                        bad = bad || (straddle && have && (mixed || mine != ref));
                                         group_sync(G);
                                     }
                                     if (p_ballot(bad) == 0ull) {  // (the halves of a wavefront decide together: one path through the code)
