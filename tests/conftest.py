@@ -73,6 +73,34 @@ def gnarly_robot():
     return m
 
 
+def hand_robot(slide="revolute"):
+    """A branching fixture with axis-aligned joint origins (test fixture only): an arm of four joints, a palm on a fixed link, three fingers of two joints with a
+    fixed tip link each -- three tips behind a common chain, so the walk parks the palm's frame for the second and third finger.  slide: the type of the arm's third
+    joint (a prismatic joint in the MIDDLE of a chain is where the joint program's folded constants round differently from the reference's frame by frame)."""
+    from bio_ik_amd import RobotModel
+    m = RobotModel("hand")
+    m.add_link("base")
+    m.add_link("a1", "base", "a1_joint", "revolute", xyz=(0, 0, 0.1), axis=(0, 0, 1), lower=-2.0, upper=2.0, velocity=1.0)
+    m.add_link("a2", "a1", "a2_joint", "revolute", xyz=(0.2, 0, 0), axis=(0, 1, 0), lower=-1.5, upper=1.5, velocity=1.5)
+    if slide == "prismatic":
+        m.add_link("slide", "a2", "slide_joint", "prismatic", xyz=(0.1, 0, 0), axis=(1, 0, 0), lower=-0.05, upper=0.2, velocity=0.3)
+    else:
+        m.add_link("slide", "a2", "slide_joint", "revolute", xyz=(0.1, 0, 0), axis=(0, 0, 1), lower=-0.5, upper=0.7, velocity=0.3)
+    m.add_link("a3", "slide", "a3_joint", "continuous", xyz=(0.15, 0, 0), axis=(1, 0, 0), velocity=2.0)
+    m.add_link("palm", "a3", "palm_joint", "fixed", xyz=(0, 0, 0))
+    joints = ["a1_joint", "a2_joint", "slide_joint", "a3_joint"]
+    tips = []
+    for i, (y, ax) in enumerate(((0.04, (0, 1, 0)), (0.0, (0, 0, 1)), (-0.04, (0, 1, 0)))):
+        f = "f%d" % i
+        m.add_link(f + "a", "palm", f + "a_joint", "revolute", xyz=(0.03, y, 0), axis=ax, lower=-1.0, upper=1.2, velocity=3.0)
+        m.add_link(f + "b", f + "a", f + "b_joint", "revolute", xyz=(0.04, 0, 0), axis=(0, 1, 0), lower=-0.2, upper=1.6, velocity=3.0)
+        m.add_link(f + "_tip", f + "b", f + "_tip_joint", "fixed", xyz=(0.03, 0, 0))
+        joints += [f + "a_joint", f + "b_joint"]
+        tips.append(f + "_tip")
+    m.add_group("hand", joints=joints, tips=tips)
+    return m
+
+
 @pytest.fixture(scope="session")
 def gnarly():
     return gnarly_robot()

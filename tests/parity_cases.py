@@ -206,3 +206,34 @@ def goal_sets_beyond_one_goal_per_tip(model, make_solver, whole_solves=True):
                 trajectory(h, o, t, n=1, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
     t = ProblemTemplate(model, "right_arm", [PoseGoal("r_wrist_roll_link")] + elbow + tail)  # (the wrist's goal first: the walk completes the elbow first)
     function_level(make_solver(t), orc.Oracle(t), model, np.random.default_rng(3), n=40, fit_rtol=1e-15)
+
+
+def branching_hand(make_solver):
+    """conftest.hand_robot: three tips behind a common chain (parked frames), goals on the palm in the middle of the chain, on every finger tip, over the joint
+    values, a JointVariableGoal -- listed in walk order: fitness, tables and whole solves bit for bit, every mode, both phenotype models, islands.  With the
+    arm's third joint PRISMATIC the tip positions agree to the last bit or two instead (the joint program applies origin and slide as one folded constant
+    where the reference concatenates frame by frame)."""
+    from conftest import hand_robot
+    from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, LookAtGoal, MinimalDisplacementGoal, OrientationGoal, PoseGoal, PositionGoal,
+                            ProblemTemplate)
+    model = hand_robot()
+    cases = {
+        "three tips": [PositionGoal("f0_tip"), PositionGoal("f1_tip", weight=0.8), PoseGoal("f2_tip", weight=0.5)],
+        "palm, tips, secondary goals": [OrientationGoal("palm", weight=0.4), PositionGoal("f0_tip"), LookAtGoal("f0_tip", (1, 0, 0), (0.5, 0.1, 0.3), weight=0.3),
+                                        PositionGoal("f1_tip", weight=0.8), PositionGoal("f2_tip", weight=0.5), MinimalDisplacementGoal(weight=0.4),
+                                        AvoidJointLimitsGoal(weight=0.6)],
+        "a link in the middle, a variable of its own": [PositionGoal("a2", weight=0.3), PositionGoal("f1_tip"), PositionGoal("f2_tip"),
+                                                        JointVariableGoal("f0a_joint", 0.3, weight=0.5), CenterJointsGoal(weight=0.2)],
+    }
+    for name, goals in cases.items():
+        t = ProblemTemplate(model, "hand", goals)
+        h, o = make_solver(t), orc.Oracle(t)
+        function_level(h, o, model, np.random.default_rng(3), n=40, exact_bits=True)
+        for mode in ("bio2", "bio2_memetic", "bio2_memetic_l"):
+            trajectory(h, o, t, n=2, pop=16, steps_list=(3,), mode=mode)
+        trajectory(h, o, t, n=2, pop=70, steps_list=(2,))
+        trajectory(h, o, t, n=2, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
+        trajectory(h, o, t, n=2, pop=128, steps_list=(2,), islands=2)
+    model_p = hand_robot("prismatic")
+    t = ProblemTemplate(model_p, "hand", cases["three tips"])
+    function_level(make_solver(t), orc.Oracle(t), model_p, np.random.default_rng(3), n=40, frame_tol=5e-16, fit_rtol=1e-14)

@@ -549,6 +549,12 @@ def test_goal_sets_beyond_one_goal_per_tip(templates):
     pc.goal_sets_beyond_one_goal_per_tip(templates["c2"].model, lambda t: HipSolver(t))
 
 
+def test_branching_hand():
+    """parity_cases.branching_hand on the device"""
+    from bio_ik_amd.solver import HipSolver
+    pc.branching_hand(lambda t: HipSolver(t))
+
+
 def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
     """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
     residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""

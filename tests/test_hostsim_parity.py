@@ -199,6 +199,11 @@ def test_goal_sets_beyond_one_goal_per_tip(hostsim_lib, templates):
     pc.goal_sets_beyond_one_goal_per_tip(templates["c2"].model, lambda t: HipSolver(t, lib=hostsim_lib))
 
 
+def test_branching_hand(hostsim_lib):
+    """parity_cases.branching_hand on the host simulator"""
+    pc.branching_hand(lambda t: HipSolver(t, lib=hostsim_lib))
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
