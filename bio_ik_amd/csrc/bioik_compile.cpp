@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace bioik {
@@ -246,11 +247,69 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     std::vector<int> src_of(nl, -1), op_of_link(nl, -1);
     std::vector<Frame> c_of(nl, identity());
     std::vector<DevOp> ops;
+    // A branch whose parent frame is not the running frame: if the chain root -> parent is short (a torso in front of two
+    // arms), walk it again in front of the branch instead of parking the parent frame in LDS (7 doubles per lane and
+    // slot set).  The repeated ops read the value of the op they repeat (mimic factor 1) and are on no tip's chain mask,
+    // so genes, Jacobian columns and the linear model are untouched and the frames are the same bits.
+    auto rewalk_short_parent_chain = [&](DevOp& op, int base_src, bool multi) {
+        if (!multi && base_src >= 0 && base_src != (int)ops.size() - 1) {
+            std::vector<int> chain;
+            bool plain = true;
+            for (int o = base_src; o >= 0; o = ops[o].src) {
+                chain.push_back(o);
+                plain = plain && (ops[o].type == BIOIK_OP_REVOLUTE || ops[o].type == BIOIK_OP_PRISMATIC);
+            }
+            if (plain && chain.size() <= 2 && ops.size() + chain.size() < (size_t)BIOIK_MAX_OPS) {
+                int prev = -1;
+                for (size_t c = chain.size(); c-- > 0;) {
+                    DevOp rep = ops[chain[c]];
+                    rep.gene = -1;
+                    rep.src = prev;
+                    rep.load_slot = rep.save_slot = -1;
+                    if (rep.mimic_src == -1) rep.mimic_src = chain[c], rep.mimic_factor = 1.0, rep.mimic_offset = 0.0;
+                    prev = (int)ops.size();
+                    ops.push_back(rep);
+                }
+                op.src = prev;
+            }
+        }
+    };
+    // BIOIK_COMPILE_EXACT=1 (diagnostics): the joint program WITHOUT folding.  By default a joint's origin and the fixed links in front of it become one
+    // constant frame of the joint's op -- p + R (o + v a) where the reference concatenates frame by frame, (p + R o) + R' (v a): the same frames to the last
+    // bit or two, exactly the same only for origins without rotation whose offsets do not add up.  Here every origin that is not the identity (a joint's, a
+    // fixed link's) is an op of its own -- a revolute op whose angle is the constant 0 (it "mimics" itself with factor 0), so that its frame is the constant
+    // alone -- and the joint's op behind it carries the bare joint: parent o origin o joint in the reference's association (forward_kinematics.h:283-330), on
+    // any robot.  About twice the ops; such a program is not a serial chain, so the kernels compiled for one do not run it.
+    const bool exact_program = std::getenv("BIOIK_COMPILE_EXACT") != nullptr && std::atoi(std::getenv("BIOIK_COMPILE_EXACT")) != 0;
+    int some_joint_var = -1;
+    for (int l : schedule)
+        if (m->links[l].type != BIOIK_JOINT_FIXED && some_joint_var < 0) some_joint_var = m->links[l].first_var;
     for (int l : schedule) {
         const HostModel::Link& L = m->links[l];
         int base_src = L.parent >= 0 ? src_of[L.parent] : -1;
         Frame base_c = L.parent >= 0 ? c_of[L.parent] : identity();
         Frame C = concat(base_c, L.origin);
+        if (exact_program && some_joint_var >= 0) {
+            if (!is_identity(L.origin)) {
+                DevOp op;
+                std::memset(&op, 0, sizeof(op));
+                op.type = BIOIK_OP_REVOLUTE;
+                op.var = L.type != BIOIK_JOINT_FIXED ? L.first_var : some_joint_var;
+                op.gene = -1;
+                op.src = base_src;
+                op.load_slot = op.save_slot = -1;
+                op.val_first = op.joint_op = -1, op.multi_slot = -1;
+                for (int c = 0; c < 3; c++) op.cpos[c] = L.origin.p[c], op.axis[c] = c == 2 ? 1.0 : 0.0;
+                for (int c = 0; c < 4; c++) op.ca[c] = L.origin.q[c];
+                double aq[4] = {0.0, 0.0, 1.0, 0.0};
+                qmul(L.origin.q, aq, op.cb);  // (multiplied by sin 0 = 0)
+                rewalk_short_parent_chain(op, base_src, false);
+                op.mimic_src = (int)ops.size(), op.mimic_factor = 0.0, op.mimic_offset = 0.0;  // its own value times nought: the angle 0
+                base_src = (int)ops.size();
+                ops.push_back(op);
+            }
+            C = identity();
+        }
         if (L.type == BIOIK_JOINT_FIXED) {
             src_of[l] = base_src;
             c_of[l] = C;
@@ -294,31 +353,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
             qrot(C.q, L.axis, op.cb);
             op.cb[3] = 0.0;
         }
-        // A branch whose parent frame is not the running frame: if the chain root -> parent is short (a torso in front of two
-        // arms), walk it again in front of the branch instead of parking the parent frame in LDS (7 doubles per lane and
-        // slot set).  The repeated ops read the value of the op they repeat (mimic factor 1) and are on no tip's chain mask,
-        // so genes, Jacobian columns and the linear model are untouched and the frames are the same bits.
-        if (!multi && base_src >= 0 && base_src != (int)ops.size() - 1) {
-            std::vector<int> chain;
-            bool plain = true;
-            for (int o = base_src; o >= 0; o = ops[o].src) {
-                chain.push_back(o);
-                plain = plain && (ops[o].type == BIOIK_OP_REVOLUTE || ops[o].type == BIOIK_OP_PRISMATIC);
-            }
-            if (plain && chain.size() <= 2 && ops.size() + chain.size() < (size_t)BIOIK_MAX_OPS) {
-                int prev = -1;
-                for (size_t c = chain.size(); c-- > 0;) {
-                    DevOp rep = ops[chain[c]];
-                    rep.gene = -1;
-                    rep.src = prev;
-                    rep.load_slot = rep.save_slot = -1;
-                    if (rep.mimic_src == -1) rep.mimic_src = chain[c], rep.mimic_factor = 1.0, rep.mimic_offset = 0.0;
-                    prev = (int)ops.size();
-                    ops.push_back(rep);
-                }
-                op.src = prev;
-            }
-        }
+        rewalk_short_parent_chain(op, base_src, multi);
         int k = (int)ops.size();
         ops.push_back(op);
         src_of[l] = k;

@@ -237,3 +237,32 @@ def branching_hand(make_solver):
     model_p = hand_robot("prismatic")
     t = ProblemTemplate(model_p, "hand", cases["three tips"])
     function_level(make_solver(t), orc.Oracle(t), model_p, np.random.default_rng(3), n=40, frame_tol=5e-16, fit_rtol=1e-14)
+
+
+def exact_joint_program(make_solver, templates, same_libm=True):
+    """BIOIK_COMPILE_EXACT=1 (bioik_compile.cpp): the joint program without folding -- an op per origin that is not the identity, the bare joint behind it, the
+    reference's frame-by-frame association on ANY robot.  The caller has set the switch.  `gnarly` (rotated origins, oblique axes, a prismatic joint inside a chain,
+    fixed links with offsets, three branches, a tip off the root) with a goal of every opcode listed in walk order, and the branching hand with a prismatic joint
+    in the middle of its arm: FK, fitness, tables, success test and whole solves bit for bit -- what the folded program reaches to 1e-12 there.  On a benchmark
+    fixture, where folding is exact, the two programs give the same bits (through other kernels: the unfolded program is not a serial chain).
+    same_libm: device and oracle share acos (the host simulator).  LookAtGoal, ConeGoal and their kind call it; on the GPU it is another library's, equal on the
+    sampled configurations of the function-level check but not on every one a memetic search visits, so there the whole solves use the goals without it."""
+    from conftest import gnarly_goals, gnarly_robot, hand_robot
+    from bio_ik_amd import PoseGoal, PositionGoal, ProblemTemplate
+    g = gnarly_robot()
+    order = {n: i for i, n in enumerate(g.link_names)}
+    goals = gnarly_goals()
+    in_walk_order = sorted([x for x in goals if x.link_name()], key=lambda x: order[x.link_name()]) + [x for x in goals if not x.link_name()]
+    hp = hand_robot("prismatic")
+    for model, group, gl in ((g, "body", in_walk_order), (g, "body", [PoseGoal("a_tool"), PoseGoal("b_tool"), PositionGoal("head")]),
+                             (hp, "hand", [PositionGoal("f0_tip"), PositionGoal("f1_tip", weight=0.8), PoseGoal("f2_tip", weight=0.5)])):
+        t = ProblemTemplate(model, group, gl)
+        h, o = make_solver(t), orc.Oracle(t)
+        function_level(h, o, model, np.random.default_rng(3), n=40, exact_bits=True)
+        if gl is in_walk_order and not same_libm:
+            continue
+        for mode in ("bio2", "bio2_memetic", "bio2_memetic_l"):
+            trajectory(h, o, t, n=2, pop=16, steps_list=(3,), mode=mode)
+        trajectory(h, o, t, n=2, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
+    t = templates["c3"]
+    trajectory(make_solver(t), orc.Oracle(t), t, n=2, pop=32, steps_list=(3,))

@@ -204,6 +204,12 @@ def test_branching_hand(hostsim_lib):
     pc.branching_hand(lambda t: HipSolver(t, lib=hostsim_lib))
 
 
+def test_exact_joint_program(hostsim_lib, templates, monkeypatch):
+    """parity_cases.exact_joint_program on the host simulator"""
+    monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
+    pc.exact_joint_program(lambda t: HipSolver(t, lib=hostsim_lib), templates)
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
