@@ -9,7 +9,11 @@
 // Reference quirks handled: Q1 stale masked tips (fixed in orc_model.h), Q2 species.fitness
 // read uninitialised on the first step (:612) -> +infinity, Q3 secondary goals see null tip frames
 // (ik_base.h:163: uninitialised in the reference; zero frames here), Q4 std::sort tie order (:376, :617)
-// -> stable order.
+// -> stable order, Q5 the line search's step on a flat model: all three support values equal make the quadratic step 0 / 0 (:503-507) and the linear one a division
+// by 0 (:547-548); the candidate's genes are NaN, RobotInfo::clip lets a NaN through (utils.h:328-333: two comparisons that are both false), and a goal that takes
+// max(0, .) of its error hides it -- the NaN candidate can be ACCEPTED and returned as the solution (found by tools/robot_fuzz_hostsim.py: 3 of 600 random robots).
+// The device clips with fmin(fmax(v, lo), hi), for which a NaN is the lower limit: quirk_mode 0 (the default, what the device is compared with) does the same,
+// quirk_mode 1 is the literal reference.
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -73,6 +77,11 @@ struct Evolution2 {
 
     // ---- ik_base.h:163-207 ----
     double secondary_fitness(const double* genes) { return problem->compute_goal_fitness(problem->secondary_goals, query, null_tip_frames.data(), genes); }
+    // (quirk Q5, see the header: the literal clip lets a NaN through; the device's fmin(fmax(v, lo), hi) makes it the lower limit)
+    double line_search_clip(double p, size_t var) const {
+        if (quirk_mode() == 0 && p != p) return model->vars[var].clip_min;
+        return model->clip(p, var);
+    }
     double primary_fitness(const Frame* frames, const double* genes) { return problem->compute_goal_fitness(problem->goals, query, frames, genes); }
     double combined_fitness(const Frame* frames, const double* genes) {
         double ret = 0.0;
@@ -311,7 +320,7 @@ struct Evolution2 {
                         double a = (v1 - v2);
                         double step_size = v / a;
                         for (size_t i = 0; i < D(); i++)
-                            gw[i] = model->clip(individual.genes[i] + gradient[i] * step_size, problem->active_variables[i]);
+                            gw[i] = line_search_clip(individual.genes[i] + gradient[i] * step_size, problem->active_variables[i]);
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {
@@ -325,7 +334,7 @@ struct Evolution2 {
                         double cost_diff = (f3 - f1) * 0.5;
                         double step_size = f2 / cost_diff;
                         for (size_t i = 0; i < D(); i++)
-                            gw[i] = model->clip(individual.genes[i] - gradient[i] * step_size, problem->active_variables[i]);
+                            gw[i] = line_search_clip(individual.genes[i] - gradient[i] * step_size, problem->active_variables[i]);
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {

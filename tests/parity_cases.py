@@ -266,3 +266,39 @@ def exact_joint_program(make_solver, templates, same_libm=True):
         trajectory(h, o, t, n=2, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
     t = templates["c3"]
     trajectory(make_solver(t), orc.Oracle(t), t, n=2, pop=32, steps_list=(3,))
+
+
+def line_search_on_a_flat_model(make_solver):
+    """Quirk Q5 (oracle/orc_evolution.h): when the three support values of the memetic line search are equal the quadratic step is 0 / 0 (ik_evolution_2.cpp:503-507);
+    the candidate's genes are NaN, RobotInfo::clip lets a NaN through (utils.h:328-333) and a goal that takes max(0, .) of its error hides it, so the literal algorithm
+    can ACCEPT the NaN candidate and return it.  The device clips with fmin(fmax(v, lo), hi) -- a NaN becomes the lower limit -- and never returns one.  The robot and
+    the goals are the case tools/robot_fuzz_hostsim.py met (three links, the last joint turns its link about the link's own origin, so a goal on that link's POSITION
+    is flat in it): the literal oracle (quirk mode 1) returns NaN genes with a finite fitness, the default oracle (mode 0) and the device the same finite solves,
+    bit for bit.  The caller has set BIOIK_COMPILE_EXACT (the last origin is rotated)."""
+    from bio_ik_amd import LineGoal, MaxDistanceGoal, PositionGoal, ProblemTemplate, RobotModel
+    m = RobotModel("flat")
+    m.add_link("l0")
+    m.add_link("l1", "l0", "j1", "fixed", xyz=(0.2893761985906587, 0.03248937499002066, -0.014841302929549098))
+    m.add_link("l2", "l1", "j2", "revolute", xyz=(0.10755360117858924, 0.02493781640192608, -0.04886061998123816), axis=(0, 1, 0), lower=-0.2803688282418388,
+               upper=3.1855786120683693, velocity=2.9325216061470356)
+    m.add_link("l3", "l2", "j3", "revolute", xyz=(-0.017080529114468283, 0.2551355563784019, -0.04863453264413984),
+               quat=(0.045195500178852516, 0.1273747337154112, 0.2667122008665194, 0.9542524015602207), axis=(0, 0, 1), lower=0.45554072748806607,
+               upper=1.4138397555794018, velocity=0.6399125293343063)
+    m.add_group("g", joints=["j2", "j3"], tips=["l1", "l2", "l3"])
+    goals = [PositionGoal("l1", (-0.5833139686114326, 0.05236954534023761, -0.48273822641048036), weight=0.3),
+             PositionGoal("l1", (0.2359118231308469, 0.3688053123007919, 0.10831832574337653), weight=1.6),
+             LineGoal("l2", (-0.162322900664759, -0.27458126148279965, -0.04181421604763092), (0.774617869644533, -0.08365929393599635, -0.6268718198846522), weight=1.6),
+             MaxDistanceGoal("l3", (-0.15454564414528751, -0.10852275777981442, -0.02007615363449216), 0.3)]
+    t = ProblemTemplate(m, "g", goals)
+    o, h = orc.Oracle(t), make_solver(t)
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2, seed=570)
+    p = abi.default_solve_params(population=8, max_steps=3, random_seed=11, mode="bio2_memetic")
+    orc.set_quirk_mode(1)
+    try:
+        literal = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=1)
+    finally:
+        orc.set_quirk_mode(0)
+    assert np.isnan(literal[0]).any() and np.isfinite(literal[1]).all()
+    want, got = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=1), h.solve_batch(p, seeds, params)
+    assert np.isfinite(want[0]).all()
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))

@@ -562,6 +562,13 @@ def test_exact_joint_program(templates, monkeypatch):
     pc.exact_joint_program(lambda t: HipSolver(t), templates, same_libm=False)
 
 
+def test_line_search_on_a_flat_model(monkeypatch):
+    """parity_cases.line_search_on_a_flat_model (quirk Q5: the reference's NaN candidate)"""
+    from bio_ik_amd.solver import HipSolver
+    monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
+    pc.line_search_on_a_flat_model(lambda t: HipSolver(t))
+
+
 def test_four_wavefront_build_of_the_computed_children_kernel(gpus, oracles, templates, monkeypatch):
     """C4 at its full population runs under the 128-register build of the computed-children kernel (k_solve_lean_cl4: the launcher's
     residency rule); its trajectories equal the oracle's and those of the 168-register build bit for bit"""

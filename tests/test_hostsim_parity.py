@@ -210,6 +210,12 @@ def test_exact_joint_program(hostsim_lib, templates, monkeypatch):
     pc.exact_joint_program(lambda t: HipSolver(t, lib=hostsim_lib), templates)
 
 
+def test_line_search_on_a_flat_model(hostsim_lib, monkeypatch):
+    """parity_cases.line_search_on_a_flat_model (quirk Q5: the reference's NaN candidate)"""
+    monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
+    pc.line_search_on_a_flat_model(lambda t: HipSolver(t, lib=hostsim_lib))
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal

@@ -1,0 +1,139 @@
+"""Robot soak WITHOUT a GPU: random kinematic TREES -- revolute, continuous, prismatic and fixed joints anywhere, rotated origins, oblique axes, mimic joints,
+branches at any depth, tips on inner links, on fixed links and off the root, fixed_joints -- with goals listed in walk order, in the host simulator
+(tests/hostsim) against the CPU oracle.  Twice per robot: the unfolded joint program (BIOIK_COMPILE_EXACT=1, bioik_compile.cpp), where FK, fitness, tables,
+success test and a whole solve must be the oracle's bit for bit on ANY robot, and the default (folded) program, which must agree to rounding (1e-12).
+usage: python tools/robot_fuzz_hostsim.py [cases] [seed]   (seconds per case; exit code 1 on a mismatch)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s"], check=True)
+import parity_cases as pc  # noqa: E402
+from bio_ik_amd import (AvoidJointLimitsGoal, CenterJointsGoal, JointVariableGoal, LineGoal, MaxDistanceGoal, MinDistanceGoal, MinimalDisplacementGoal,  # noqa: E402
+                        OrientationGoal, PlaneGoal, PoseGoal, PositionGoal, ProblemTemplate, RegularizationGoal, RobotModel, abi, solver)
+from oracle import orc  # noqa: E402
+
+
+def unit(rng, n):
+    v = rng.normal(size=n)
+    return tuple(v / np.linalg.norm(v))
+
+
+def random_robot(rng, case):
+    m = RobotModel("r%d" % case)
+    m.add_link("l0")
+    n = int(rng.integers(4, 15))
+    joints, moving = [], []
+    for i in range(1, n):
+        parent = "l%d" % (i - 1 if rng.random() < 0.7 else int(rng.integers(0, i)))
+        kind = str(rng.choice(["revolute", "revolute", "revolute", "continuous", "prismatic", "fixed"]))
+        xyz = tuple(rng.normal(size=3) * 0.15) if rng.random() < 0.8 else (0.0, 0.0, 0.0)
+        rpy = tuple(rng.normal(size=3) * 0.6) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
+        axis = unit(rng, 3) if rng.random() < 0.5 else tuple(np.eye(3)[int(rng.integers(3))])
+        kw = {}
+        if kind in ("revolute", "prismatic"):
+            lo, hi = sorted(rng.normal(size=2) * (1.5 if kind == "revolute" else 0.2))
+            kw = {"lower": float(lo - 0.1), "upper": float(hi + 0.1)}
+        if kind != "fixed":
+            kw["velocity"] = float(rng.uniform(0.3, 3.0))
+            if moving and kind in ("revolute", "prismatic") and rng.random() < 0.12:
+                kw["mimic"] = (str(rng.choice(moving)), float(rng.choice([1.0, -0.5, 2.0])), float(rng.choice([0.0, 0.1])))
+        m.add_link("l%d" % i, parent, "j%d" % i, kind, xyz=xyz, rpy=rpy, axis=axis, **kw)
+        if kind != "fixed":
+            joints.append("j%d" % i)
+            if kind in ("revolute", "prismatic") and "mimic" not in kw:
+                moving.append("j%d" % i)
+    return m, joints, n
+
+
+def whole_solve(h, o, t, pop, steps, mode, fk, case):
+    """parity_cases.trajectory with NaNs compared as equal: a goal that is met exactly makes the quadratic line search divide 0 by 0 (ik_evolution_2.cpp:498-539),
+    in the reference as here, and the NaN genes that follow must then be the same ones on both sides"""
+    from bio_ik_amd.workload import make_queries
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2, seed=case)
+    p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=11, mode=mode, fk_mode=fk)
+    sa = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
+    sb = h.solve_batch(p, seeds, params)
+    for a, b in zip(sa, sb):
+        assert np.array_equal(a, b, equal_nan=True), "whole solves differ: %g" % np.nanmax(np.abs(np.asarray(a, float) - np.asarray(b, float)))
+    return "  [NaN genes, the same on both sides]" if np.isnan(sa[0]).any() else ""
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    lib = solver.load_library(os.path.join(ROOT, "tests", "hostsim", "libbioik_hostsim.so"))
+    orc.set_trig_mode(1)
+    bad = skipped = 0
+    for case in range(n_cases):
+        model, joints, n = random_robot(rng, case)
+        if not joints:
+            continue
+        tips = sorted(rng.choice(np.arange(1, n), size=min(int(rng.integers(1, 4)), n - 1), replace=False))
+        model.add_group("g", joints=joints, tips=["l%d" % t for t in tips])
+        goals = []
+        for t in tips:  # (ascending link index: an ancestor in front of its descendants, unrelated tips in the order of the list = the order of the walk)
+            for _ in range(int(rng.choice([1, 1, 2]))):
+                link, w, p = "l%d" % t, float(rng.choice([0.3, 1.0, 1.6])), tuple(rng.normal(size=3) * 0.3)
+                k = int(rng.integers(7))
+                goals.append([PositionGoal(link, p, weight=w), OrientationGoal(link, unit(rng, 4), weight=w), PoseGoal(link, p, unit(rng, 4), weight=w),
+                              MaxDistanceGoal(link, p, 0.3, weight=w), MinDistanceGoal(link, p, 0.3, weight=w), LineGoal(link, p, unit(rng, 3), weight=w),
+                              PlaneGoal(link, p, unit(rng, 3), weight=w)][k])
+        for _ in range(int(rng.integers(0, 3))):
+            k, w, sec = int(rng.integers(5)), float(rng.choice([0.1, 0.5])), bool(rng.random() < 0.5)
+            if k == 0:
+                goals.append(JointVariableGoal(str(rng.choice(joints)), float(rng.normal() * 0.3), weight=w, secondary=sec))
+            elif k == 1:
+                g = RegularizationGoal(weight=w)
+                g.secondary_ = sec
+                goals.append(g)
+            else:
+                goals.append((MinimalDisplacementGoal, AvoidJointLimitsGoal, CenterJointsGoal)[k - 2](weight=w, secondary=sec))
+        fixed = [str(rng.choice(joints))] if rng.random() < 0.2 else []
+        desc = "%d links, tips %s, fixed %s | %s" % (n, list(tips), fixed, " ".join("%s%s" % (type(g).__name__.replace("Goal", ""), "*" if g.secondary_ else "") for g in goals))
+        mode = str(rng.choice(["bio2", "bio2_memetic", "bio2_memetic_l"]))
+        fk = int(rng.choice([abi.FK_EXACT, abi.FK_LINEAR]))
+        pop, steps = int(rng.choice([8, 16, 33])), int(rng.choice([1, 2, 3]))
+        try:
+            t = ProblemTemplate(model, "g", goals, fixed_joints=fixed)
+            try:
+                o = orc.Oracle(t)
+            except orc.OracleError as e:  # (what the reference refuses -- a goal on the variable of a mimic joint -- the device must refuse too)
+                try:
+                    solver.HipSolver(t, lib=lib)
+                    bad += 1
+                    print("%-3d BAD  %s: the oracle refuses (%s), the device does not" % (case, desc, e), flush=True)
+                except solver.BioIKError as e2:
+                    skipped += 1
+                    print("%-3d skip %s (both refuse: %s | %s)" % (case, desc, e, e2), flush=True)
+                continue
+            if o.D == 0:
+                skipped += 1
+                print("%-3d skip %s (no active variable)" % (case, desc), flush=True)
+                continue
+            os.environ["BIOIK_COMPILE_EXACT"] = "1"
+            h = solver.HipSolver(t, lib=lib)
+            pc.function_level(h, o, model, np.random.default_rng(case), n=16, exact_bits=True)
+            nan_note = whole_solve(h, o, t, pop, steps, mode, fk, case)
+            os.environ["BIOIK_COMPILE_EXACT"] = "0"
+            h2 = solver.HipSolver(t, lib=lib)
+            pc.function_level(h2, o, model, np.random.default_rng(case), n=16, frame_tol=1e-12, fit_rtol=1e-9)
+            print("%-3d ok   %s%s" % (case, desc, nan_note), flush=True)
+        except solver.BioIKError as e:
+            skipped += 1
+            print("%-3d skip %s (%s)" % (case, desc, e), flush=True)
+        except AssertionError as e:
+            import traceback
+            bad += 1
+            print("%-3d BAD  [EXACT=%s] %s: %s @ %s" % (case, os.environ["BIOIK_COMPILE_EXACT"], desc, e, traceback.format_exc().splitlines()[-3].strip()), flush=True)
+    print("%d cases, %d skipped (unsupported by the device, or no active variable), %d mismatches" % (n_cases, skipped, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
