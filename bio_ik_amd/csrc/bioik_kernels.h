@@ -1560,6 +1560,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         //   round 1  L1 normalisation (:477-482) and the two support points x - g (even lanes), x + g (odd lanes) (:485-495)
                         //   round 2  step along the gradient (:498-568), clipped candidate, acceptance on primary fitness
                         double f2p = 0.0, fa = 0.0, fnorm = 0.0;
+                        bool nan_gene = false;  // (round 2: a gene of the candidate is not a number)
                         for (int round = 0; round < 3; round++) {
                             double* dv0 = s_dv + (round == 0 ? 0 : round == 1 ? 1 : 3) * M;
                             double* fc0 = (L.fc >= 0 ? s_fc : popS + (S.cur ^ 1) * BF) + (round == 0 ? 0 : round == 1 ? 1 : 3) * FB;  // (make_layout: fc_in_pop)
@@ -1589,13 +1590,23 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                     double cost_diff = (f3 - f1) * 0.5;
                                     step_size = -(f2 / cost_diff);
                                 }
+                                // A step that is not a number: three equal support values make the quadratic step 0 / 0, the linear one f2 / 0 -- and 0 * inf for
+                                // a gene the gradient does not move.  The reference's clip lets a NaN through (utils.h:328-333), its candidate's fitness is NaN and
+                                // fails the comparison below: the search stops.  fmin / fmax would make the lower limit of a NaN (-DBL_MAX for a joint without
+                                // limits) and the candidate a jump there; so a candidate with a NaN gene is no candidate.  (Where a goal hides the NaN -- max(0, .)
+                                // of its error -- the literal reference ACCEPTS the NaN genes and can return them: quirk Q5, oracle/orc_evolution.h.)
+                                bool nan_here = false;
                                 for (int k = gtid; k < n_ops; k += Gw) {
                                     const double e = el[k], gv = s_gop[k] * fnorm;
                                     const bool on = (active_mask >> k) & 1ull;
-                                    const double x4 = on ? fmin(fmax(e + gv * step_size, s_clip[k]), s_clip[M + k]) : e;
+                                    const double raw = e + gv * step_size;
+                                    const bool is_nan = on && !(raw == raw);
+                                    nan_here = nan_here || is_nan;
+                                    const double x4 = (on && !is_nan) ? fmin(fmax(raw, s_clip[k]), s_clip[M + k]) : e;
                                     s_x4[k] = x4;
                                     dv0[k] = on ? x4 - s_base[k] : 0.0;
                                 }
+                                nan_gene = (p_ballot(nan_here) & (G >= 64 ? ~0ull : 0xffffffffull << (tid & 32))) != 0ull;
                             }
                             p_wave_sync();
                             PHASE_MARK(PH_MEM_SUPPORT_COLS);
@@ -1624,7 +1635,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 if (gtid < 2) s_ex[2 + gtid] = vall;
                                 p_wave_sync();
                             } else {
-                                const bool accept = vprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
+                                const bool accept = !nan_gene && vprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
                                 // (a half-wave group shares its wavefront with the other species: it stays in step with it and merely
                                 // repeats the rejected iteration, which changes nothing -- until the other species has stopped as well)
                                 if (G >= 64 ? !accept : p_ballot(accept) == 0ull) descending = false;

@@ -12,8 +12,8 @@
 // -> stable order, Q5 the line search's step on a flat model: all three support values equal make the quadratic step 0 / 0 (:503-507) and the linear one a division
 // by 0 (:547-548); the candidate's genes are NaN, RobotInfo::clip lets a NaN through (utils.h:328-333: two comparisons that are both false), and a goal that takes
 // max(0, .) of its error hides it -- the NaN candidate can be ACCEPTED and returned as the solution (found by tools/robot_fuzz_hostsim.py: 3 of 600 random robots).
-// The device clips with fmin(fmax(v, lo), hi), for which a NaN is the lower limit: quirk_mode 0 (the default, what the device is compared with) does the same,
-// quirk_mode 1 is the literal reference.
+// The device takes a candidate with a NaN gene for no candidate and stops the search there -- what the reference does whenever the NaN is NOT hidden (its fitness is
+// NaN and fails the comparison): quirk_mode 0 (the default, what the device is compared with) does the same, quirk_mode 1 is the literal reference.
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -77,9 +77,13 @@ struct Evolution2 {
 
     // ---- ik_base.h:163-207 ----
     double secondary_fitness(const double* genes) { return problem->compute_goal_fitness(problem->secondary_goals, query, null_tip_frames.data(), genes); }
-    // (quirk Q5, see the header: the literal clip lets a NaN through; the device's fmin(fmax(v, lo), hi) makes it the lower limit)
-    double line_search_clip(double p, size_t var) const {
-        if (quirk_mode() == 0 && p != p) return model->vars[var].clip_min;
+    // (quirk Q5, see the header: the literal clip lets a NaN through; the default mode marks the candidate instead -- it is then no candidate, as on the device)
+    bool candidate_has_nan = false;
+    double line_search_clip(double p, size_t var) {
+        if (quirk_mode() == 0 && p != p) {
+            candidate_has_nan = true;
+            return p;
+        }
         return model->clip(p, var);
     }
     double primary_fitness(const Frame* frames, const double* genes) { return problem->compute_goal_fitness(problem->goals, query, frames, genes); }
@@ -319,8 +323,10 @@ struct Evolution2 {
                         double v = (v1 + v2) * 0.5;
                         double a = (v1 - v2);
                         double step_size = v / a;
+                        candidate_has_nan = false;
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] + gradient[i] * step_size, problem->active_variables[i]);
+                        if (candidate_has_nan) break;  // (Q5, default mode)
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {
@@ -333,8 +339,10 @@ struct Evolution2 {
                     if (memetic == 'l') {  // :545-568
                         double cost_diff = (f3 - f1) * 0.5;
                         double step_size = f2 / cost_diff;
+                        candidate_has_nan = false;
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] - gradient[i] * step_size, problem->active_variables[i]);
+                        if (candidate_has_nan) break;  // (Q5, default mode)
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {
