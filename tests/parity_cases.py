@@ -271,7 +271,8 @@ def exact_joint_program(make_solver, templates, same_libm=True):
 def line_search_on_a_flat_model(make_solver):
     """Quirk Q5 (oracle/orc_evolution.h): when the three support values of the memetic line search are equal the quadratic step is 0 / 0 (ik_evolution_2.cpp:503-507);
     the candidate's genes are NaN, RobotInfo::clip lets a NaN through (utils.h:328-333) and a goal that takes max(0, .) of its error hides it, so the literal algorithm
-    can ACCEPT the NaN candidate and return it.  The device clips with fmin(fmax(v, lo), hi) -- a NaN becomes the lower limit -- and never returns one.  The robot and
+    can ACCEPT the NaN candidate and return it.  The device takes a candidate with a NaN gene for no candidate and stops the search, as the reference does whenever the
+    NaN is not hidden; it never returns one.  The robot and
     the goals are the case tools/robot_fuzz_hostsim.py met (three links, the last joint turns its link about the link's own origin, so a goal on that link's POSITION
     is flat in it): the literal oracle (quirk mode 1) returns NaN genes with a finite fitness, the default oracle (mode 0) and the device the same finite solves,
     bit for bit.  The caller has set BIOIK_COMPILE_EXACT (the last origin is rotated)."""
