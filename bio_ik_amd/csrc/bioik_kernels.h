@@ -1594,7 +1594,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 // a gene the gradient does not move.  The reference's clip lets a NaN through (utils.h:328-333), its candidate's fitness is NaN and
                                 // fails the comparison below: the search stops.  fmin / fmax would make the lower limit of a NaN (-DBL_MAX for a joint without
                                 // limits) and the candidate a jump there; so a candidate with a NaN gene is no candidate.  (Where a goal hides the NaN -- max(0, .)
-                                // of its error -- the literal reference ACCEPTS the NaN genes and can return them: quirk Q5, oracle/orc_evolution.h.)
+                                // of its error -- the literal reference ACCEPTS the NaN genes and can return them: quirk Q5)
                                 bool nan_here = false;
                                 for (int k = gtid; k < n_ops; k += Gw) {
                                     const double e = el[k], gv = s_gop[k] * fnorm;

@@ -134,6 +134,8 @@ def main():
         mode = str(rng.choice(["bio2", "bio2_memetic", "bio2_memetic_l"]))
         fk = int(rng.choice([abi.FK_EXACT, abi.FK_LINEAR]))
         pop, steps = int(rng.choice([8, 16, 33])), int(rng.choice([1, 2, 3]))
+        if os.environ.get("ROBOT_FUZZ_GRADIENT") and case % 3 == 0:  # (the gradient family's point solvers on the same trees)
+            mode, fk, steps = str(("gd", "gd_r", "gd_c")[(case // 3) % 3]), abi.FK_EXACT, int(rng.choice([1, 5, 20]))
         try:
             t = ProblemTemplate(model, "g", goals, fixed_joints=fixed)
             try:
