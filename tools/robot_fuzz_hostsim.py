@@ -2,6 +2,8 @@
 branches at any depth, tips on inner links, on fixed links and off the root, fixed_joints -- with goals listed in walk order, in the host simulator
 (tests/hostsim) against the CPU oracle.  Twice per robot: the unfolded joint program (BIOIK_COMPILE_EXACT=1, bioik_compile.cpp), where FK, fitness, tables,
 success test and a whole solve must be the oracle's bit for bit on ANY robot, and the default (folded) program, which must agree to rounding (1e-12).
+ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead.  (Floating / planar joints are not drawn:
+their unbounded variables need a sampler of their own; tests/test_*_parity.py: test_floating_and_planar_joints_anywhere covers them on fixtures.)
 usage: python tools/robot_fuzz_hostsim.py [cases] [seed]   (seconds per case; exit code 1 on a mismatch)"""
 import os
 import subprocess
