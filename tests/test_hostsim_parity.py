@@ -216,6 +216,18 @@ def test_line_search_on_a_flat_model(hostsim_lib, monkeypatch):
     pc.line_search_on_a_flat_model(lambda t: HipSolver(t, lib=hostsim_lib))
 
 
+def test_random_trees_and_goal_lists(hostsim_lib):
+    """A dozen cases each of the two CPU soaks (tools/robot_fuzz_hostsim.py: random kinematic trees, the unfolded joint program bit for bit and the folded one to
+    rounding; tools/goal_fuzz_hostsim.py: random goal lists on the PR2-like robot, bit for bit) -- the soaks of record are under profiles/ (600 + 600 + 400 cases)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tool, args in (("robot_fuzz_hostsim.py", ["12", "5"]), ("goal_fuzz_hostsim.py", ["8", "5"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "0 mismatches" in r.stdout
+
+
 def test_mimic_joints(hostsim_lib):
     """a joint that follows a gene and a joint that follows a joint outside every goal chain: function level and whole solves"""
     from bio_ik_amd import MinimalDisplacementGoal, PoseGoal, PositionGoal
