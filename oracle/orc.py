@@ -61,7 +61,7 @@ def shared_sincos(x, kind="strict"):
 
 
 def set_quirk_mode(mode, kind="strict"):
-    """0 = reference quirks Q1/Q4 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
+    """0 = reference quirks Q1 / Q4 / Q5 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
     lib(kind).orc_set_quirk_mode(C.c_int(mode))
 
 
