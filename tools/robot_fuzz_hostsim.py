@@ -2,7 +2,7 @@
 branches at any depth, tips on inner links, on fixed links and off the root, fixed_joints -- with goals listed in walk order, in the host simulator
 (tests/hostsim) against the CPU oracle.  Twice per robot: the unfolded joint program (BIOIK_COMPILE_EXACT=1, bioik_compile.cpp), where FK, fitness, tables,
 success test and a whole solve must be the oracle's bit for bit on ANY robot, and the default (folded) program, which must agree to rounding (1e-12).
-ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead.  (Floating / planar joints are not drawn:
+ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead; ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips.  (Floating / planar joints are not drawn:
 their unbounded variables need a sampler of their own; tests/test_*_parity.py: test_floating_and_planar_joints_anywhere covers them on fixtures.)
 usage: python tools/robot_fuzz_hostsim.py [cases] [seed]   (seconds per case; exit code 1 on a mismatch)"""
 import os
@@ -30,8 +30,8 @@ def unit(rng, n):
 def random_robot(rng, case):
     m = RobotModel("r%d" % case)
     m.add_link("l0")
-    n = int(rng.integers(4, 15))
-    joints, moving = [], []
+    n = int(rng.integers(4, 15)) if not os.environ.get("ROBOT_FUZZ_BIG") else int(rng.integers(12, 31))  # (ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips)
+    joints, moving, mimicable = [], [], []
     for i in range(1, n):
         parent = "l%d" % (i - 1 if rng.random() < 0.7 else int(rng.integers(0, i)))
         kind = str(rng.choice(["revolute", "revolute", "revolute", "continuous", "prismatic", "fixed"]))
@@ -45,12 +45,14 @@ def random_robot(rng, case):
         if kind != "fixed":
             kw["velocity"] = float(rng.uniform(0.3, 3.0))
             if moving and kind in ("revolute", "prismatic") and rng.random() < 0.12:
-                kw["mimic"] = (str(rng.choice(moving)), float(rng.choice([1.0, -0.5, 2.0])), float(rng.choice([0.0, 0.1])))
+                kw["mimic"] = (str(rng.choice(mimicable)), float(rng.choice([1.0, -0.5, 2.0])), float(rng.choice([0.0, 0.1])))  # (also of a joint that mimics another)
         m.add_link("l%d" % i, parent, "j%d" % i, kind, xyz=xyz, rpy=rpy, axis=axis, **kw)
         if kind != "fixed":
             joints.append("j%d" % i)
-            if kind in ("revolute", "prismatic") and "mimic" not in kw:
-                moving.append("j%d" % i)
+            if kind in ("revolute", "prismatic"):
+                mimicable.append("j%d" % i)
+                if "mimic" not in kw:
+                    moving.append("j%d" % i)
     return m, joints, n
 
 
@@ -110,7 +112,7 @@ def main():
         model, joints, n = random_robot(rng, case)
         if not joints:
             continue
-        tips = walk_order(model, sorted(int(t) for t in rng.choice(np.arange(1, n), size=min(int(rng.integers(1, 4)), n - 1), replace=False)))
+        tips = walk_order(model, sorted(int(t) for t in rng.choice(np.arange(1, n), size=min(int(rng.integers(1, 7 if os.environ.get("ROBOT_FUZZ_BIG") else 4)), n - 1), replace=False)))
         model.add_group("g", joints=joints, tips=["l%d" % t for t in tips])
         goals = []
         for t in tips:  # (the order in which the walk completes them: the order in which device and reference add the same sum)
