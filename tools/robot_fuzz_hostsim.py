@@ -2,7 +2,7 @@
 branches at any depth, tips on inner links, on fixed links and off the root, fixed_joints -- with goals listed in walk order, in the host simulator
 (tests/hostsim) against the CPU oracle.  Twice per robot: the unfolded joint program (BIOIK_COMPILE_EXACT=1, bioik_compile.cpp), where FK, fitness, tables,
 success test and a whole solve must be the oracle's bit for bit on ANY robot, and the default (folded) program, which must agree to rounding (1e-12).
-ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead; ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips.  (Floating / planar joints are not drawn:
+ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead; ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).  (Floating / planar joints are not drawn:
 their unbounded variables need a sampler of their own; tests/test_*_parity.py: test_floating_and_planar_joints_anywhere covers them on fixtures.)
 usage: python tools/robot_fuzz_hostsim.py [cases] [seed]   (seconds per case; exit code 1 on a mismatch)"""
 import os
@@ -30,7 +30,7 @@ def unit(rng, n):
 def random_robot(rng, case):
     m = RobotModel("r%d" % case)
     m.add_link("l0")
-    n = int(rng.integers(4, 15)) if not os.environ.get("ROBOT_FUZZ_BIG") else int(rng.integers(12, 31))  # (ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips)
+    n = int(rng.integers(4, 15)) if not os.environ.get("ROBOT_FUZZ_BIG") else int(rng.integers(12, 31))  # (ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).
     joints, moving, mimicable = [], [], []
     for i in range(1, n):
         parent = "l%d" % (i - 1 if rng.random() < 0.7 else int(rng.integers(0, i)))
@@ -46,6 +46,8 @@ def random_robot(rng, case):
             kw["velocity"] = float(rng.uniform(0.3, 3.0))
             if moving and kind in ("revolute", "prismatic") and rng.random() < 0.12:
                 kw["mimic"] = (str(rng.choice(mimicable)), float(rng.choice([1.0, -0.5, 2.0])), float(rng.choice([0.0, 0.1])))  # (also of a joint that mimics another)
+        if os.environ.get("ROBOT_FUZZ_BALANCE") and rng.random() < 0.6:  # (ROBOT_FUZZ_BALANCE=1: links with mass, a BalanceGoal among the goals)
+            kw["mass"], kw["com"] = float(rng.uniform(0.2, 3.0)), tuple(rng.normal(size=3) * 0.05)
         m.add_link("l%d" % i, parent, "j%d" % i, kind, xyz=xyz, rpy=rpy, axis=axis, **kw)
         if kind != "fixed":
             joints.append("j%d" % i)
@@ -123,6 +125,9 @@ def main():
                               MaxDistanceGoal(link, p, 0.3, weight=w), MinDistanceGoal(link, p, 0.3, weight=w), LineGoal(link, p, unit(rng, 3), weight=w),
                               PlaneGoal(link, p, unit(rng, 3), weight=w), LookAtGoal(link, unit(rng, 3), p, weight=w), SideGoal(link, unit(rng, 3), unit(rng, 3), weight=w),
                               DirectionGoal(link, unit(rng, 3), unit(rng, 3), weight=w), ConeGoal(link, unit(rng, 3), unit(rng, 3), 0.4, weight=w)][k])
+        if os.environ.get("ROBOT_FUZZ_BALANCE") and sum(model.link_mass) > 0:
+            from bio_ik_amd import BalanceGoal
+            goals.append(BalanceGoal(tuple(rng.normal(size=3) * 0.1), weight=float(rng.choice([0.4, 1.0]))))
         for _ in range(int(rng.integers(0, 3))):
             k, w, sec = int(rng.integers(5)), float(rng.choice([0.1, 0.5])), bool(rng.random() < 0.5)
             if k == 0:
