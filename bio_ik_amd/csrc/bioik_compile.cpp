@@ -281,9 +281,10 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     // alone -- and the joint's op behind it carries the bare joint: parent o origin o joint in the reference's association (forward_kinematics.h:283-330), on
     // any robot.  About twice the ops; such a program is not a serial chain, so the kernels compiled for one do not run it.
     const bool exact_program = std::getenv("BIOIK_COMPILE_EXACT") != nullptr && std::atoi(std::getenv("BIOIK_COMPILE_EXACT")) != 0;
-    int some_joint_var = -1;
+    int some_joint_var = -1;  // (the variable a constant op of a FIXED link is filed under: any -- its value is multiplied by nought)
     for (int l : schedule)
         if (m->links[l].type != BIOIK_JOINT_FIXED && some_joint_var < 0) some_joint_var = m->links[l].first_var;
+    if (some_joint_var < 0 && D > 0) some_joint_var = active_variables[0];  // (every tip hangs off the root behind fixed links: the genes are goal variables off the chains)
     for (int l : schedule) {
         const HostModel::Link& L = m->links[l];
         int base_src = L.parent >= 0 ? src_of[L.parent] : -1;
@@ -365,7 +366,7 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
     std::vector<char> var_has_op(nv, 0);
     for (int k = 0; k < n_chain; k++) {
         if (ops[k].type < BIOIK_OP_FLOATING) {
-            var_has_op[ops[k].var] = 1;
+            if (ops[k].mimic_src != k) var_has_op[ops[k].var] = 1;  // (not the constant ops of BIOIK_COMPILE_EXACT: they read no variable)
             continue;
         }
         const int cnt = ops[k].type == BIOIK_OP_FLOATING ? 7 : 3;

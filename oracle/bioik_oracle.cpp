@@ -54,6 +54,7 @@ void orc_shared_sincos(size_t n, const double* x, double* s, double* c) {
     for (size_t i = 0; i < n; i++) bioik_sincos(x[i], s + i, c + i);
 }
 int orc_get_trig_mode(void) { return trig_mode(); }
+unsigned long long orc_debug_unbounded_candidates(void) { return unbounded_candidates().load(); }
 void orc_set_quirk_mode(int mode) { quirk_mode() = mode ? 1 : 0; }
 
 void* orc_model_create(const bioik_model_desc* desc) {

@@ -42,6 +42,8 @@ void orc_set_trig_mode(int mode);
 /* the sincos shared with the device kernels (bio_ik_amd/csrc/bioik_sincos.h), exposed for its accuracy test */
 void orc_shared_sincos(size_t n, const double* x, double* s, double* c);
 int orc_get_trig_mode(void);
+/* diagnostics (soaks): candidates of the memetic line search with a gene at +-DBL_MAX so far -- an infinite step on a joint without limits (orc_model.h) */
+unsigned long long orc_debug_unbounded_candidates(void);
 /* 0: quirks Q1 (stale masked tips), Q4 (unstable pre-selection sort) and Q5 (the line search accepts a candidate with NaN genes, orc_evolution.h) fixed, as on the device (default);
  * 1: literal reference behaviour, for the trajectory comparison against oracle/_ref (orc_model.h) */
 void orc_set_quirk_mode(int mode);

@@ -17,6 +17,7 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <limits>
 #include <vector>
 
@@ -327,6 +328,8 @@ struct Evolution2 {
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] + gradient[i] * step_size, problem->active_variables[i]);
                         if (candidate_has_nan) break;  // (Q5, default mode)
+                        for (size_t i = 0; i < D(); i++)
+                            if (std::fabs(gw[i]) >= 1e300) unbounded_candidates()++;
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {
@@ -343,6 +346,8 @@ struct Evolution2 {
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] - gradient[i] * step_size, problem->active_variables[i]);
                         if (candidate_has_nan) break;  // (Q5, default mode)
+                        for (size_t i = 0; i < D(); i++)
+                            if (std::fabs(gw[i]) >= 1e300) unbounded_candidates()++;
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {

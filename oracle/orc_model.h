@@ -4,6 +4,7 @@
 // :553-731 (analytic Jacobian), :783-1234 (mutation approximator), reading the flat model of
 // include/bioik_hip.h instead of moveit::core::RobotModel (MoveIt is not on disk).
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <cfloat>
 #include <stdexcept>
@@ -24,6 +25,13 @@ namespace orc {
 inline int& quirk_mode() {
     static int mode = 0;
     return mode;
+}
+// diagnostics for the soaks (tools/robot_fuzz_hostsim.py): how many candidates of the memetic line search had a gene clipped to +-DBL_MAX -- an infinite step
+// (curvature 0, slope not) on a joint WITHOUT limits.  The model is then evaluated at 1.8e308, where it overflows; what comes out is garbage in the reference
+// as here, and the kernels' fused arithmetic overflows along another path, so such a solve is not comparable bit for bit
+inline std::atomic<unsigned long long>& unbounded_candidates() {
+    static std::atomic<unsigned long long> n{0};
+    return n;
 }
 
 struct Link {

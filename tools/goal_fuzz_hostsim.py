@@ -86,6 +86,9 @@ def main():
         try:
             t = ProblemTemplate(model, group, goals, fixed_joints=fixed)
             h, o = solver.HipSolver(t, lib=lib), orc.Oracle(t)
+            if o.D == 0:  # (the fixed joint was the only one that moves a goal's link)
+                print("%-3d skip %s (no active variable)" % (case, desc), flush=True)
+                continue
             pc.function_level(h, o, model, np.random.default_rng(case), n=24, exact_bits=True)
             mode = str(rng.choice(["bio2", "bio2_memetic", "bio2_memetic_l"]))
             fk = int(rng.choice([abi.FK_EXACT, abi.FK_LINEAR]))

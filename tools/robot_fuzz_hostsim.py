@@ -92,9 +92,13 @@ def whole_solve(h, o, t, pop, steps, mode, fk, case):
     from bio_ik_amd.workload import make_queries
     seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2, seed=case)
     p = abi.default_solve_params(population=pop, max_steps=steps, random_seed=11, mode=mode, fk_mode=fk, islands=1 + case % 2)
+    import ctypes
+    count = orc.lib().orc_debug_unbounded_candidates
+    count.restype = ctypes.c_ulonglong
+    before = count()
     sa = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=4)
     sb = h.solve_batch(p, seeds, params)
-    if (np.abs(sa[0]) > 1e300).any() or (np.abs(sb[0]) > 1e300).any():
+    if count() != before or (np.abs(sa[0]) > 1e300).any() or (np.abs(sb[0]) > 1e300).any():
         # an INFINITE step of the line search (its quadratic model has no curvature: v / 0) clips a joint WITHOUT limits to +-DBL_MAX, in the reference as here
         # (utils.h:328-333, robot_info.h: clip_max = DBL_MAX); the linear model is then evaluated at 1.8e308, where it overflows -- along one path in the oracle,
         # along another (fused) one in the kernels.  Either value is garbage, either side may accept it: not compared
