@@ -439,7 +439,9 @@ HostProblem::HostProblem(const HostModel* m, const bioik_problem_desc& d) : mode
         }
         ops[k].mimic_src = value_op_of_var[sv];
     }
-    if ((int)ops.size() > BIOIK_MAX_OPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 moving joints on the goal chains");
+    if ((int)ops.size() > BIOIK_MAX_OPS)
+        throw Error(BIOIK_ERR_UNSUPPORTED, exact_program ? "more than 64 ops in the unfolded joint program (BIOIK_COMPILE_EXACT: an op per origin and per joint)"
+                                                         : "more than 64 moving joints on the goal chains");
     if ((int)tip_links.size() > BIOIK_MAX_TIPS) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 64 tip links");
     if (n_balance_goals > BIOIK_MAX_BALANCE) throw Error(BIOIK_ERR_UNSUPPORTED, "more than 4 BalanceGoals");
     for (size_t k = 0; k < ops.size(); k++) {
