@@ -2,7 +2,7 @@
 branches at any depth, tips on inner links, on fixed links and off the root, fixed_joints -- with goals listed in walk order, in the host simulator
 (tests/hostsim) against the CPU oracle.  Twice per robot: the unfolded joint program (BIOIK_COMPILE_EXACT=1, bioik_compile.cpp), where FK, fitness, tables,
 success test and a whole solve must be the oracle's bit for bit on ANY robot, and the default (folded) program, which must agree to rounding (1e-12).
-ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead; ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).  (Floating / planar joints are not drawn:
+ROBOT_FUZZ_GRADIENT=1: every third robot is solved by a point solver of the gradient family (gd / gd_r / gd_c) instead; ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_PLAIN=1: trees whose default program folds exactly (unrotated origins, no prismatic joint, fixed links without offset) -- the DEFAULT program bit for bit, populations 16 ... 200; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).  (Floating / planar joints are not drawn:
 their unbounded variables need a sampler of their own; tests/test_*_parity.py: test_floating_and_planar_joints_anywhere covers them on fixtures.)
 usage: python tools/robot_fuzz_hostsim.py [cases] [seed]   (seconds per case; exit code 1 on a mismatch)"""
 import os
@@ -30,13 +30,19 @@ def unit(rng, n):
 def random_robot(rng, case):
     m = RobotModel("r%d" % case)
     m.add_link("l0")
-    n = int(rng.integers(4, 15)) if not os.environ.get("ROBOT_FUZZ_BIG") else int(rng.integers(12, 31))  # (ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).
+    n = int(rng.integers(4, 15)) if not os.environ.get("ROBOT_FUZZ_BIG") else int(rng.integers(12, 31))  # (ROBOT_FUZZ_BIG=1: 12 - 30 links, up to six tips; ROBOT_FUZZ_PLAIN=1: trees whose default program folds exactly (unrotated origins, no prismatic joint, fixed links without offset) -- the DEFAULT program bit for bit, populations 16 ... 200; ROBOT_FUZZ_BALANCE=1: links with mass and a BalanceGoal (whose sum over the links the device takes in walk order: agreement to rounding, DESIGN.md section 7 -- the strict comparison of this tool then reports it).
     joints, moving, mimicable = [], [], []
     for i in range(1, n):
         parent = "l%d" % (i - 1 if rng.random() < 0.7 else int(rng.integers(0, i)))
         kind = str(rng.choice(["revolute", "revolute", "revolute", "continuous", "prismatic", "fixed"]))
         xyz = tuple(rng.normal(size=3) * 0.15) if rng.random() < 0.8 else (0.0, 0.0, 0.0)
         rpy = tuple(rng.normal(size=3) * 0.6) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
+        if os.environ.get("ROBOT_FUZZ_PLAIN"):  # (ROBOT_FUZZ_PLAIN=1: trees whose DEFAULT joint program folds exactly -- no rotated origin, no prismatic joint, fixed links without offset)
+            rpy = (0.0, 0.0, 0.0)
+            if kind == "prismatic":
+                kind = "revolute"
+            if kind == "fixed":
+                xyz = (0.0, 0.0, 0.0)
         axis = unit(rng, 3) if rng.random() < 0.5 else tuple(np.eye(3)[int(rng.integers(3))])
         kw = {}
         if kind in ("revolute", "prismatic"):
@@ -166,6 +172,13 @@ def main():
             if o.D == 0:
                 skipped += 1
                 print("%-3d skip %s (no active variable)" % (case, desc), flush=True)
+                continue
+            if os.environ.get("ROBOT_FUZZ_PLAIN"):  # the default program itself, bit for bit, populations up to the lane counts of the kernels compiled for one mapping
+                os.environ["BIOIK_COMPILE_EXACT"] = "0"
+                h = solver.HipSolver(t, lib=lib)
+                pc.function_level(h, o, model, np.random.default_rng(case), n=16, exact_bits=True)
+                nan_note = whole_solve(h, o, t, int(rng.choice([16, 64, 128, 200])), steps, mode, fk, case)
+                print("%-3d ok   %s%s" % (case, desc, nan_note), flush=True)
                 continue
             os.environ["BIOIK_COMPILE_EXACT"] = "1"
             h = solver.HipSolver(t, lib=lib)
