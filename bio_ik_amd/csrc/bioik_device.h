@@ -146,13 +146,16 @@ BIOIK_DEV void revolute_apply(F7 (&f)[N], const double (&sn)[N], const double (&
 // post-processing, so that the device and the CPU restatement used by the tests produce bit-identical doubles.
 // ---------------------------------------------------------------------------------------------------------
 enum { RNG_REPRODUCE = 0, RNG_PRESELECT = 1, RNG_MEMETIC_SIGN = 2, RNG_WIPEOUT = 3, RNG_WIPEOUT_GENE = 4, RNG_POINT_RANDOM = 5 };
-// Random words of child c in one generation -- the bulk of all draws, 1 + D words per child -- come from a two-multiply
-// avalanche hash of the counter instead of Philox (a Philox2x32-10 call is twenty 32-bit multiplies, and an integer multiply
-// costs 2.4 issue slots of an FP64 FMA on gfx950: profiles/r01_gfx950_latency_microbench.log):
-//     word w = mix32( ((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77) ),   mix32 = MurmurHash3's 32-bit finaliser
-// The stream value mix32(key ^ ...) is wavefront-uniform (scalar unit), (c << 8) * 0x9E3779B1 is per child, w * 0x9E3779B1 per
-// word and uniform: a word costs one add and the finaliser.  Word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g.
-// Philox2x32-10 keeps the control draws (query key, pre-selection count, memetic sign, wipe-out).
+// Random words of child c in one generation -- the bulk of all draws, 1 + D words per child -- come from avalanche hashes of the counter instead of
+// Philox (a Philox2x32-10 call is twenty 32-bit multiplies).  Round 6 (profiles/r06_issue_cost.log: on a SIMD that has several wavefronts to choose from, a
+// 32-bit multiply takes the slot of an FP64 FMA, a VOP2 shift or xor half of one -- a gene's draw costs what its instructions COUNT):
+//     stream        = mix32(key ^ ctr1 * 0x85EBCA77)                      wavefront-uniform (scalar unit), one per species and generation
+//     base of child = mix32((c << 8) * 0x9E3779B1 + stream)               one FULL avalanche per child: children share nothing
+//     word w >= 1   = mix1(base + w * 0x9E3779B1)                          one multiply per word: the words of ONE child are the lighter hash of a Weyl sequence
+//                                                                          that starts at the child's own random point
+// mix32 = MurmurHash3's 32-bit finaliser (two multiplies), mix1 = its first half (xor-shift 16, * 0x85EBCA6B, xor-shift 13).  The child's base is its word 0:
+// its top four bits are the mutation-rate exponent; word 1 + g -> the Gaussian of gene g.  (Until round 5 every word was a mix32 of the counter: five more
+// instructions per gene.)  Philox2x32-10 keeps the control draws (query key, pre-selection count, memetic sign, wipe-out).
 BIOIK_DEV uint32_t rng_mix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -161,7 +164,16 @@ BIOIK_DEV uint32_t rng_mix32(uint32_t h) {
     h ^= h >> 16;
     return h;
 }
+BIOIK_DEV uint32_t rng_mix1(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h;
+}
 BIOIK_DEV uint32_t rng_child_stream(uint32_t key, uint32_t ctr1) { return rng_mix32(key ^ (ctr1 * 0x85EBCA77u)); }
+BIOIK_DEV uint32_t rng_child_base(uint32_t stream, uint32_t child) { return rng_mix32((child << 8) * 0x9E3779B1u + stream); }  // word 0 of the child
+BIOIK_DEV uint32_t rng_child_word(uint32_t base, uint32_t w) { return rng_mix1(base + w * 0x9E3779B1u); }                   // word w >= 1
+BIOIK_DEV double rng_child_rate(uint32_t base) { return (double)(1u << (base >> 28)) * (1.0 / (double)(1 << 23)); }           // ik_evolution_2.cpp:283 with the counter's exponent
 
 BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
 #pragma unroll
@@ -177,21 +189,12 @@ BIOIK_DEV void philox2x32_10(uint32_t key, uint32_t c0, uint32_t c1, uint32_t& o
 }
 BIOIK_DEV uint32_t rng_ctr0(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
 BIOIK_DEV uint32_t rng_ctr1(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
-// ~N(0,1) from ONE 32-bit word: Binomial(16,1/2) lattice (popcount of the low half) + triangular jitter (sum of the two
-// high bytes) -> continuous piecewise-linear density, integer-only up to one exact conversion and one rounding
-BIOIK_DEV double rng_gauss32(uint32_t x) {
-#if defined(BIOIK_GAUSS_TWO_CONVERSIONS)  // the definition, term by term (what the CPU restatements of the tests evaluate)
-    int k = p_popc(x & 0xffffu) - 8;
-    uint32_t s = ((x >> 16) & 0xffu) + (x >> 24);
-    double t = (double)s * (1.0 / 256.0) - 1.0;
-    return ((double)k + t) * 0.4898979485566356;  // 1 / sqrt(4 + 1/6)
-#else
-    // the same number from ONE integer and ONE conversion: (k - 8) + s / 256 - 1 = (256 k + s - 2304) / 256 is exact in either form,
-    // and scaling the constant by 2^-8 is exact too, so the single rounding of the product is the same rounding
-    const int v = (p_popc(x & 0xffffu) << 8) + (int)(((x >> 16) & 0xffu) + (x >> 24)) - 2304;
-    return (double)v * (0.4898979485566356 / 256.0);
-#endif
-}
+// ~N(0,1) from ONE 32-bit word: the sum of its four bytes (Irwin-Hall, n = 4: mean 510, variance 4 (256^2 - 1) / 12 = 21845 -- unit variance after the scaling,
+// support +-3.451, a piecewise-cubic density, distribution function within 0.84 % of the normal one everywhere, kurtosis 2.70; tests/test_oracle_rng.py
+// enumerates it).  Three instructions -- v_sad_u8 against zero with -510 as its addend, one exact conversion, one rounding -- where the Binomial(16) lattice
+// with triangular jitter of rounds 1 - 5 took eight.
+#define BIOIK_GAUSS_SCALE 0.006765875086793228 /* 1 / sqrt(21845) */
+BIOIK_DEV double rng_gauss32(uint32_t x) { return (double)p_byte_sum(x, -510) * BIOIK_GAUSS_SCALE; }
 BIOIK_DEV double rng_uniform(uint32_t x0, uint32_t x1) {
     uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;
     return (double)u * (1.0 / 9007199254740992.0);
@@ -576,7 +579,7 @@ BIOIK_DEV double secondary_fitness(ProbPtr pb, const XA& x, const QueryCtx& qc) 
 }
 // the same for N individuals at once (see goal_eval_joint_set_xn); per individual: the goals in their order, each weighted as above
 // AvoidJointLimitsGoal (goal_types.h:387-401) costs a variable nothing while it stays in the middle half of its range: |x - mid| * 2 <= span / 2.  A child's
-// gene is parent_gene + gauss * rate * span + parent_gradient * factor with |gauss| <= 4.41 (rng_gauss32: 2304 lattice steps of 0.4899 / 256), rate <= 2^-8
+// gene is parent_gene + gauss * rate * span + parent_gradient * factor with |gauss| <= 4.41 (rng_gauss32: 3.451 since round 6, 4.41 = the bound of the lattice Gaussian of rounds 1 - 5), rate <= 2^-8
 // (ChildX: 2^(15 - 23)) and factor <= 2, clipped towards the inside afterwards: whenever the parent's gene is further inside the free zone than
 // 0.0173 span + 2 |parent_gradient| (+ a margin far above any rounding), EVERY child of the generation has that gene in the free zone.  True for about half
 // the genes of a typical elite -- and for those the pre-selection need not generate the children's values at all.
@@ -1232,11 +1235,11 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
     const uint32_t stream = rng_child_stream(key, ctr1);
     uint32_t base[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) base[i] = (child_index[i] << 8) * 0x9E3779B1u + stream;
+    for (int i = 0; i < N; i++) base[i] = rng_child_base(stream, child_index[i]);
     for (int w0 = 0; D > 0 && w0 <= D; w0 += 8) {  // (a problem whose variables are all fixed has no gene to draw)
         if (w0 == 0) {
 #pragma unroll
-            for (int i = 0; i < N; i++) mutation_rate[i] = (double)(1u << (rng_mix32(base[i]) & 15u)) * (1.0 / (double)(1 << 23));
+            for (int i = 0; i < N; i++) mutation_rate[i] = rng_child_rate(base[i]);
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -1253,7 +1256,7 @@ BIOIK_DEV void reproduce_children(PB pb, uint32_t key, uint32_t ctr1, const uint
                 const double parent_gene = p0g[k], d0 = p0d[k], d1 = p1d[k];
 #pragma unroll
                 for (int i = 0; i < N; i++) {
-                    const uint32_t word = rng_mix32(base[i] + (uint32_t)(w0 + w) * 0x9E3779B1u);
+                    const uint32_t word = rng_child_word(base[i], (uint32_t)(w0 + w));
                     double r = rng_gauss32(word);
                     double f = mutation_rate[i] * span;
                     double gn = parent_gene;
@@ -1297,7 +1300,7 @@ template <class PB>
 struct ChildX {
     PB pb;
     const double *p0g, *p0d, *p1d;  // LDS, op-indexed: genes of parent 0, momentum of parents 0 and 1
-    uint32_t base;                  // (child << 8) * 0x9E3779B1 + stream
+    uint32_t base;                  // the child's word 0 (rng_child_base)
     double mutation_rate, fmix, gradient_factor;
     // UNIFORM: the op index is the same in every lane of the wavefront (a loop counter of the chain walk): the clip range then comes as scalar operands
     // (p_clamp_uniform); false where lane k asks for op k (the winners' re-derivation): the same two instructions on vector operands
@@ -1309,7 +1312,7 @@ struct ChildX {
         if (g < 0) return parent_gene;  // inactive op: the seed's value, carried by every elite
         const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
         const double d0 = p0d[k], d1 = p1d[k];
-        const uint32_t word = rng_mix32(base + (uint32_t)(g + 1) * 0x9E3779B1u);
+        const uint32_t word = rng_child_word(base, (uint32_t)(g + 1));
         double r = rng_gauss32(word);
         double f = mutation_rate * span;
         double gn = parent_gene;
@@ -1330,8 +1333,8 @@ template <class PB>
 BIOIK_DEV ChildX<PB> make_child_x(PB pb, uint32_t key, uint32_t ctr1, uint32_t child_index, const double* p0g, const double* p0d, const double* p1d) {
     ChildX<PB> c;
     c.pb = pb, c.p0g = p0g, c.p0d = p0d, c.p1d = p1d;
-    c.base = (child_index << 8) * 0x9E3779B1u + rng_child_stream(key, ctr1);
-    c.mutation_rate = (double)(1u << (rng_mix32(c.base) & 15u)) * (1.0 / (double)(1 << 23));
+    c.base = rng_child_base(rng_child_stream(key, ctr1), child_index);
+    c.mutation_rate = rng_child_rate(c.base);
     c.fmix = (child_index % 2u == 0u) ? 0.2 : 0.0;
     c.gradient_factor = (double)(child_index % 3u);
     return c;
@@ -1358,7 +1361,7 @@ struct ChildT {
         const double parent_gene = p0g[k];
         if (g < 0) return parent_gene;
         const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
-        const uint32_t word = rng_mix32(base + (uint32_t)(g + 1) * 0x9E3779B1u);
+        const uint32_t word = rng_child_word(base, (uint32_t)(g + 1));
         double r = rng_gauss32(word);
         double f = mutation_rate * span;
         double gn = parent_gene;
@@ -1375,8 +1378,8 @@ BIOIK_DEV ChildT<PB> make_child_t(PB pb, uint32_t key, uint32_t ctr1, uint32_t c
     ChildT<PB> c;
     c.pb = pb, c.p0g = p0g;
     c.pgrow = pgtable + (int)(child_index % 2u) * M;
-    c.base = (child_index << 8) * 0x9E3779B1u + rng_child_stream(key, ctr1);
-    c.mutation_rate = (double)(1u << (rng_mix32(c.base) & 15u)) * (1.0 / (double)(1 << 23));
+    c.base = rng_child_base(rng_child_stream(key, ctr1), child_index);
+    c.mutation_rate = rng_child_rate(c.base);
     c.gradient_factor = (double)(child_index % 3u);
     return c;
 }

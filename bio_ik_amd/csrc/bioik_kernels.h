@@ -17,6 +17,9 @@
 #include "bioik_device.h"
 
 
+#ifndef BIOIK_CANDIDATE_BOUND
+#define BIOIK_CANDIDATE_BOUND 1e300  // a candidate of the memetic line search with a gene of this magnitude or more is no candidate (quirk Q7; the oracle's default mode has the same bound)
+#endif
 #ifndef BIOIK_COOP_WALKS
 #define BIOIK_COOP_WALKS 1  // single-individual walks of the solver share the joints' trigonometry over the lanes (fk_walk<COOP>); 0: every lane repeats it
 #endif
@@ -1552,6 +1555,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                     for (int k = gtid; k < n_ops; k += Gw) s_gop[k] = 0.0;
                     const bool odd = gtid & 1;
                     bool descending = true;
+                    double f2p = 0.0, fa = 0.0;  // primary fitness / all goals at the elite, as the last gradient round left them
                     for (int it = 0; it < 8 && descending; it++) {
                         PHASE_COUNT(PH_N_MEM_ITER);
                         // three rounds of the same shape -- op lanes prepare displacement vectors, component lanes run the chains, every
@@ -1559,9 +1563,15 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         //   round 0  gradient (:450-475): D + 1 evaluations, one per lane
                         //   round 1  L1 normalisation (:477-482) and the two support points x - g (even lanes), x + g (odd lanes) (:485-495)
                         //   round 2  step along the gradient (:498-568), clipped candidate, acceptance on primary fitness
-                        double f2p = 0.0, fa = 0.0, fnorm = 0.0;
+                        // Round 6: round 2 IS the next iteration's round 0.  An accepted candidate becomes the elite, and the gradient round that follows evaluates
+                        // that very vector (lane D) and the D vectors with one gene advanced by dp (lanes i < D) -- on the candidate's frames, which round 2 has
+                        // just built: the same displacements x4 - base, the same chains, the same goals.  So round 2 evaluates all D + 1 of them (a wavefront
+                        // instruction costs the same for one lane as for eight), lane D's primary fitness decides, and on acceptance the gradient of the next
+                        // iteration is already there: every iteration but the first is two rounds instead of three.  A rejected candidate's gradient is dropped
+                        // (the species stops).  Same operations on the same operands: the same bits.
+                        double fnorm = 0.0;
                         bool nan_gene = false;  // (round 2: a gene of the candidate is not a number)
-                        for (int round = 0; round < 3; round++) {
+                        for (int round = it == 0 ? 0 : 1; round < 3; round++) {
                             double* dv0 = s_dv + (round == 0 ? 0 : round == 1 ? 1 : 3) * M;
                             double* fc0 = (L.fc >= 0 ? s_fc : popS + (S.cur ^ 1) * BF) + (round == 0 ? 0 : round == 1 ? 1 : 3) * FB;  // (make_layout: fc_in_pop)
                             if (round == 0) {
@@ -1595,14 +1605,17 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 // fails the comparison below: the search stops.  fmin / fmax would make the lower limit of a NaN (-DBL_MAX for a joint without
                                 // limits) and the candidate a jump there; so a candidate with a NaN gene is no candidate.  (Where a goal hides the NaN -- max(0, .)
                                 // of its error -- the literal reference ACCEPTS the NaN genes and can return them: quirk Q5)
+                                // A step without bound -- v / 0 of a model without curvature -- puts a joint WITHOUT limits at its clip range's end, +-DBL_MAX
+                                // (robot_info.h:109-113), where the linear model overflows; the literal reference may accept that vector and return it (quirk Q7,
+                                // DESIGN.md section 3).  A candidate with a gene of magnitude 1e300 or more is no candidate either: the search stops.
                                 bool nan_here = false;
                                 for (int k = gtid; k < n_ops; k += Gw) {
                                     const double e = el[k], gv = s_gop[k] * fnorm;
                                     const bool on = (active_mask >> k) & 1ull;
                                     const double raw = e + gv * step_size;
                                     const bool is_nan = on && !(raw == raw);
-                                    nan_here = nan_here || is_nan;
                                     const double x4 = (on && !is_nan) ? fmin(fmax(raw, s_clip[k]), s_clip[M + k]) : e;
+                                    nan_here = nan_here || is_nan || (on && fabs(x4) >= BIOIK_CANDIDATE_BOUND);
                                     s_x4[k] = x4;
                                     dv0[k] = on ? x4 - s_base[k] : 0.0;
                                 }
@@ -1615,10 +1628,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                             double vprim, vall;
                             // what joint-value goals read: the lane's own vector -- in the gradient round the elite with its gene advanced by dp
                             // (computed where it is read, no column), else the shared support point / candidate
-                            const PerturbX xq{round == 0 ? el : (round == 2 ? s_x4 : (odd ? s_xp : s_xm)), round == 0 ? my_op : -1, round == 0 ? dp : 0.0};
-                            // (the vectors whose terms the lanes share: the elite, or the two support points -- even lanes read the first's sums, odd lanes the second's)
-                            const PerturbX xs{round == 0 ? el : s_xm, round == 0 ? my_op : -1, round == 0 ? dp : 0.0, round == 1 ? s_xp : nullptr};
-                            goals_on(fc0 + ((round == 1 && odd) ? FB : 0), round == 0 ? my_op : -1, round == 0 ? dp : 0.0, xq, vprim, vall, round != 2, xs,
+                            const bool grad_round = round != 1;  // (the candidate's round too: lanes i < D advance gene i on the candidate's frames)
+                            const PerturbX xq{round == 0 ? el : (round == 2 ? s_x4 : (odd ? s_xp : s_xm)), grad_round ? my_op : -1, grad_round ? dp : 0.0};
+                            // (the vectors whose terms the lanes share: the elite / the candidate, or the two support points -- even lanes read the first's sums, odd lanes the second's)
+                            const PerturbX xs{round == 0 ? el : (round == 2 ? s_x4 : s_xm), grad_round ? my_op : -1, grad_round ? dp : 0.0, round == 1 ? s_xp : nullptr};
+                            goals_on(fc0 + ((round == 1 && odd) ? FB : 0), grad_round ? my_op : -1, grad_round ? dp : 0.0, xq, vprim, vall, true, xs,
                                      s_tm + ((round == 1 && odd) ? 3 * M : 0));
                             PHASE_MARK(PH_MEM_SUPPORT_EVAL);
                             if (round == 0) {
@@ -1635,12 +1649,22 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                                 if (gtid < 2) s_ex[2 + gtid] = vall;
                                 p_wave_sync();
                             } else {
-                                const bool accept = !nan_gene && vprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
+                                if (gtid == D) s_ex[0] = vprim, s_ex[1] = vall;  // the candidate itself (the other lanes: the candidate with a gene advanced)
+                                p_wave_sync();
+                                const double cprim = s_ex[0], call = s_ex[1];
+                                const bool accept = !nan_gene && cprim < f2p;  // accept iff the primary fitness improves, else stop (:527-538)
                                 // (a half-wave group shares its wavefront with the other species: it stays in step with it and merely
-                                // repeats the rejected iteration, which changes nothing -- until the other species has stopped as well)
+                                // repeats the rejected iteration from its support points on, which changes nothing -- its elite, its gradient and the
+                                // fitness values that belong to them stay as they are -- until the other species has stopped as well)
                                 if (G >= 64 ? !accept : p_ballot(accept) == 0ull) descending = false;
-                                if (accept)
+                                if (accept) {
                                     for (int k = gtid; k < n_ops; k += Gw) el[k] = s_x4[k];
+                                    f2p = cprim, fa = call;  // the candidate is the elite: what the gradient round of the next iteration would compute
+                                    if (my_op >= 0) {
+                                        s_grad[gtid] = vall - call;
+                                        s_gop[my_op] = vall - call;
+                                    }
+                                }
                                 p_wave_sync();
                                 PHASE_MARK(PH_MEM_ACCEPT);
                             }

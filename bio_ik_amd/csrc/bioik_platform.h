@@ -118,6 +118,7 @@ BIOIK_DEV double p_clamp(double x, double lo, double hi) {
 }
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
+BIOIK_DEV int p_byte_sum(uint32_t v, int addend) { return (int)__builtin_amdgcn_sad_u8(v, 0u, (uint32_t)addend); }  // the four bytes of v + addend: v_sad_u8 against zero
 BIOIK_DEV int p_popc64(unsigned long long v) { return __popcll(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock
 BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned long long value) {  // first caller's value wins; returns the winner

@@ -25,6 +25,10 @@
 #include "orc_problem.h"
 #include "orc_rng.h"
 
+#ifndef ORC_CANDIDATE_BOUND
+#define ORC_CANDIDATE_BOUND 1e300  // (bioik_kernels.h: BIOIK_CANDIDATE_BOUND)
+#endif
+
 namespace orc {
 
 struct Individual {
@@ -85,7 +89,11 @@ struct Evolution2 {
             candidate_has_nan = true;
             return p;
         }
-        return model->clip(p, var);
+        const double c = model->clip(p, var);
+        // (quirk Q7: a step without bound clips a joint WITHOUT limits to +-DBL_MAX, robot_info.h:109-113; the default mode takes a candidate with a gene of
+        // magnitude 1e300 or more for no candidate, as the device does -- mode 1 keeps it and evaluates the linear model there, as the reference does)
+        if (quirk_mode() == 0 && std::fabs(c) >= ORC_CANDIDATE_BOUND) candidate_has_nan = true;
+        return c;
     }
     double primary_fitness(const Frame* frames, const double* genes) { return problem->compute_goal_fitness(problem->goals, query, frames, genes); }
     double combined_fitness(const Frame* frames, const double* genes) {

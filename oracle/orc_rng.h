@@ -59,12 +59,14 @@ inline void philox4x32_10(const uint32_t* key2, const uint32_t* ctr4, uint32_t* 
 
 // counter layout and integer->double post-processing
 enum { PURPOSE_REPRODUCE = 0, PURPOSE_PRESELECT = 1, PURPOSE_MEMETIC_SIGN = 2, PURPOSE_WIPEOUT = 3, PURPOSE_WIPEOUT_GENE = 4, PURPOSE_POINT_RANDOM = 5 };
-// random words of child c in one generation (the bulk of all draws: 1 + D words per child):
-//     word w = mix32( ((c << 8) + w) * 0x9E3779B1 + mix32(key ^ ctr1 * 0x85EBCA77) )
+// random words of child c in one generation (the bulk of all draws: 1 + D words per child; bioik_device.h states the same, round 6's form):
+//     stream        = mix32(key ^ ctr1 * 0x85EBCA77)
+//     base of child = mix32((c << 8) * 0x9E3779B1 + stream)        = the child's word 0; its top four bits are the mutation-rate exponent
+//     word w >= 1   = mix1(base + w * 0x9E3779B1)                   word 1 + g -> Gaussian of gene g
 // mix32 = the 32-bit finaliser of MurmurHash3 (Appleby, public domain: xor-shift 16, * 0x85EBCA6B, xor-shift 13, * 0xC2B2AE35,
-// xor-shift 16 -- every input bit flips every output bit with probability ~1/2).  The odd multiplier makes the inner value
-// a bijection of (c, w) for a given stream (key, ctr1), so no two words of a generation share their input.
-// word 0 -> mutation-rate exponent, word 1 + g -> Gaussian of gene g
+// xor-shift 16 -- every input bit flips every output bit with probability ~1/2); mix1 = its first half (one multiply).  Both are bijections, and
+// the odd multiplier makes the value under the child's mix32 a bijection of c for a given stream (key, ctr1): no two children share a base, no
+// two words of a child their input.
 inline uint32_t mix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -73,19 +75,26 @@ inline uint32_t mix32(uint32_t h) {
     h ^= h >> 16;
     return h;
 }
+inline uint32_t mix1(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h;
+}
 inline uint32_t child_stream(uint32_t key, uint32_t ctr1) { return mix32(key ^ (ctr1 * 0x85EBCA77u)); }
-inline uint32_t child_word_of(uint32_t stream, uint32_t child, uint32_t w) { return mix32(((child << 8) + w) * 0x9E3779B1u + stream); }
+inline uint32_t child_word_of(uint32_t stream, uint32_t child, uint32_t w) {
+    const uint32_t base = mix32((child << 8) * 0x9E3779B1u + stream);
+    return w == 0 ? base : mix1(base + w * 0x9E3779B1u);
+}
 
 inline uint32_t ctr0_of(uint32_t child, uint32_t slot) { return (child << 8) | slot; }
 inline uint32_t ctr1_of(uint32_t generation, uint32_t species, uint32_t purpose) { return (generation << 4) | (species << 3) | purpose; }
 
-// approximately N(0,1) from ONE 32-bit word: Binomial(16,1/2) lattice (popcount of the low half) + triangular jitter on
-// [-1,1) (sum of the two high bytes) -> continuous piecewise-linear density
+// approximately N(0,1) from ONE 32-bit word: the sum of its four bytes (Irwin-Hall, n = 4), centred and scaled to unit variance:
+// mean 510, variance 4 (256^2 - 1) / 12 = 21845
 inline double counter_gauss_from32(uint32_t x) {
-    int k = __builtin_popcount(x & 0xffffu) - 8;
-    uint32_t s = ((x >> 16) & 0xffu) + (x >> 24);
-    double t = (double)s * (1.0 / 256.0) - 1.0;
-    return ((double)k + t) * 0.4898979485566356;  // 1/sqrt(4 + 1/6)
+    const int v = (int)((x & 255u) + ((x >> 8) & 255u) + ((x >> 16) & 255u) + (x >> 24)) - 510;
+    return (double)v * 0.006765875086793228;  // 1 / sqrt(21845)
 }
 inline double counter_uniform_from(uint32_t x0, uint32_t x1) {
     uint64_t u = (((uint64_t)x0 << 32) | (uint64_t)x1) >> 11;
@@ -111,7 +120,7 @@ struct CounterRandom {
     uint32_t child_word(size_t child_index, uint32_t w) {
         return child_word_of(child_stream(key, ctr1_of(generation, species, PURPOSE_REPRODUCE)), (uint32_t)child_index, w);
     }
-    unsigned rate_exponent(size_t child_index) { return child_word(child_index, 0) & 15u; }
+    unsigned rate_exponent(size_t child_index) { return child_word(child_index, 0) >> 28; }
     double gauss(size_t child_index, size_t gene) { return counter_gauss_from32(child_word(child_index, (uint32_t)gene + 1u)); }
     void child_end(size_t /*gene_count*/) {}
     size_t preselect_count(size_t mu_, size_t lambda) {  // in [mu+1, mu+lambda-1]

@@ -99,6 +99,7 @@ BIOIK_DEV unsigned long long p_ballot(bool pred, int site = __builtin_LINE()) { 
     return m;
 }
 BIOIK_DEV int p_popc(uint32_t v) { return __builtin_popcount(v); }
+BIOIK_DEV int p_byte_sum(uint32_t v, int addend) { return (int)((v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24)) + addend; }
 BIOIK_DEV int p_popc64(unsigned long long v) { return __builtin_popcountll(v); }
 unsigned long long sim_wall_clock();  // 100 MHz ticks of a steady host clock (defined with the simulator's back end)
 BIOIK_DEV unsigned long long p_wall_clock() { return sim_wall_clock(); }

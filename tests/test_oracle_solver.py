@@ -21,7 +21,7 @@ def test_reproduce_matches_formula(oracles, templates):
     genes, grads = o.reproduce_counter(lam, key, sp, gen, parents)
     c1 = (gen << 4) | (sp << 3) | 0
     for c in range(2, 2 + lam):
-        k = orc.child_word(key, c1, c, 0) & 15  # random word 0 of the child
+        k = orc.child_word(key, c1, c, 0) >> 28  # random word 0 of the child (its base): the top four bits
         rate = (1 << k) * (1.0 / (1 << 23))
         fmix = 0.2 if c % 2 == 0 else 0.0
         gf = float(c % 3)
