@@ -345,6 +345,12 @@ public:
         // query-indexed random streams make the result independent of the split
         const size_t W = tk->handles.size();
         tk->tickets.assign(W, 0);
+        // gpu_islands: 0 (BIOIK_ISLANDS_AUTO) sizes the islands to the call: resolved ONCE per request, for the largest shard, so that every shard of a request
+        // that is cut over several devices runs the same solve (rows = 2049 on two devices would otherwise run 1024 queries on four islands and 1025 on one)
+        if (W > 1 && sp.islands <= 0 && rows > 0) {
+            int32_t isl = 1, sync = 0;
+            if (bioik_resolve_islands(tk->handles[0], &sp, (rows + W - 1) / W, &isl, &sync) == BIOIK_OK) sp.islands = isl, sp.island_sync = sync;
+        }
         const uint64_t first = settings_.gpu_reproducible_calls ? 0 : next_query_;
         next_query_ += rows;
         for (size_t r = 0; r < W; r++) {

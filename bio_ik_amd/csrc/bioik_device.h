@@ -50,7 +50,14 @@ BIOIK_DEV V3 normalized3(V3 a) {  // tf2: v * (1 / length)
 }
 BIOIK_DEV double qdot(Q4 a, Q4 b) { return bk_dot4(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
 BIOIK_DEV Q4 qinv(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
-BIOIK_DEV double clamped_acos(double x) { return acos(fmin(1.0, fmax(-1.0, x))); }
+// tf2Acos (tf2/LinearMath/Scalar.h): two comparisons that clamp the argument -- and let a NaN through, as the reference's does: acos(NaN) is NaN, and a goal that
+// takes max(0, .) of its angle then costs nothing.  (fmin / fmax would make -1 of the NaN and pi of the angle: what separated the kernels from the oracle on the
+// frames of a linear model evaluated at 1e308, profiles/r06_robot_fuzz_hostsim.log.)
+BIOIK_DEV double clamped_acos(double x) {
+    x = x < -1.0 ? -1.0 : x;
+    x = x > 1.0 ? 1.0 : x;
+    return bioik_acos(x);  // (the shared implementation, bioik_acos.h: the device library's and libm's differ in the last ulp)
+}
 BIOIK_DEV F7 f7_identity() { return F7{{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 1.0}}; }
 
 // rotate v by unit quaternion q (frame.h:108-149; its identity/zero short-cuts are arithmetic no-ops); fused form
@@ -1443,7 +1450,7 @@ BIOIK_DEV V3 kdl_get_rot(const double* d) {  // KDL::Rotation::GetRot
     double f = (d[0] + d[4] + d[8] - 1) / 2;
     double x = (d[7] - d[5]), y = (d[2] - d[6]), z = (d[3] - d[1]);
     double n = sqrt(x * x + y * y + z * z);
-    double angle = atan2(n / 2, f);
+    double angle = bioik_atan2(n / 2, f);
     return v3(x / n * angle, y / n * angle, z / n * angle);
 }
 // Twist(Ma^-1 * diff(pa,pb), Ma^-1 * diff(Ma,Mb)) of problem.cpp:281/300/321

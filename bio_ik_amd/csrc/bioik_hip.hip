@@ -128,22 +128,29 @@ static void be_fill_async(void* p, size_t bytes, int byte_value, stream_t s) {  
     HIP_CHECK(hipGetLastError());
 }
 __global__ void k_read_clock(unsigned long long* out) { *out = wall_clock64(); }
-// the device's constant 100 MHz clock as of "now" (a one-lane kernel on a stream of its own and a wait for it: ~30 us; launch_solve calls it rarely)
+// the device's constant 100 MHz clock as of "now" (a one-lane kernel on a stream of its own and a wait for it: ~30 us; launch_solve calls it rarely).
+// The stream and the word the kernel writes exist once per DEVICE for the life of the process (a map under a mutex) -- whatever thread asks, and however often the
+// caller's threads come and go: per-thread copies keyed on the last device leaked a stream and a pinned block whenever a thread alternated between two devices
+// (the plugin's shards) or was created per call (bioik_solve_batch_multi's workers).
+struct ClockReader {
+    hipStream_t stream = nullptr;
+    unsigned long long* word = nullptr;  // (page-locked and mapped: the kernel writes it, the host reads it after the wait)
+};
+static std::mutex g_clock_mtx;
+static std::map<int, ClockReader> g_clock_readers;
 static unsigned long long be_device_clock_now() {
-    static thread_local hipStream_t cs = nullptr;
-    static thread_local int cs_device = -1;
-    static thread_local unsigned long long* word = nullptr;  // (page-locked and mapped: the kernel writes it, the host reads it after the wait)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (cs_device != dev) {
-        HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        HIP_CHECK(hipHostMalloc((void**)&word, 64, hipHostMallocDefault));
-        cs_device = dev;
+    std::lock_guard<std::mutex> lock(g_clock_mtx);
+    ClockReader& r = g_clock_readers[dev];
+    if (!r.stream) {
+        HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        HIP_CHECK(hipHostMalloc((void**)&r.word, 64, hipHostMallocDefault));
     }
-    hipLaunchKernelGGL(k_read_clock, dim3(1), dim3(1), 0, cs, word);
+    hipLaunchKernelGGL(k_read_clock, dim3(1), dim3(1), 0, r.stream, r.word);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(cs));
-    return *(volatile unsigned long long*)word;
+    HIP_CHECK(hipStreamSynchronize(r.stream));
+    return *(volatile unsigned long long*)r.word;
 }
 // wall time of what `enqueue` puts on stream s, in ms (two events and a wait for the second): the launcher's measured mapping choice (solve_dispatch)
 static bool be_can_time() { return true; }
@@ -346,6 +353,9 @@ struct bioik_problem {
     unsigned long long* d_clocks = nullptr;
     unsigned clock_next = 0;
     static constexpr unsigned kCaptureClocks = 64;
+    // SolveArgs::error: one word per host-pointer slot and one for the device-pointer entry, in page-locked host memory the kernels can write: a rendezvous between
+    // wavefronts that gave up (k_solve_lean_cl4h) sets the word of its call; the call's wait (or, for the device-pointer entry, the handle's next call) reports it
+    unsigned int* h_error = nullptr;
     unsigned int* d_resident = nullptr;  // workgroups of the throughput schedule's launches that are running now (SolveArgs::resident), all streams of this handle
     // Scratch of a solve that needs some (per-island results, the state of handed-over units): one persistent buffer per (stream, purpose), grown when a
     // solve asks for more.  Solves on one stream follow each other, so they may share it; solves on other streams have their own.  (Stream-ordered
@@ -416,6 +426,7 @@ struct SolveSwitches {
     int drain_test = 0;         // BIOIK_SOLVE_DRAIN_TEST=n (parity suites): any solve, unit u leaves its first launch after 1 + hash(u) % n steps
     int helped = 1024;  // BIOIK_SOLVE_HELPED=N: launches of up to N (query, island) units of a problem k_solve_lean_cl4 covers without a secondary goal run its helped
                         // build (k_solve_lean_cl4h: four wavefronts per unit), as do the stragglers a chip-filling call hands over; 0: never
+    int debug_flags = 0;  // BIOIK_SOLVE_DEBUG_FLAGS (tests): SolveArgs::debug_flags
     int autotune = 1;  // BIOIK_SOLVE_AUTOTUNE: 1 (default) = the host-pointer entries time the eligible lane mappings on a handle's first chip-filling call of a kind and keep
                        // the fastest (solve_dispatch); 2 = the device-pointer entry does so too (it then waits for its stream once); 0 = the rules alone
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
@@ -461,6 +472,7 @@ static SolveSwitches parse_switches() {
     w.memset_nodes = geti("BIOIK_SOLVE_MEMSET_NODES", 0) != 0;
     w.autotune = geti("BIOIK_SOLVE_AUTOTUNE", 1);
     w.helped = geti("BIOIK_SOLVE_HELPED", 1024);
+    w.debug_flags = geti("BIOIK_SOLVE_DEBUG_FLAGS", 0);
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -573,7 +585,7 @@ static void set_deadline(bioik_problem* p, const DevSolveParams& sp, stream_t st
 }
 
 static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
-                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream, const SolveSwitches& sw) {
+                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream, const SolveSwitches& sw, unsigned int* error_word) {
     if (n == 0) return;
     DevSolveParams sp = sp_in;
     const DevProblem& dp = p->host.dev;
@@ -807,6 +819,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     a.phase_cycles = nullptr;
     a.sort_key_drop = sw.sort_key_drop;
     a.preselect = sw.preselect | (sw.tie_test_bits << 8);
+    a.error = error_word;
+    a.debug_flags = sw.debug_flags;
     set_deadline(p, sp, stream, a);
 #if defined(BIOIK_PHASE_TIMING)
     DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
@@ -997,9 +1011,9 @@ static SolveSwitches preset_switches(const SolveSwitches& base, int i) {
     return w;
 }
 static void solve_dispatch(bioik_problem* p, const DevSolveParams& sp, size_t n, const double* d_seeds, const double* d_params, double* d_solutions, double* d_fitness,
-                           int32_t* d_success, int32_t* d_steps, stream_t stream, bool may_wait) {
+                           int32_t* d_success, int32_t* d_steps, stream_t stream, bool may_wait, unsigned int* error_word) {
     const SolveSwitches sw = switches();  // (the diagnostic switches as last parsed: no environment access on the launch path)
-    auto run = [&](const SolveSwitches& w) { launch_solve(p, sp, n, d_seeds, d_params, d_solutions, d_fitness, d_success, d_steps, stream, w); };
+    auto run = [&](const SolveSwitches& w) { launch_solve(p, sp, n, d_seeds, d_params, d_solutions, d_fitness, d_success, d_steps, stream, w, error_word); };
     const uint64_t units = (uint64_t)n * (uint64_t)sp.islands;
     const bool kind_ok = sw.autotune > 0 && !sw.manual() && !sw.general_set && !sw.two_phase_set && sw.drain_test == 0 && sw.dense_handover == 0 && sp.solver == 0 &&
                          sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && sp.timeout_ticks == 0 && units >= 8 * (uint64_t)p->model->dev.cus && sp.max_steps >= 8;
@@ -1100,6 +1114,8 @@ int bioik_problem_create(bioik_model* model, const bioik_problem_desc* desc, bio
     p->d_clocks = (unsigned long long*)be_alloc(bioik_problem::kCaptureClocks * sizeof(unsigned long long));
     p->d_resident = (unsigned int*)be_alloc(16 * 128);
     be_zero_async(p->d_resident, 16 * 128, 0);
+    p->h_error = (unsigned int*)be_alloc_pinned(64);
+    std::memset(p->h_error, 0, 64);
     be_h2d(p->d_pb, &p->host.dev, sizeof(DevProblem), 0);
     be_sync(0);
     *out = p.release();
@@ -1110,6 +1126,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     be_free(p->d_pb);
     be_free(p->d_clocks);
     be_free(p->d_resident);
+    be_free_pinned(p->h_error);
     for (auto& kv : p->scratch) be_free(kv.second.base);
     for (void* q : p->retired_scratch) be_free(q);
     for (auto& sl : p->io) {
@@ -1146,6 +1163,13 @@ int bioik_problem_set_first_query(bioik_problem* p, uint64_t first_query) {
     return BIOIK_OK;
 }
 
+int bioik_resolve_islands(const bioik_problem* p, const bioik_solve_params* params, size_t n, int32_t* islands, int32_t* island_sync) {
+    API_BEGIN
+    if (!p || !params || !islands || !island_sync) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "null argument");
+    const DevSolveParams r = bioik::normalize_params(*params, 0, n, 8 * (size_t)p->model->dev.cus);
+    *islands = r.islands, *island_sync = r.island_sync;
+    API_END
+}
 int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* d_seeds, const double* d_goal_params,
                              double* d_solutions, double* d_fitness, int32_t* d_success, int32_t* d_steps, void* hip_stream) {
     API_BEGIN
@@ -1155,7 +1179,12 @@ int bioik_solve_batch_device(bioik_problem* p, const bioik_solve_params* params,
     std::lock_guard<std::mutex> lock(p->mtx);
     DeviceGuard on_device(p->model->device);
     DevSolveParams sp = bioik::normalize_params(*params, p->first_query, n, 8 * (size_t)p->model->dev.cus);
-    solve_dispatch(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream, false);
+    // (this entry does not wait for its solve: a rendezvous time-out of an EARLIER solve through it is reported here)
+    if (p->h_error[bioik_problem::kIoSlots] != 0u) {
+        p->h_error[bioik_problem::kIoSlots] = 0u;
+        throw Error(BIOIK_ERR_HIP, "an earlier solve of this handle through bioik_solve_batch_device timed out at a rendezvous between its wavefronts (k_solve_lean_cl4h): its results are not valid");
+    }
+    solve_dispatch(p, sp, n, d_seeds, d_goal_params, d_solutions, d_fitness, d_success, d_steps, (stream_t)hip_stream, false, p->h_error + bioik_problem::kIoSlots);
     API_END
 }
 
@@ -1174,6 +1203,13 @@ static void io_finish(bioik_problem* p, bioik_problem::IoSlot& sl) {
         return;
     }
     sl.pending = false;
+    unsigned int& err = p->h_error[&sl - p->io];
+    if (err != 0u) {  // (SolveArgs::error: a wavefront of this solve gave up waiting for its partner and went on unsynchronised)
+        err = 0u;
+        sl.failed_ticket = sl.ticket, sl.failed_code = BIOIK_ERR_HIP;
+        sl.failed_message = "a rendezvous between the wavefronts of a workgroup timed out (k_solve_lean_cl4h): the results of this solve are not valid";
+        return;
+    }
     const size_t V = p->host.dev.V;
     const char* hd = (const char*)sl.host;
     std::memcpy(sl.solutions, hd + sl.o_sol, sl.n * V * 8);
@@ -1214,7 +1250,7 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
     // (profiles/r03_inflight_and_schedule.log, host pipeline).
     solve_dispatch(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
-                   (int32_t*)(hd + o_steps), st, true);
+                   (int32_t*)(hd + o_steps), st, true, p->h_error + (&sl - p->io));
     sl.pending = true, sl.ticket = ticket, sl.n = n;
     sl.o_sol = o_sol, sl.o_fit = o_fit, sl.o_suc = o_suc, sl.o_steps = o_steps;
     sl.solutions = solutions, sl.fitness = fitness, sl.success = success, sl.steps = steps;
@@ -1235,6 +1271,7 @@ static void solve_host(bioik_problem* p, const bioik_solve_params& params, uint6
     bioik_problem::IoSlot& sl = p->io[pick];
     io_begin(p, sl, ticket, params, first_query, n, seeds, goal_params, solutions, fitness, success, steps);
     io_finish(p, sl);
+    if (sl.failed_ticket == ticket) throw Error(sl.failed_code, "the solve failed on the device: " + sl.failed_message);  // (the synchronous call is its own ticket's wait)
 }
 
 int bioik_solve_batch(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seeds, const double* goal_params, double* solutions,

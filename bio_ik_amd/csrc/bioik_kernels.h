@@ -418,6 +418,11 @@ struct SolveArgs {
     // Which units leave when depends on timing; their results do not (every mapping computes the same trajectory).
     int32_t sort_key_drop = 10;                    // the pre-selection's sort keys give up this many low bits of a fitness for the child index (sort_key)
     int32_t preselect = 1;                         // bit 0: the pre-selection's survivors by selection (select_threshold) instead of the sort; bits 8...: parity suites -- the parked fitness values lose that many low bits, so that children tie
+    // A rendezvous between wavefronts through words in LDS (the helped kernel) that gives up -- its partner did not answer within 2^22 polls: a debugger, a
+    // context switch, a wavefront that died -- sets this word of the handle (page-locked host memory, mapped): the host turns it into BIOIK_ERR_HIP for the call.
+    // The reference's boost::barrier cannot time out (ik_parallel.h:64-67); a solve that went on unsynchronised must not pass for a result.
+    unsigned int* error = nullptr;
+    int32_t debug_flags = 0;                       // tests: bit 0 -- the helper wavefront of species 0 never answers (the host simulator's rendezvous test)
     unsigned int* resident = nullptr;              // [16][32]: word 32 x of XCD x
     int32_t drain_below = 0, drain_min_steps = 0;  // (wavefronts per XCD)  // (drain_below < 0: test pattern -- unit u leaves after 1 + hash(u) % -drain_below steps)
 };
@@ -555,6 +560,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             const int hs = p_wave_index() - 2;
             unsigned int* const hw = (unsigned int*)(lds + L.help);
             double* const s_fit = lds + L.g_first + hs * L.g_stride + L.fitp;
+            if ((a.debug_flags & 1) != 0 && hs == 0) return;  // (tests: a helper that never answers)
             for (unsigned int expect = 1u;; expect++) {
                 if (p_flag_wait_ge(hw + 2 + hs, expect) == 0xffffffffu) break;
                 const int off_p0g = (int)hw[6 + 4 * hs], off_pgt = (int)hw[7 + 4 * hs], n_walk = (int)hw[9 + 4 * hs];
@@ -580,6 +586,14 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     }
     // the rendezvous of the workgroup: the hardware barrier, or (helped kernel: its helpers are elsewhere) a count per main wavefront in LDS that the other one waits for
     unsigned int bar_count = 0u, gen_count = 0u;  // (gen_count: generations this main wavefront has published to its helper)
+    // (helped kernel) a wait of this wavefront has given up: its partner -- the other main wavefront, or its helper -- did not answer.  The handle's error word is
+    // set (the host reports BIOIK_ERR_HIP for the call), this wavefront waits for nobody any more (it keeps raising its own counts, so that a partner that is
+    // merely late does not wait for IT) and leaves the step loop at the end of the step; whatever it computes from here on is not a result.
+    bool lost = false;
+    auto rendezvous_lost = [&]() {
+        lost = true;
+        if (a.error) p_store_device(a.error, 1u);
+    };
     auto wg_barrier = [&]() {
         if constexpr (HELPED) {
             unsigned int* const hw = (unsigned int*)(lds + L.help);
@@ -587,7 +601,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
             p_wave_sync();
             bar_count++;
             p_flag_store(hw + w, bar_count);
-            (void)p_flag_wait_ge(hw + (w ^ 1), bar_count);
+            if (!lost && p_flag_wait_ge(hw + (w ^ 1), bar_count) == 0xffffffffu) rendezvous_lost();
         } else {
             p_barrier();
         }
@@ -1130,7 +1144,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
                         {
                             BIOIK_LANE_SCOPE;
                             p_wave_sync();
-                            (void)p_flag_wait_ge(hw + 4 + p_wave_index(), gen_count);  // the helper's share of the fitness values is parked
+                            if (!lost && p_flag_wait_ge(hw + 4 + p_wave_index(), gen_count) == 0xffffffffu) rendezvous_lost();  // the helper's share of the fitness values is parked
                         }
                         {
                             BIOIK_LANE_SCOPE;
@@ -1745,6 +1759,11 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         final_fit = s_solst[0];
         success = s_solst[1] != 0.0;
         PHASE_MARK(PH_CHECK);
+        if constexpr (HELPED)
+            if (lost) {  // (a rendezvous of this wavefront gave up: nothing it holds is a result)
+                success = false, final_fit = BIOIK_DBL_MAX;
+                break;
+            }
         if (success) {
             if (a.first_success && tid == 0) p_atomic_min(a.first_success + q, (unsigned int)steps);  // ik_parallel.h:176-177 `finished = 1`
             break;
@@ -1781,7 +1800,7 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
     PHASE_DUMP(a.phase_cycles, unit);
     BIOIK_EPILOGUE_SCOPE_BEGIN
     if (a.resident && tid == 0) p_atomic_sub(my_resident(), (unsigned int)(HELPED ? 4 : nth >> 6));
-    const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && (step_end < sp.max_steps || drained);  // neither solved nor out of time: the next launch goes on
+    const bool handed_over = a.carry_list && !success && !expired && !overtaken_out && !lost && (step_end < sp.max_steps || drained);  // neither solved nor out of time: the next launch goes on
     if (handed_over) {
         double* c = a.carry + unit * (uint64_t)carry_n;
         for (int i = tid; i < 2 * BF; i += nth) {
@@ -1988,21 +2007,25 @@ BIOIK_DEV void eval_check_body(const EvalArgs& a, uint64_t block, double* lds) {
 // mode both include is evaluated here on the device for arbitrary arguments, so that a test can hold it against an independent high-precision
 // reference (tests/test_arith_headers.py) -- bit parity between two users of one header cannot show a defect of the header itself.
 // ---------------------------------------------------------------------------------------------------------
-enum { ARITH_SINCOS = 0, ARITH_QROT = 1, ARITH_QMUL = 2, ARITH_DOT3 = 3, ARITH_DOT4 = 4, ARITH_REVOLUTE = 5 };
+enum { ARITH_SINCOS = 0, ARITH_QROT = 1, ARITH_QMUL = 2, ARITH_DOT3 = 3, ARITH_DOT4 = 4, ARITH_REVOLUTE = 5, ARITH_ACOS = 6, ARITH_ATAN2 = 7 };
 struct ArithArgs {
     int32_t op, pad;
     uint64_t n;
     const double* in;  // [n][arith_in(op)]
     double* out;       // [n][arith_out(op)]
 };
-BIOIK_HD int arith_in(int op) { return op == ARITH_SINCOS ? 1 : op == ARITH_QROT ? 7 : op == ARITH_QMUL ? 8 : op == ARITH_DOT3 ? 6 : op == ARITH_DOT4 ? 8 : op == ARITH_REVOLUTE ? 22 : 0; }
-BIOIK_HD int arith_out(int op) { return op == ARITH_SINCOS ? 2 : op == ARITH_QROT ? 3 : op == ARITH_QMUL ? 4 : op == ARITH_DOT3 ? 1 : op == ARITH_DOT4 ? 1 : op == ARITH_REVOLUTE ? 14 : 0; }
+BIOIK_HD int arith_in(int op) { return op == ARITH_SINCOS ? 1 : op == ARITH_QROT ? 7 : op == ARITH_QMUL ? 8 : op == ARITH_DOT3 ? 6 : op == ARITH_DOT4 ? 8 : op == ARITH_REVOLUTE ? 22 : op == ARITH_ACOS ? 1 : op == ARITH_ATAN2 ? 2 : 0; }
+BIOIK_HD int arith_out(int op) { return op == ARITH_SINCOS ? 2 : op == ARITH_QROT ? 3 : op == ARITH_QMUL ? 4 : op == ARITH_DOT3 ? 1 : op == ARITH_DOT4 ? 1 : op == ARITH_REVOLUTE ? 14 : op == ARITH_ACOS ? 1 : op == ARITH_ATAN2 ? 1 : 0; }
 BIOIK_DEV void arith_body(const ArithArgs& a, uint64_t i) {
     if (i >= a.n) return;
     const double* x = a.in + i * (uint64_t)arith_in(a.op);
     double* o = a.out + i * (uint64_t)arith_out(a.op);
     if (a.op == ARITH_SINCOS) {
         p_sincos(x[0], &o[0], &o[1]);
+    } else if (a.op == ARITH_ACOS) {
+        o[0] = bioik_acos(x[0]);
+    } else if (a.op == ARITH_ATAN2) {
+        o[0] = bioik_atan2(x[0], x[1]);
     } else if (a.op == ARITH_QROT) {
         const V3 r = qrot(Q4{x[0], x[1], x[2], x[3]}, v3(x[4], x[5], x[6]));
         o[0] = r.x, o[1] = r.y, o[2] = r.z;

@@ -118,7 +118,13 @@ BIOIK_DEV double p_clamp(double x, double lo, double hi) {
 }
 BIOIK_DEV unsigned long long p_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }  // lane mask of the wavefront (every lane calls it)
 BIOIK_DEV int p_popc(uint32_t v) { return __popc(v); }
-BIOIK_DEV int p_byte_sum(uint32_t v, int addend) { return (int)__builtin_amdgcn_sad_u8(v, 0u, (uint32_t)addend); }  // the four bytes of v + addend: v_sad_u8 against zero
+// the four bytes of v + addend: v_sad_u8 against zero, the (uniform) addend as a SCALAR operand -- through the builtin the compiler moves the constant into a vector
+// register first, once per call (VOP3 takes no literal on gfx9): one more instruction per gene and child in the hottest loop
+BIOIK_DEV int p_byte_sum(uint32_t v, int addend) {
+    int r;
+    asm("v_sad_u8 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(addend));
+    return r;
+}
 BIOIK_DEV int p_popc64(unsigned long long v) { return __popcll(v); }
 BIOIK_DEV unsigned long long p_wall_clock() { return wall_clock64(); }  // s_memrealtime: the chip-wide constant 100 MHz clock
 BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned long long value) {  // first caller's value wins; returns the winner
@@ -243,6 +249,9 @@ enum { PH_INIT = 0, PH_REPRODUCE = 1, PH_FITNESS = 2, PH_SELECTION = 3, PH_MEMET
 #define BIOIK_FUSED_FN BIOIK_DEV
 #include "bioik_fused.h"
 BIOIK_DEV void p_sincos(double x, double* s, double* c) { bioik_sincos(x, s, c); }
+// acos / atan2 of the goal costs and of the success test: the shared bit-reproducible implementations (bioik_acos.h)
+#define BIOIK_ACOS_FN BIOIK_DEV
+#include "bioik_acos.h"
 
 #define BIOIK_DBL_MAX 1.7976931348623157e308
 #define BIOIK_PI 3.14159265358979323846

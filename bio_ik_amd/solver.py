@@ -28,6 +28,7 @@ EXPORTS = [
     "bioik_problem_param_count", "bioik_problem_variable_count", "bioik_problem_set_first_query", "bioik_solve_batch", "bioik_solve_batch_multi",
     "bioik_solve_batch_device", "bioik_eval_fk", "bioik_eval_fitness", "bioik_eval_approximator", "bioik_eval_reproduce",
     "bioik_eval_check", "bioik_stream_fitness_device", "bioik_solve_batch_submit", "bioik_solve_batch_wait", "bioik_debug_reload_switches", "bioik_eval_arith",
+    "bioik_resolve_islands",
 ]
 
 
@@ -130,8 +131,8 @@ def sync_debug_switches(L):
         _switch_snapshot[key] = snap
 
 
-ARITH_IN = {0: 1, 1: 7, 2: 8, 3: 6, 4: 8, 5: 22}
-ARITH_OUT = {0: 2, 1: 3, 2: 4, 3: 1, 4: 1, 5: 14}
+ARITH_IN = {0: 1, 1: 7, 2: 8, 3: 6, 4: 8, 5: 22, 6: 1, 7: 2}
+ARITH_OUT = {0: 2, 1: 3, 2: 4, 3: 1, 4: 1, 5: 14, 6: 1, 7: 1}
 
 
 def eval_arith(op, x, device=0, lib=None):

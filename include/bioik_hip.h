@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define BIOIK_ABI_VERSION 5 /* 5 (round 5): bioik_solve_params::islands = 0 means BIOIK_ISLANDS_AUTO (versions up to 4 took 0 as 1); `timeout` counts from the call; no new entry point */
+#define BIOIK_ABI_VERSION 6 /* 6 (round 6): bioik_resolve_islands (the island count BIOIK_ISLANDS_AUTO gives a call of n queries, for callers that shard a request themselves);
+                               a rendezvous time-out inside a workgroup is BIOIK_ERR_HIP for its call; a line-search candidate with a joint value of magnitude >= 1e300 is no candidate.
+                               5 (round 5): bioik_solve_params::islands = 0 means BIOIK_ISLANDS_AUTO (versions up to 4 took 0 as 1); `timeout` counts from the call */
 
 /* ---- status codes ------------------------------------------------------------------------- */
 enum {
@@ -267,6 +269,11 @@ int bioik_problem_variable_count(const bioik_problem* p);                 /* rob
  * keyed by (random_seed, global query index, island), so a batch sharded over several GPUs / calls reproduces the
  * unsharded run when every shard announces its offset.  (New: the reference has one query per call.) */
 int bioik_problem_set_first_query(bioik_problem* p, uint64_t first_query);
+/* What bioik_solve_params::islands = BIOIK_ISLANDS_AUTO means for a call of n queries on this handle's device: the island count and island_sync the call would
+ * run with (an explicit count comes back as it is).  For callers that cut ONE request into several calls -- the MoveIt plugin's shards over `gpu_devices` --
+ * and want every part to run the same solve whatever its size: resolve once for the largest part (ceil(rows / W), as bioik_solve_batch_multi does) and pass the
+ * explicit figures to every call.  (The reference has no counterpart: its island count is the host's thread count, src/ik_parallel.h:84, utils.h:423.) */
+int bioik_resolve_islands(const bioik_problem* p, const bioik_solve_params* params, size_t n, int32_t* islands, int32_t* island_sync);
 
 /*
  * The batched solve: replaces IKParallel::solve() for n independent queries
@@ -354,7 +361,7 @@ int bioik_eval_reproduce(bioik_problem* p, int population, uint32_t rng_key, int
 int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t n, const double* seed,
                      const double* goal_params, const double* genes, int32_t* ok);
 
-/* The shared arithmetic of both sides of the boundary, one function at a time on the device (bio_ik_amd/csrc/bioik_sincos.h, bioik_fused.h -- the
+/* The shared arithmetic of both sides of the boundary, one function at a time on the device (bio_ik_amd/csrc/bioik_sincos.h, bioik_fused.h, bioik_acos.h -- the
  * headers the kernels and the test-suite's CPU checker both include): so that a test can hold them against an INDEPENDENT high-precision
  * reference (tests/test_arith_headers.py).  op / doubles in / doubles out per element:
  *   0 sincos        x                                      -> sin x, cos x           (reference: libm, src/forward_kinematics.h:89-112)
@@ -362,6 +369,8 @@ int bioik_eval_check(bioik_problem* p, const bioik_solve_params* params, size_t 
  *   2 qmul          p[4] q[4]                              -> p (x) q                 (frame.h:151-172)
  *   3 dot3          a[3] b[3]   4 dot4  a[4] b[4]          -> a . b
  *   5 revolute      frame[7] half_angle cpos[3] ca[4] cb[4] pos_kind rot_kind pad  -> frame'[7] by the general form, frame'[7] by the sparse form
+ *   6 acos          x                                      -> acos x                  (reference: tf2Acos -> libm, include/bio_ik/goal_types.h:183-212, 646-712)
+ *   7 atan2         y x                                    -> atan2(y, x)             (reference: KDL::Rotation::GetRot -> libm, src/problem.cpp:281-321)
  * Host pointers. */
 int bioik_eval_arith(int device, int op, size_t n, const double* in, double* out);
 

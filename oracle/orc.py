@@ -60,8 +60,15 @@ def shared_sincos(x, kind="strict"):
     return s, c
 
 
+def unbounded_candidates(kind="strict"):
+    """how many line-search candidates with a gene of magnitude >= 1e300 the oracle has met so far (quirk Q7, orc_evolution.h)"""
+    L = lib(kind)
+    L.orc_debug_unbounded_candidates.restype = C.c_ulonglong
+    return int(L.orc_debug_unbounded_candidates())
+
+
 def set_quirk_mode(mode, kind="strict"):
-    """0 = reference quirks Q1 / Q4 / Q5 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
+    """0 = reference quirks Q1 / Q4 / Q5 / Q7 fixed as on the device (default); 1 = literal reference behaviour (for oracle/_ref)."""
     lib(kind).orc_set_quirk_mode(C.c_int(mode))
 
 

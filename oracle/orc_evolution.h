@@ -14,6 +14,10 @@
 // max(0, .) of its error hides it -- the NaN candidate can be ACCEPTED and returned as the solution (found by tools/robot_fuzz_hostsim.py: 3 of 600 random robots).
 // The device takes a candidate with a NaN gene for no candidate and stops the search there -- what the reference does whenever the NaN is NOT hidden (its fitness is
 // NaN and fails the comparison): quirk_mode 0 (the default, what the device is compared with) does the same, quirk_mode 1 is the literal reference.
+// Q7 (round 6) the same line search on a model without curvature but with a slope: v / 0 is an INFINITE step, RobotInfo::clip puts a joint WITHOUT limits at
+// +-DBL_MAX (robot_info.h:109-113: clip_max = DBL_MAX), the linear model is evaluated at 1.8e308 and -- where a goal hides the overflow, e.g. the angle of a
+// ConeGoal: acos(NaN) under max(0, .) -- the candidate is accepted: the reference can return a joint value of 1.8e308 (tools/robot_fuzz_hostsim.py: 4 of 8000 random
+// robots).  The device takes a candidate with a gene of magnitude >= 1e300 for no candidate (BIOIK_CANDIDATE_BOUND); quirk_mode 0 does the same, mode 1 is literal.
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -92,7 +96,10 @@ struct Evolution2 {
         const double c = model->clip(p, var);
         // (quirk Q7: a step without bound clips a joint WITHOUT limits to +-DBL_MAX, robot_info.h:109-113; the default mode takes a candidate with a gene of
         // magnitude 1e300 or more for no candidate, as the device does -- mode 1 keeps it and evaluates the linear model there, as the reference does)
-        if (quirk_mode() == 0 && std::fabs(c) >= ORC_CANDIDATE_BOUND) candidate_has_nan = true;
+        if (std::fabs(c) >= ORC_CANDIDATE_BOUND) {
+            unbounded_candidates()++;  // (diagnostics: how often a line search met such a candidate, in either mode)
+            if (quirk_mode() == 0) candidate_has_nan = true;
+        }
         return c;
     }
     double primary_fitness(const Frame* frames, const double* genes) { return problem->compute_goal_fitness(problem->goals, query, frames, genes); }
@@ -336,8 +343,6 @@ struct Evolution2 {
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] + gradient[i] * step_size, problem->active_variables[i]);
                         if (candidate_has_nan) break;  // (Q5, default mode)
-                        for (size_t i = 0; i < D(); i++)
-                            if (std::fabs(gw[i]) >= 1e300) unbounded_candidates()++;
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {
@@ -354,8 +359,6 @@ struct Evolution2 {
                         for (size_t i = 0; i < D(); i++)
                             gw[i] = line_search_clip(individual.genes[i] - gradient[i] * step_size, problem->active_variables[i]);
                         if (candidate_has_nan) break;  // (Q5, default mode)
-                        for (size_t i = 0; i < D(); i++)
-                            if (std::fabs(gw[i]) >= 1e300) unbounded_candidates()++;
                         phenotypes_of(1, &g0, phenotypes2, BIOIK_FK_LINEAR);
                         double f4p = primary_fitness(phenotypes2.data(), g0);
                         if (f4p < f2p) {

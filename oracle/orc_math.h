@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "../bio_ik_amd/csrc/bioik_fused.h"
+#include "../bio_ik_amd/csrc/bioik_acos.h"
 
 namespace orc {
 
@@ -71,7 +72,7 @@ inline Vec3 normalized(const Vec3& a) {  // tf2: *this / length(), and tf2's ope
 inline double tf2_acos(double x) {  // tf2Acos clamps its argument (tf2/LinearMath/Scalar.h)
     if (x < -1.0) x = -1.0;
     if (x > 1.0) x = 1.0;
-    return std::acos(x);
+    return fused() ? bioik_acos(x) : std::acos(x);  // (device-arithmetic mode: the implementation the kernels share, bioik_acos.h)
 }
 inline double angle(const Vec3& a, const Vec3& b) {  // tf2::Vector3::angle
     double s = std::sqrt(length2(a) * length2(b));
@@ -256,7 +257,7 @@ inline Vec3 kdl_get_rot(const double* d) {
     double f = (d[0] + d[4] + d[8] - 1) / 2;
     double x = (d[7] - d[5]), y = (d[2] - d[6]), z = (d[3] - d[1]);
     double n = std::sqrt(x * x + y * y + z * z);
-    double angle = std::atan2(n / 2, f);
+    double angle = fused() ? bioik_atan2(n / 2, f) : std::atan2(n / 2, f);
     return {x / n * angle, y / n * angle, z / n * angle};
 }
 // Twist( Ma^-1 * diff(pa,pb), Ma^-1 * diff(Ma,Mb) ), problem.cpp:281/300/321.

@@ -26,9 +26,8 @@ inline int& quirk_mode() {
     static int mode = 0;
     return mode;
 }
-// diagnostics for the soaks (tools/robot_fuzz_hostsim.py): how many candidates of the memetic line search had a gene clipped to +-DBL_MAX -- an infinite step
-// (curvature 0, slope not) on a joint WITHOUT limits.  The model is then evaluated at 1.8e308, where it overflows; what comes out is garbage in the reference
-// as here, and the kernels' fused arithmetic overflows along another path, so such a solve is not comparable bit for bit
+// diagnostics (tests, tools/robot_fuzz_hostsim.py): how many candidates of the memetic line search had a gene of magnitude >= 1e300 -- an infinite step (curvature
+// 0, slope not) on a joint WITHOUT limits, clipped to +-DBL_MAX.  Quirk Q7 (orc_evolution.h): no candidate in the default mode, literal in mode 1.
 inline std::atomic<unsigned long long>& unbounded_candidates() {
     static std::atomic<unsigned long long> n{0};
     return n;

@@ -126,7 +126,7 @@ BIOIK_DEV void p_store_device(T* p, T v) { *(volatile T*)p = v; }
 // (the lanes of a workgroup are fibres of one thread: a lane that waits for a word hands control on until another lane has written it)
 BIOIK_DEV void p_flag_store(unsigned int* word, unsigned int value) { *(volatile unsigned int*)word = value; }
 BIOIK_DEV unsigned int p_flag_wait_ge(const unsigned int* word, unsigned int value) {
-    for (long spin = 0; spin < (1L << 24); spin++) {
+    for (long spin = 0; spin < (1L << 20); spin++) {  // (a partner that is on its way arrives within a few thousand switches; the give-up itself is a test)
         const unsigned int r = *(const volatile unsigned int*)word;
         if (r >= value) return r;
         sim::yield();

@@ -152,8 +152,8 @@ def balance_errors(template, o, sol, params, off):
 def point_solvers(h, o, template, n=8, exact_jac=True):
     """gd_c and jac (src/ik_gradient.cpp) through the batched entry point against the oracle's restatement (itself pinned bit for bit
     against the reference's source, tests/test_oracle_vs_reference.py): tracking seeds, several step budgets.  gd_c touches only the
-    shared exact-FK arithmetic: identical bits.  jac goes through acos (twist of the pose error), which the device math library and libm
-    may round differently: identical where both sides run on the host, to 1e-9 on the device."""
+    shared exact-FK arithmetic: identical bits.  jac goes through acos (twist of the pose error): the shared implementation of bioik_acos.h since round 6 --
+    identical bits on the host simulator and on the device (exact_jac=False: the tolerance of rounds 2 - 5, when the device used its own library's)."""
     seeds, params, _ = make_queries(template, o.active_variables, o.fk_genes, n, seed=41, kind="tracking")
     # islands = N: the reference's gd_N / gd_r_N / gd_c_N / jac_N (solver threads 1 ... N - 1 start at random configurations, the best
     # island wins); gd_r: random restarts after a step that did not improve (the draws of both are the counter generator's)
@@ -239,14 +239,14 @@ def branching_hand(make_solver):
     function_level(make_solver(t), orc.Oracle(t), model_p, np.random.default_rng(3), n=40, frame_tol=5e-16, fit_rtol=1e-14)
 
 
-def exact_joint_program(make_solver, templates, same_libm=True):
+def exact_joint_program(make_solver, templates):
     """BIOIK_COMPILE_EXACT=1 (bioik_compile.cpp): the joint program without folding -- an op per origin that is not the identity, the bare joint behind it, the
     reference's frame-by-frame association on ANY robot.  The caller has set the switch.  `gnarly` (rotated origins, oblique axes, a prismatic joint inside a chain,
     fixed links with offsets, three branches, a tip off the root) with a goal of every opcode listed in walk order, and the branching hand with a prismatic joint
     in the middle of its arm: FK, fitness, tables, success test and whole solves bit for bit -- what the folded program reaches to 1e-12 there.  On a benchmark
     fixture, where folding is exact, the two programs give the same bits (through other kernels: the unfolded program is not a serial chain).
-    same_libm: device and oracle share acos (the host simulator).  LookAtGoal, ConeGoal and their kind call it; on the GPU it is another library's, equal on the
-    sampled configurations of the function-level check but not on every one a memetic search visits, so there the whole solves use the goals without it."""
+    (Until round 5 the GPU suite left the whole solves with LookAtGoal / ConeGoal out: their acos was the device library's.  Since round 6 it is bioik_acos.h's on
+    both sides.)"""
     from conftest import gnarly_goals, gnarly_robot, hand_robot
     from bio_ik_amd import PoseGoal, PositionGoal, ProblemTemplate
     g = gnarly_robot()
@@ -259,8 +259,6 @@ def exact_joint_program(make_solver, templates, same_libm=True):
         t = ProblemTemplate(model, group, gl)
         h, o = make_solver(t), orc.Oracle(t)
         function_level(h, o, model, np.random.default_rng(3), n=40, exact_bits=True)
-        if gl is in_walk_order and not same_libm:
-            continue
         for mode in ("bio2", "bio2_memetic", "bio2_memetic_l"):
             trajectory(h, o, t, n=2, pop=16, steps_list=(3,), mode=mode)
         trajectory(h, o, t, n=2, pop=24, steps_list=(3,), fk_mode=abi.FK_LINEAR)
@@ -303,3 +301,55 @@ def line_search_on_a_flat_model(make_solver):
     want, got = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=1), h.solve_batch(p, seeds, params)
     assert np.isfinite(want[0]).all()
     assert all(np.array_equal(a, b) for a, b in zip(want, got))
+
+
+def line_search_step_without_bound(make_solver):
+    """Quirk Q7 (oracle/orc_evolution.h): a line search whose three support values have a slope but no curvature steps by v / 0 = infinity (ik_evolution_2.cpp:498-507);
+    RobotInfo::clip puts a joint WITHOUT limits at +-DBL_MAX (utils.h:328-333, robot_info.h:109-113), the linear model is evaluated at 1.8e308, and where a goal
+    hides the overflow the candidate is ACCEPTED: the literal algorithm returns a joint value of 1.8e308.  Here: the case tools/robot_fuzz_hostsim.py met (its robot
+    7252 of seed 1001): a link on a continuous joint under a ConeGoal without a position term -- acos of a NaN is NaN, max(0, NaN - angle) = 0.  The literal oracle
+    (quirk mode 1) returns +-DBL_MAX; the default oracle and the device take such a candidate for none, return the same finite solves bit for bit, and no joint
+    value of magnitude 1e300 or more ever leaves the product.  The caller has set BIOIK_COMPILE_EXACT (rotated origins)."""
+    from bio_ik_amd import ConeGoal, ProblemTemplate, RobotModel
+    m = RobotModel("unbounded")
+    m.add_link("l0")
+    m.add_link("l1", "l0", "j1", "continuous", xyz=(0.0, 0.0, 0.0), rpy=(0.0, 0.0, 0.0), axis=(1.0, 0.0, 0.0), velocity=0.5426426563843417)
+    m.add_link("l2", "l1", "j2", "revolute", xyz=(0.04572965481048473, 0.05277106152021511, 0.05050941592637754), rpy=(-0.3608740952450565, 0.980351570493485, -1.22862373643628),
+               axis=(0.9541379120674467, 0.013104401555596383, -0.2990804564250949), lower=-2.2247343186350625, upper=3.2019406218963327, velocity=1.182617098045548)
+    m.add_link("l3", "l2", "j3", "revolute", xyz=(0.005954400579178779, -0.08672517736579491, -0.04541483446181143), rpy=(0.0, 0.0, 0.0),
+               axis=(-0.24200882816021646, -0.9626430338070318, 0.12145005786459118), lower=-0.7251913054947542, upper=0.053860341485142835, velocity=1.7665671554542268)
+    m.add_link("l4", "l3", "j4", "fixed", xyz=(0.24972201631502833, -0.25755953675525123, 0.26952303216126744), rpy=(-0.042157648764034404, -1.0784397959920873, 0.08927858511789348))
+    m.add_link("l5", "l1", "j5", "revolute", xyz=(0.17325897707111526, 0.1524531895817025, -0.11564002553074237), rpy=(-0.7542471072117699, 0.280108269925566, 0.32269292633260394),
+               axis=(0.0, 0.0, 1.0), lower=1.5690686444480715, upper=1.8057083350514227, velocity=1.2485997210011077)
+    m.add_link("l6", "l5", "j6", "continuous", xyz=(0.059373342160621435, 0.033905455876769394, 0.22673021365372945), rpy=(0.8700779369263824, 0.647723143901797, 0.9600318977820447),
+               axis=(0.0, 0.0, 1.0), velocity=1.0493670281090843)
+    m.add_link("l7", "l6", "j7", "prismatic", xyz=(0.0, 0.0, 0.0), rpy=(0.0, 0.0, 0.0), axis=(0.0, 0.0, 1.0), lower=-0.24420766820072295, upper=0.31795360850378185, velocity=2.567223066835506)
+    m.add_link("l8", "l6", "j8", "revolute", xyz=(0.3110930684668922, 0.21261168225543117, -0.07030637061651651), rpy=(0.0, 0.0, 0.0),
+               axis=(-0.5912632433391664, -0.7366574365173285, 0.3282431999292108), lower=-0.26411770069874596, upper=1.3269122675011662, velocity=2.9448390157031685)
+    m.add_link("l9", "l8", "j9", "revolute", xyz=(0.00858138555622114, -0.10387504668282581, 0.1110967330723456), rpy=(0.0, 0.0, 0.0),
+               axis=(0.8810341758029753, 0.07523516021682576, 0.46703153184160984), lower=-2.9528953897285146, upper=1.794084985679735, velocity=2.1667318473448707)
+    m.add_link("l10", "l3", "j10", "fixed", xyz=(0.03843744082044307, 0.09418822225340512, -0.03241751247524506), rpy=(-0.28941665223466384, -0.8663386046162123, -1.0747080865501497))
+    m.add_group("g", joints=["j1", "j2", "j3", "j5", "j6", "j7", "j8", "j9"], tips=["l1"])
+    goals = [ConeGoal("l1", axis=(0.34061279580669074, 0.10192115422766176, -0.9346630417715525), direction=(-0.24861241457165142, 0.9594718696304163, 0.13268609086398958),
+                      angle=0.4, weight=1.6)]
+    t = ProblemTemplate(m, "g", goals)
+    o, h = orc.Oracle(t), make_solver(t)
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2, seed=7252)
+    p = abi.default_solve_params(population=8, max_steps=2, random_seed=11, mode="bio2_memetic")
+    orc.set_quirk_mode(1)
+    try:
+        literal = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=1)
+    finally:
+        orc.set_quirk_mode(0)
+    assert (np.abs(literal[0]) >= 1e300).any()  # the reference's behaviour: a joint value of +-DBL_MAX as the solution
+    met = orc.unbounded_candidates()
+    want, got = o.solve_batch(p, orc.RNG_COUNTER, seeds, params, n_threads=1), h.solve_batch(p, seeds, params)
+    assert orc.unbounded_candidates() > met  # (the default mode met such candidates too -- and dropped them)
+    assert np.isfinite(want[0]).all() and np.abs(want[0]).max() < 1e300
+    assert np.isfinite(got[0]).all() and np.abs(got[0]).max() < 1e300
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    # ... and over a longer search with more streams: nothing of magnitude 1e300 ever comes back from the device
+    seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 32, seed=99)
+    for mode in ("bio2_memetic", "bio2_memetic_l"):
+        sol = h.solve_batch(abi.default_solve_params(population=16, max_steps=12, random_seed=5, mode=mode), seeds, params)[0]
+        assert np.isfinite(sol).all() and np.abs(sol).max() < 1e300

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_pod_layout_and_defaults(lib):
-    assert lib.bioik_abi_version() == 5
+    assert lib.bioik_abi_version() == 6
     p = abi.SolveParams()
     lib.bioik_default_solve_params(C.byref(p))
     assert p.struct_size == C.sizeof(abi.SolveParams)

@@ -93,12 +93,47 @@ def _check_revolute(ev, n):
             assert np.all(np.abs(out[:, :7].astype(np.longdouble) - ref) <= 24 * EPS * mag)
 
 
+def _check_acos_atan2(ev, n):
+    """bioik_acos.h: the fdlibm algorithms.  acos held to 1 ulp, atan2 to 1.5 ulp against long double (itself held against mpmath at 50 digits on a sample), on
+    random arguments, on the algorithm's branch points and next to +-1 where acos is steepest (the angle of two nearly parallel directions: ConeGoal, LookAtGoal)."""
+    rng = np.random.default_rng(20261001)
+    xs = np.concatenate([rng.uniform(-1.0, 1.0, n), 1.0 - 10.0 ** rng.uniform(-16, 0, n // 4), -1.0 + 10.0 ** rng.uniform(-16, 0, n // 4), ar.acos_special_arguments()])
+    got = ev(6, xs)[:, 0]
+    ref = ar.acos_longdouble(xs)
+    ulp = np.spacing(np.abs(ref.astype(np.float64)))
+    err = np.abs(got.astype(np.longdouble) - ref)
+    worst_acos = float(np.max(err / ulp))
+    assert worst_acos <= 1.0, "acos: %.3f ulp" % worst_acos
+    assert got[xs == 1.0].max() == 0.0 and np.all(got[xs == -1.0] == np.pi) and np.all(got[xs == 0.0] == np.pi / 2)
+    special = ev(6, np.array([np.nan, 1.0000000001, -2.0]))[:, 0]
+    assert np.all(np.isnan(special))  # (the callers clamp; a NaN stays a NaN, as through tf2Acos)
+    yx = np.concatenate([rng.normal(size=(n, 2)) * 10.0 ** rng.uniform(-3, 3, (n, 2)), np.stack([np.abs(rng.normal(size=n // 2)) * 1e-4, rng.uniform(-1.0, 1.0, n // 2)], axis=1),
+                         ar.atan2_special_arguments()])
+    got2 = ev(7, yx)[:, 0]
+    ref2 = ar.atan2_longdouble(yx)
+    ulp2 = np.spacing(np.abs(ref2.astype(np.float64)))
+    err2 = np.abs(got2.astype(np.longdouble) - ref2)
+    worst_atan2 = float(np.max(err2 / np.maximum(ulp2, 5e-324)))
+    # (atan of the ROUNDED quotient y / x: the quotient's half ulp counts double where the angle falls into the binade below the quotient's, e.g. 0.2522 -> 0.24698)
+    assert worst_atan2 <= 1.5, "atan2: %.3f ulp" % worst_atan2
+    edge = ev(7, np.array([[0.0, 1.0], [0.0, -1.0], [-0.0, -1.0], [1.0, 0.0], [-1.0, 0.0], [np.nan, 1.0], [1.0, np.inf], [1.0, -np.inf], [np.inf, np.inf], [-np.inf, -np.inf]]))[:, 0]
+    assert edge[0] == 0.0 and edge[1] == np.pi and edge[2] == -np.pi and edge[3] == np.pi / 2 and edge[4] == -np.pi / 2 and np.isnan(edge[5])
+    assert edge[6] == 0.0 and edge[7] == np.pi and edge[8] == np.pi / 4 and edge[9] == -3 * np.pi / 4
+    # the long double references themselves against mpmath (50 digits) on a sample
+    xm = np.concatenate([xs[:300], ar.acos_special_arguments()])
+    assert float(np.max(np.abs(ar.acos_longdouble(xm) - ar.acos_mpmath(xm)))) < 4e-19
+    ym = np.concatenate([yx[:300], ar.atan2_special_arguments()[::7]])
+    assert float(np.max(np.abs(ar.atan2_longdouble(ym) - ar.atan2_mpmath(ym)))) < 4e-19
+    return worst_acos, worst_atan2
+
+
 def test_shared_arithmetic_headers_in_the_host_simulator(hostsim_lib):
-    """-m "not gpu": bioik_sincos.h / bioik_fused.h as g++ compiles them (the bits the CPU checker's device-arithmetic mode computes)"""
+    """-m "not gpu": bioik_sincos.h / bioik_fused.h / bioik_acos.h as g++ compiles them (the bits the CPU checker's device-arithmetic mode computes)"""
     ev = lambda op, x: solver.eval_arith(op, x, lib=hostsim_lib)  # noqa: E731
     _check_sincos(ev, 40000)
     _check_fused(ev, 20000)
     _check_revolute(ev, 2000)
+    _check_acos_atan2(ev, 40000)
 
 
 @pytest.mark.gpu
@@ -108,7 +143,8 @@ def test_shared_arithmetic_headers_on_the_device():
     worst = _check_sincos(ev, 1000000)
     _check_fused(ev, 1000000)
     _check_revolute(ev, 50000)
-    print("sincos worst error %.3f ulp" % worst)
+    wa, wt = _check_acos_atan2(ev, 1000000)
+    print("sincos worst error %.3f ulp, acos %.3f ulp, atan2 %.3f ulp" % (worst, wa, wt))
 
 
 @pytest.mark.gpu
@@ -120,3 +156,7 @@ def test_device_and_host_simulator_agree_bit_for_bit(hostsim_lib):
     for op, w in ((1, 7), (2, 8), (3, 6), (4, 8)):
         y = rng.normal(size=(100000, w))
         assert np.array_equal(solver.eval_arith(op, y), solver.eval_arith(op, y, lib=hostsim_lib))
+    xa = np.concatenate([rng.uniform(-1.0, 1.0, 200000), 1.0 - 10.0 ** rng.uniform(-16, 0, 50000), ar.acos_special_arguments()])
+    assert np.array_equal(solver.eval_arith(6, xa), solver.eval_arith(6, xa, lib=hostsim_lib))
+    yx = np.concatenate([rng.normal(size=(200000, 2)) * 10.0 ** rng.uniform(-3, 3, (200000, 2)), ar.atan2_special_arguments()])
+    assert np.array_equal(solver.eval_arith(7, yx), solver.eval_arith(7, yx, lib=hostsim_lib))

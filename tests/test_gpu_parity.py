@@ -149,7 +149,7 @@ def test_balance_goal():
 def test_gradient_descent_and_jacobian_solvers(gpus, oracles, templates, cfg):
     """modes gd_c and jac (reference src/ik_gradient.cpp:136-251, 42-133) on the device, one wavefront per query (k_solve_point)"""
     h, o, t = gpus[cfg], oracles[cfg], templates[cfg]
-    pc.point_solvers(h, o, t, n=64, exact_jac=False)
+    pc.point_solvers(h, o, t, n=64, exact_jac=True)  # (round 6: jac's twist goes through the shared acos, bioik_acos.h -- the same bits as every other mode)
     if cfg == "c2":  # result level: jac converges on tracking queries; every success reproduces its pose under the reference-pinned FK
         with pc.oracle_arithmetic(0):
             seeds, params, _ = make_queries(t, o.active_variables, o.fk_genes, 2048, seed=17, kind="tracking")
@@ -197,8 +197,8 @@ def test_more_than_32_joints():
 @pytest.mark.parametrize("mid,with_base", [("planar", False), ("floating", False), ("planar", True)])
 def test_floating_and_planar_joints_anywhere(mid, with_base):
     """a planar stage / a floating coupling in the MIDDLE of the chain, and two multi-variable joints on one chain (round 5: forward_kinematics.h:120-135,
-    331-354 take them wherever they are).  As for the free base below: the forward-difference Jacobian columns go through acos / sqrt, which the device
-    library and libm round differently -- tables to 1e-9, plain `bio2` solves bit for bit, memetic solves at result level."""
+    331-354 take them wherever they are).  As for the free base below: the forward-difference Jacobian columns go through acos / sqrt -- since round 6 the
+    shared acos of bioik_acos.h and the IEEE sqrt: everything bit for bit, memetic solves included, plus the result level at 48 steps."""
     from bio_ik_amd import PoseGoal, PositionGoal
     from bio_ik_amd.solver import HipSolver
     from conftest import stage_robot
@@ -206,8 +206,9 @@ def test_floating_and_planar_joints_anywhere(mid, with_base):
     t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("stage", weight=0.2)])
     h, o = HipSolver(t), orc.Oracle(t)
     assert h.D == o.D == 4 + (7 if mid == "floating" else 3) + (3 if with_base else 0)
-    pc.function_level(h, o, m, np.random.default_rng(9), n=500, frame_tol=1e-9, fit_rtol=1e-9)
+    pc.function_level(h, o, m, np.random.default_rng(9), n=500, exact_bits=True)
     pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 5), mode="bio2")
+    pc.trajectory(h, o, t, n=8, pop=64, steps_list=(3,))
     t1 = ProblemTemplate(m, "whole", [PoseGoal("tool")])
     h1, o1 = HipSolver(t1), orc.Oracle(t1)
     seeds, params, _ = make_queries(t1, o1.active_variables, o1.fk_genes, 256, seed=22)
@@ -222,8 +223,8 @@ def test_floating_and_planar_joints_anywhere(mid, with_base):
 @pytest.mark.parametrize("base", ["floating", "planar"])
 def test_floating_and_planar_joints(base):
     """a free base in front of the arm (forward_kinematics.h:120-135, 695-726; ik_evolution_2.cpp:203-215, 320-324).  The Jacobian
-    columns of these joints come from a forward difference through acos / sqrt (frame.h:240-259), which the device math library
-    and libm round differently: the tables agree to 1e-9, plain `bio2` solves bit for bit, memetic solves at result level."""
+    columns of these joints come from a forward difference through acos / sqrt (frame.h:240-259) -- since round 6 the shared acos of
+    bioik_acos.h and the IEEE sqrt: tables and solves bit for bit, memetic solves included, plus the result level at 48 steps."""
     from bio_ik_amd import PoseGoal, PositionGoal
     from bio_ik_amd.solver import HipSolver
     from conftest import mobile_robot
@@ -231,8 +232,9 @@ def test_floating_and_planar_joints(base):
     t = ProblemTemplate(m, "whole", [PoseGoal("tool"), PositionGoal("base", weight=0.2)])
     h, o = HipSolver(t), orc.Oracle(t)
     assert h.D == o.D == (10 if base == "floating" else 6)
-    pc.function_level(h, o, m, np.random.default_rng(8), n=500, frame_tol=1e-9, fit_rtol=1e-9)
+    pc.function_level(h, o, m, np.random.default_rng(8), n=500, exact_bits=True)
     pc.trajectory(h, o, t, n=16, pop=128, steps_list=(1, 5), mode="bio2")
+    pc.trajectory(h, o, t, n=8, pop=64, steps_list=(3,))
     # result level on the tool pose alone (the two-goal problem converges slowly: a low-weight goal against dtwist = 1e-5)
     t1 = ProblemTemplate(m, "whole", [PoseGoal("tool")])
     h1, o1 = HipSolver(t1), orc.Oracle(t1)
@@ -559,7 +561,14 @@ def test_exact_joint_program(templates, monkeypatch):
     """parity_cases.exact_joint_program on the device"""
     from bio_ik_amd.solver import HipSolver
     monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
-    pc.exact_joint_program(lambda t: HipSolver(t), templates, same_libm=False)
+    pc.exact_joint_program(lambda t: HipSolver(t), templates)
+
+
+def test_line_search_step_without_bound(monkeypatch):
+    """parity_cases.line_search_step_without_bound (quirk Q7: the reference's candidate at +-DBL_MAX; no joint value of magnitude 1e300 leaves the product)"""
+    from bio_ik_amd.solver import HipSolver
+    monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
+    pc.line_search_step_without_bound(lambda t: HipSolver(t))
 
 
 def test_line_search_on_a_flat_model(monkeypatch):

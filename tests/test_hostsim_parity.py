@@ -210,6 +210,12 @@ def test_exact_joint_program(hostsim_lib, templates, monkeypatch):
     pc.exact_joint_program(lambda t: HipSolver(t, lib=hostsim_lib), templates)
 
 
+def test_line_search_step_without_bound(hostsim_lib, monkeypatch):
+    """parity_cases.line_search_step_without_bound (quirk Q7: the reference's candidate at +-DBL_MAX; no joint value of magnitude 1e300 leaves the product)"""
+    monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
+    pc.line_search_step_without_bound(lambda t: HipSolver(t, lib=hostsim_lib))
+
+
 def test_line_search_on_a_flat_model(hostsim_lib, monkeypatch):
     """parity_cases.line_search_on_a_flat_model (quirk Q5: the reference's NaN candidate)"""
     monkeypatch.setenv("BIOIK_COMPILE_EXACT", "1")
@@ -465,6 +471,30 @@ def test_throughput_schedule_changes_no_result(sims, oracles, templates):
     for tk in tickets:
         got = h.wait_batch(tk)
         assert all(np.array_equal(a, b) for a, b in zip(want, got))
+
+
+def test_a_helper_that_never_answers_is_an_error_not_a_result(sims, templates, monkeypatch):
+    """The helped kernel's wavefronts meet at words in LDS, and a wait gives up after a bounded number of polls (bioik_platform.h: p_flag_wait_ge).  A main wavefront
+    whose helper never answers (BIOIK_SOLVE_DEBUG_FLAGS=1: the helper of species 0 leaves at once) must not go on as if nothing had happened: it sets the call's
+    error word (SolveArgs::error), and the host-pointer entries report BIOIK_ERR_HIP instead of handing out the arrays -- the synchronous call, the ticket's wait,
+    and the device-pointer entry at the handle's next call.  The reference's boost::barrier cannot time out (ik_parallel.h:64-67)."""
+    from bio_ik_amd.solver import BioIKError
+    from bio_ik_amd.workload import make_queries
+    h, t = sims["c2"], templates["c2"]
+    seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 1, seed=21)
+    p = abi.default_solve_params(population=128, max_steps=2, random_seed=3)
+    good = h.solve_batch(p, seeds, params)
+    monkeypatch.setenv("BIOIK_SOLVE_DEBUG_FLAGS", "1")
+    with pytest.raises(BioIKError) as e:
+        h.solve_batch(p, seeds, params)
+    assert e.value.code == abi.ERR_HIP and "rendezvous" in str(e.value)
+    tk = h.submit_batch(p, seeds, params)
+    with pytest.raises(BioIKError) as e:
+        h.wait_batch(tk)
+    assert e.value.code == abi.ERR_HIP
+    monkeypatch.delenv("BIOIK_SOLVE_DEBUG_FLAGS")
+    again = h.solve_batch(p, seeds, params)  # the handle is as good as before
+    assert all(np.array_equal(a, b) for a, b in zip(good, again))
 
 
 def test_kernels_compiled_for_one_mapping(sims, oracles, templates, monkeypatch):

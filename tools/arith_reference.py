@@ -1,4 +1,4 @@
-"""Independent references for the shared arithmetic headers (bio_ik_amd/csrc/bioik_sincos.h, bioik_fused.h): NumPy long double (x87 80-bit: 64-bit
+"""Independent references for the shared arithmetic headers (bio_ik_amd/csrc/bioik_sincos.h, bioik_fused.h, bioik_acos.h): NumPy long double (x87 80-bit: 64-bit
 mantissa) for bulk comparisons and mpmath (50 digits) to validate the long double values themselves.  Used by tests/test_arith_headers.py at test time
 (nothing is stored); `python tools/arith_reference.py` prints the agreement of the two references.  Written from the mathematical definitions
 (frame.h:108-172 of the reference for the quaternion algebra), not from the headers under test."""
@@ -25,6 +25,48 @@ def sincos_mpmath(x):
     s = np.array([LD(mpmath.nstr(mpmath.sin(mpmath.mpf(float(v))), 30)) for v in x], dtype=LD)
     c = np.array([LD(mpmath.nstr(mpmath.cos(mpmath.mpf(float(v))), 30)) for v in x], dtype=LD)
     return s, c
+
+
+def acos_special_arguments():
+    """the branch points of the fdlibm algorithm (0.5, 1, tiny arguments), both signs, and their neighbours"""
+    base = np.array([0.0, 2.0 ** -58, 2.0 ** -57, 2.0 ** -56, 1e-300, 1e-10, 0.25, 0.4999999, 0.5, 0.5000001, 0.75, 0.9, 0.99, 0.999999, 1.0 - 2.0 ** -52, 1.0 - 2.0 ** -53, 1.0])
+    near = np.concatenate([base, np.nextafter(base, 2.0), np.nextafter(base, -2.0)])
+    near = near[np.abs(near) <= 1.0]
+    return np.concatenate([near, -near])
+
+
+def acos_longdouble(x):
+    return np.arccos(np.asarray(x, dtype=np.float64).astype(LD))
+
+
+def acos_mpmath(x):
+    import mpmath
+    mpmath.mp.dps = 50
+    return np.array([LD(mpmath.nstr(mpmath.acos(mpmath.mpf(float(v))), 30)) for v in x], dtype=LD)
+
+
+def atan2_special_arguments():
+    """the reduction thresholds of atan (0.4375, 0.6875, 1.1875, 2.4375) as ratios, the axes, both signs of everything"""
+    r = np.array([0.0, 1e-300, 2.0 ** -30, 2.0 ** -29, 0.4374999, 0.4375, 0.6875, 1.0, 1.1875, 2.4375, 1e10, 2.0 ** 61, 1e300])
+    r = np.concatenate([r, np.nextafter(r, np.inf), np.nextafter(r, -np.inf)])
+    r = r[r >= 0.0]
+    ys, xs = [], []
+    for sy in (1.0, -1.0):
+        for sx in (1.0, -1.0):
+            ys.append(sy * r), xs.append(np.full(r.shape, sx))          # y / x = the ratio
+            ys.append(np.full(r.shape, sy)), xs.append(sx * np.maximum(r, 1e-300))  # x / y = the ratio
+    return np.stack([np.concatenate(ys), np.concatenate(xs)], axis=1)
+
+
+def atan2_longdouble(yx):
+    yx = np.asarray(yx, dtype=np.float64).astype(LD)
+    return np.arctan2(yx[:, 0], yx[:, 1])
+
+
+def atan2_mpmath(yx):
+    import mpmath
+    mpmath.mp.dps = 50
+    return np.array([LD(mpmath.nstr(mpmath.atan2(mpmath.mpf(float(y)), mpmath.mpf(float(x))), 30)) for y, x in yx], dtype=LD)
 
 
 def _cross(a, b):
