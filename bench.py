@@ -224,7 +224,22 @@ def bench_c5(args, rank, world, gpu, dev):
         dist.destroy_process_group()
 
 
-def small_batches(h, template, dev, seeds, params, cpu=True):
+def small_batches_secondary(dev, cpu=True):
+    """small_batches for the two usual MoveIt configurations WITH a secondary goal: the 7-joint arm with a MinimalDisplacementGoal (128 children) and the 31-joint
+    chain with an AvoidJointLimitsGoal (512 children, BASELINE.json configs[3]): ms per call for 1 / 16 / 256 queries, the reference's thread beside them"""
+    from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, ProblemTemplate, pr2_like, snake
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.workload import make_queries
+    out = {}
+    for key, template, pop in (("arm_minimal_displacement", ProblemTemplate(pr2_like(), "right_arm", [PoseGoal("r_wrist_roll_link"), MinimalDisplacementGoal()]), 128),
+                               ("snake31_avoid_joint_limits", ProblemTemplate(snake(31), "snake", [PoseGoal("tip"), AvoidJointLimitsGoal()]), 512)):
+        h = HipSolver(template, device=dev.index)
+        seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, 1024, seed=0x5EC0)
+        out[key] = small_batches(h, template, dev, seeds, params, cpu=cpu, sizes=(1, 16, 256), pop=pop, batch=1024, ref_steps=2048)["sizes"]
+    return out
+
+
+def small_batches(h, template, dev, seeds, params, cpu=True, sizes=(1, 16, 64, 256, 1024), pop=None, batch=None, ref_steps=512):
     """Calls that cannot fill the chip (MoveIt's own pattern is ONE pose per call, kinematics_plugin.cpp:437-655): ms per call for n = 1 ... 1024 queries of
     the headline workload, device arrays in and out, one call at a time, under the plugin's default (islands = BIOIK_ISLANDS_AUTO: as many islands as the idle
     part of the chip carries, stopping each other) and with one island; beside them the reference's own code on one host thread and on all of them for the
@@ -232,9 +247,11 @@ def small_batches(h, template, dev, seeds, params, cpu=True):
     import numpy as np
     import torch
     from bio_ik_amd import abi
-    sizes, out = (1, 16, 64, 256, 1024), []
-    pa = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1, islands=abi.ISLANDS_AUTO)
-    p1 = abi.default_solve_params(population=POP, max_steps=MAX_STEPS, random_seed=1)
+    out = []
+    pop = POP if pop is None else pop
+    batch = BATCH if batch is None else batch
+    pa = abi.default_solve_params(population=pop, max_steps=MAX_STEPS, random_seed=1, islands=abi.ISLANDS_AUTO)
+    p1 = abi.default_solve_params(population=pop, max_steps=MAX_STEPS, random_seed=1)
     s = torch.cuda.Stream(dev)
     r = None
     if cpu:
@@ -242,14 +259,14 @@ def small_batches(h, template, dev, seeds, params, cpu=True):
             from oracle import ref
             if ref.release_available():
                 r = ref.Reference(template, abi.default_solve_params(mode="bio2_memetic", random_seed=1), release=True)
-                r.solve_batch(seeds[:4], params[:4], 512)
+                r.solve_batch(seeds[:4], params[:4], ref_steps)
         except Exception:
             r = None
     for n in sizes:
         reps = 16 if n <= 256 else 4
         o = (torch.empty((n, h.V), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
              torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
-        sets = [((k * n) % (BATCH - n + 1)) for k in range(reps)]  # windows of the headline batch: different queries per call
+        sets = [((k * n) % (batch - n + 1)) for k in range(reps)]  # windows of the batch: different queries per call
         dsets = [(torch.from_numpy(seeds[a:a + n]).to(dev), torch.from_numpy(params[a:a + n]).to(dev)) for a in sets]
         e = {"n": n}
         for key, p in (("gpu_ms", pa), ("gpu_one_island_ms", p1)):
@@ -268,18 +285,78 @@ def small_batches(h, template, dev, seeds, params, cpu=True):
             if key == "gpu_ms":
                 e["gpu_solves_per_s"] = suc / float(np.sum(ts))
                 e["gpu_success_rate"] = suc / (reps * n)
-                e["gpu_islands"] = max(4, min(16, 2048 // n)) if n <= 1024 else 1
+                e["gpu_islands"] = max(max(4, min(16, 2048 // n)), min(64, 2048 // (4 * n))) if n <= 1024 else 1  # (bioik_compile.cpp: normalize_params)
                 e["gpu_max_steps_of_a_call"] = float(np.mean(st))
         if r is not None:
             ts = []
             for a in sets[:8 if n <= 256 else 2]:
                 t1 = time.perf_counter()
-                r.solve_batch(seeds[a:a + n], params[a:a + n], 512)
+                r.solve_batch(seeds[a:a + n], params[a:a + n], ref_steps)
                 ts.append(time.perf_counter() - t1)
             e["reference_1thread_ms"] = 1e3 * float(np.mean(ts))
         out.append(e)
     return {"sizes": out, "what": "ms per call, one call at a time, device arrays; gpu_ms: islands = BIOIK_ISLANDS_AUTO (the plugin's default); reference: oracle/_ref on ONE host thread, "
                                   "its own parameters (pop 16, linearised FK, <= 512 steps), the same queries"}
+
+
+def one_pose_timeouts(dev, cpu=True, n_calls=512):
+    """The drop-in claim where MoveIt lives: ONE pose per searchPositionIK call under the reference's timeouts (/root/reference/README.md:74-101: 1 ms recommended
+    for 6 - 7-DOF arms, 5 ms and 20 ms in its PR2 yaml; the loop is src/ik_parallel.h:160-190).  For four problems -- the PoseGoal arm, the arm with a secondary
+    MinimalDisplacementGoal, PR2 `all` (two PoseGoals + MinimalDisplacementGoal), the 31-joint snake with AvoidJointLimitsGoal -- `n_calls` single-pose calls each
+    through the PLUGIN path (bio_ik_amd/cpp/bio_ik/plugin_core.h: Engine::submit / wait per pose, looped inside the plugin library: bioik_plugin_search_each) at
+    the plugin's defaults (gpu_population 128, gpu_islands 0 = sized to the idle chip) with timeout = 1 / 5 / 20 ms: success rate and mean latency per call; beside
+    every cell the reference's own code (oracle/_ref, Release build, ONE solver thread, its wall-clock loop with the same timeout) on a bounded sample of the same
+    queries (<= 2.5 s of CPU per cell)."""
+    import numpy as np
+
+    from bio_ik_amd import AvoidJointLimitsGoal, MinimalDisplacementGoal, PoseGoal, ProblemTemplate, abi, pr2_like, snake
+    from bio_ik_amd.goals import BioIKKinematicsQueryOptions
+    from bio_ik_amd.plugin import BioIKKinematicsPlugin
+    from bio_ik_amd.solver import HipSolver
+    from bio_ik_amd.workload import make_queries
+    rows = []
+    for name, model, group, tips, extra in (
+            ("7-DOF arm, PoseGoal", pr2_like(), "right_arm", ["r_wrist_roll_link"], []),
+            ("7-DOF arm, PoseGoal + MinimalDisplacementGoal", pr2_like(), "right_arm", ["r_wrist_roll_link"], [MinimalDisplacementGoal()]),
+            ("PR2 all (15 DOF), 2 PoseGoals + MinimalDisplacementGoal", pr2_like(), "all", ["r_wrist_roll_link", "l_wrist_roll_link"], [MinimalDisplacementGoal()]),
+            ("31-joint snake, PoseGoal + AvoidJointLimitsGoal", snake(31), "snake", ["tip"], [AvoidJointLimitsGoal()])):
+        template = ProblemTemplate(model, group, [PoseGoal(t) for t in tips] + extra)
+        h = HipSolver(template, device=dev.index)
+        seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n_calls, seed=0x0E905E)
+        plug = BioIKKinematicsPlugin()
+        # (gpu_max_steps: the MoveIt face's default, bio_ik/plugin_core.h Settings -- the timeout is what ends a call, as in the reference)
+        plug.initialize(model, group, model.link_names[0], tips, params={"random_seed": 1, "gpu_devices": [dev.index], "gpu_max_steps": 4096})
+        gv = plug._group_vars
+        poses = np.stack([params[:, 8 * t:8 * t + 7] for t in range(len(tips))], axis=1)  # [n][tips][7]: the PoseGoals' numbers, in the root's frame
+        opts = BioIKKinematicsQueryOptions()
+        opts.goals = list(extra)
+        plug.searchPositionIKEach(poses[:8], seeds[:8, gv], opts, timeout=0.02)  # (handles, streams, the launcher's first calls)
+        r = None
+        if cpu:
+            try:
+                from oracle import ref
+                if ref.release_available():
+                    r = ref.Reference(template, abi.default_solve_params(mode="bio2_memetic", random_seed=1), release=True)
+                    if not hasattr(r.L, "ref_solve_batch_timeout"):
+                        r = None
+                    else:
+                        r.solve_batch_timeout(seeds[:4], params[:4], 0.005)
+            except Exception:
+                r = None
+        cells = []
+        for timeout in (0.001, 0.005, 0.020):
+            _, ok, _, sec = plug.searchPositionIKEach(poses, seeds[:, gv], opts, timeout=timeout)
+            c = {"timeout_ms": 1e3 * timeout, "gpu_success_rate": float(ok.mean()), "gpu_mean_ms": 1e3 * float(sec.mean()), "gpu_p99_ms": 1e3 * float(np.quantile(sec, 0.99))}
+            if r is not None:
+                m = max(16, min(n_calls, int(2.5 / timeout)))
+                _, _, suc, _, rsec = r.solve_batch_timeout(seeds[:m], params[:m], timeout)
+                c["reference_success_rate"], c["reference_mean_ms"], c["reference_calls"] = float(suc.mean()), 1e3 * float(rsec.mean()), m
+            cells.append(c)
+        rows.append({"problem": name, "calls": n_calls, "cells": cells})
+        plug.close()
+    return {"rows": rows, "what": "one pose per searchPositionIK call through the plugin core (plugin defaults: gpu_population 128, gpu_islands 0), timeout 1 / 5 / 20 ms: success rate, "
+                                  "mean and 99th-percentile latency per call; reference = oracle/_ref, Release build, one solver thread, its own wall-clock loop (src/ik_parallel.h:160-190), "
+                                  "its own parameters (16 children, linearised phenotypes), the same queries"}
 
 
 def main():
@@ -786,6 +863,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_SMALL", "1") != "0":
         out["small_batches"] = small_batches(h, template, dev, seeds, params, cpu=not args.no_cpu_baseline)
+        out["small_batches_secondary_goals"] = small_batches_secondary(dev, cpu=not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_ONE_POSE", "1") != "0":
+        out["one_pose_timeouts"] = one_pose_timeouts(dev, cpu=not args.no_cpu_baseline)
 
     if rank == 0:
         # the figures a reader looks for first, in one object at the END of the line (what a truncated tail still shows)
@@ -805,6 +885,9 @@ def main():
             "ms_per_call_n1_n16_n256": [r3(sb.get(k, {}).get("gpu_ms")) for k in ("1", "16", "256")],
             "ref_1thread_ms_n1_n16_n256": [r3(sb.get(k, {}).get("reference_1thread_ms")) for k in ("1", "16", "256")],
             "cpu_1thread": r3(out.get("cpu_baseline", {}).get("value")), "x_cpu": r3(out.get("speedup_vs_cpu_1thread")),
+            # one pose per plugin call with timeout 1 / 5 / 20 ms, per problem (arm; arm + MinimalDisplacement; PR2 all; snake): [gpu success, gpu ms, reference success, reference ms]
+            "one_pose_timeouts": [[[r3(c.get("gpu_success_rate")), r3(c.get("gpu_mean_ms")), r3(c.get("reference_success_rate")), r3(c.get("reference_mean_ms"))] for c in row["cells"]]
+                                  for row in out.get("one_pose_timeouts", {}).get("rows", [])],
         }
         print(json.dumps(out))
     if world > 1:

@@ -5,6 +5,7 @@
 // 465-641) are core::Engine's, reached through the few C entry points below (ctypes).  The Python side hands over flat arrays: the
 // model as a bioik_model_desc plus its name tables, the caller's goals as (opcode, link, variable, weight, secondary, numbers) records
 // -- the form every built-in goal of bio_ik_amd/goals.py serialises itself into.  Not part of the drop-in boundary (include/bioik_hip.h).
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -215,6 +216,26 @@ int bioik_plugin_wait(bioik_plugin* p, uint64_t ticket, double* solutions, uint8
             for (size_t i = 0; i < G; i++) solutions[k * G + i] = sols[k].size() == G ? sols[k][i] : f.seed_states[k][i];
         }
     });
+}
+
+// What MoveIt does with a list of poses: ONE searchPositionIK call per pose (kinematics_plugin.cpp:437-655), each with the caller's `timeout`, the next call when the
+// last has returned.  n such calls in a row -- submit and wait of one query each -- with the wall time of every call [s]: the figures of bench.py's
+// `one_pose_timeouts` leg, taken around the plugin core without the Python face's marshalling in them.  Arrays as for bioik_plugin_submit / _wait.
+int bioik_plugin_search_each(bioik_plugin* p, uint64_t n, const double* seeds, const double* tip_poses, const double* base_frame, const double* context, uint32_t n_goals,
+                             const bioik_plugin_goal* goals, int32_t replace, uint32_t n_fixed, const char* const* fixed_joints, double timeout,
+                             int32_t return_approximate_solution, double* solutions, uint8_t* ok, double* fitness, double* seconds) {
+    const size_t G = p->engine.modelView().group_vars.size();
+    const size_t T = replace ? 0 : p->tip_frames.size();
+    for (uint64_t k = 0; k < n; k++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t ticket = 0;
+        int rc = bioik_plugin_submit(p, 1, seeds + k * G, T ? tip_poses + k * T * 7 : nullptr, base_frame, context, n_goals, goals, replace, n_fixed, fixed_joints, timeout,
+                                     return_approximate_solution, &ticket);
+        if (rc == 0) rc = bioik_plugin_wait(p, ticket, solutions + k * G, ok + k, fitness + k);
+        if (rc != 0) return rc;
+        seconds[k] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
 }
 
 // the post-processing of bioik_plugin_wait on its own (:580-616), on full variable vectors: states [n][n_variables] in place

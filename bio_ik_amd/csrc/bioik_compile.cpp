@@ -633,6 +633,10 @@ DevSolveParams normalize_params(const bioik_solve_params& p, uint64_t first_quer
         // workgroups still gain from four, 896 queries 6.1 -> 5.1 ms --; beyond that one)
         size_t isl = std::min<size_t>(16, resident_units / n_queries);
         if (n_queries <= resident_units / 2) isl = std::max<size_t>(isl, 4);
+        // (round 6: a call of a few poses -- MoveIt's one pose per searchPositionIK -- leaves nearly all of the chip idle: 64 islands up to eight queries, 32 up to sixteen.
+        // One pose per call, 64 against 16 islands: PoseGoal arm 0.80 -> 0.75 ms, the arm with a MinimalDisplacementGoal 3.9 -> 3.6 ms and 0.84 -> 0.95 of the poses
+        // within a 5 ms timeout, the 31-joint chain 7.5 -> 6.8 ms: profiles/r06_one_pose_islands.log)
+        isl = std::max<size_t>(isl, std::min<size_t>(64, resident_units / (4 * n_queries)));
         o.islands = (int32_t)std::max<size_t>(1, isl);
     }
     o.max_steps = p.max_steps > 0 ? p.max_steps : 0;

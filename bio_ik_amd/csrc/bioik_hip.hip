@@ -366,6 +366,11 @@ struct bioik_problem {
         void* base = nullptr;
         size_t capacity = 0;
         bool pinned = false;
+        // purpose 0 (the islands' results): the control words of SolveArgs::island_done -- per query a count of the islands that have filed and the first_success word --
+        // lie at the buffer's start, `ctl_n` of each, and are back in their resting state (0 / 0xffffffff) whenever no solve is running on them: the kernel that uses
+        // them puts them back.  ctl_base != base (or a call of more than ctl_n queries): they have to be set up (a new buffer, a call of the other kind in between)
+        void* ctl_base = nullptr;
+        size_t ctl_n = 0;
     };
     std::map<std::pair<stream_t, int>, Scratch> scratch;
     // The launcher's MEASURED mapping choice (solve_dispatch): per kind of call -- (children per species, FK mode, islands or not) under the latency schedule --
@@ -427,6 +432,7 @@ struct SolveSwitches {
     int helped = 1024;  // BIOIK_SOLVE_HELPED=N: launches of up to N (query, island) units of a problem k_solve_lean_cl4 covers without a secondary goal run its helped
                         // build (k_solve_lean_cl4h: four wavefronts per unit), as do the stragglers a chip-filling call hands over; 0: never
     int debug_flags = 0;  // BIOIK_SOLVE_DEBUG_FLAGS (tests): SolveArgs::debug_flags
+    int fused_select = 1;  // BIOIK_SOLVE_FUSED_SELECT=0: the islands of a one-launch solve are reduced by k_select in a launch of its own (and the first_success words set up by a fill kernel), as until round 5
     int autotune = 1;  // BIOIK_SOLVE_AUTOTUNE: 1 (default) = the host-pointer entries time the eligible lane mappings on a handle's first chip-filling call of a kind and keep
                        // the fastest (solve_dispatch); 2 = the device-pointer entry does so too (it then waits for its stream once); 0 = the rules alone
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
@@ -473,6 +479,7 @@ static SolveSwitches parse_switches() {
     w.autotune = geti("BIOIK_SOLVE_AUTOTUNE", 1);
     w.helped = geti("BIOIK_SOLVE_HELPED", 1024);
     w.debug_flags = geti("BIOIK_SOLVE_DEBUG_FLAGS", 0);
+    w.fused_select = geti("BIOIK_SOLVE_FUSED_SELECT", 1);
     if (w.sort_key_drop < 10 || w.sort_key_drop > 52) w.sort_key_drop = 10;
     if (const char* e = std::getenv("BIOIK_SOLVE_TWO_PHASE")) {
         w.two_phase_set = true;
@@ -572,10 +579,18 @@ static void set_deadline(bioik_problem* p, const DevSolveParams& sp, stream_t st
     const auto now = std::chrono::steady_clock::now();
     if (!p->clock_valid || now - p->clock_host0 > std::chrono::seconds(4)) {
         try {
-            const auto t0 = std::chrono::steady_clock::now();
-            const unsigned long long dev = be_device_clock_now();
-            const auto t1 = std::chrono::steady_clock::now();
-            p->clock_dev0 = dev, p->clock_host0 = t0 + (t1 - t0) / 2, p->clock_valid = true;  // (the kernel ran somewhere between the two readings: +- half the ~30 us between them)
+            // (the first reading of a process pays for the reader's stream, its page-locked word and the kernel's first launch -- milliseconds, with the kernel at their
+            // END: paired with the middle of that interval the deadline of every call of the next four seconds came ~3 ms late, tools/timeout_probe.py.  So: one
+            // reading to set things up, then the pairing from the tighter of two)
+            if (!p->clock_valid) (void)be_device_clock_now();
+            std::chrono::steady_clock::duration best = std::chrono::steady_clock::duration::max();
+            for (int attempt = 0; attempt < 2; attempt++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                const unsigned long long dev = be_device_clock_now();
+                const auto t1 = std::chrono::steady_clock::now();
+                if (t1 - t0 < best) best = t1 - t0, p->clock_dev0 = dev, p->clock_host0 = t0 + (t1 - t0) / 2;  // (the kernel ran somewhere between the two readings: +- half the ~30 us between them)
+            }
+            p->clock_valid = true;
         } catch (const Error&) {
             if (!p->clock_valid) throw;  // (a reading that is a few seconds old still serves: the clocks drift by parts per million)
         }
@@ -627,25 +642,50 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         stream_t s;
         ~AsyncFree() { be_free_async(p, s); }
     } island_ws_guard{island_ws, stream};
-    // where the launch writes its results: the caller's arrays, or (islands > 1) per-island arrays that select_islands then reduces
-    auto result_arrays = [&](SolveArgs& args) {
+    // where the launch writes its results: the caller's arrays, or (islands > 1) per-island arrays that are then reduced to them -- by the query's last island
+    // itself (`fused`: SolveArgs::island_done; one launch in all) or by k_select behind the solve's launches (select_islands)
+    bool fused_select = false;
+    auto result_arrays = [&](SolveArgs& args, bool fused) {
         if (sp.islands == 1) {
             args.solutions = d_solutions, args.fitness = d_fitness, args.success = d_success, args.steps = d_steps;
             return;
         }
         const size_t per = (size_t)dp.V * 8 + 8 + 4 + 4;
-        char* w = (char*)scratch(0, units * per + 64 + n * 4, island_ws);
+        const size_t ctl_n = fused ? std::max<size_t>(n, 256) : 0;  // (the control words of the fused form: room for calls of up to this many queries)
+        const size_t ctl_bytes = (2 * ctl_n * 4 + 63) / 64 * 64;
+        char* w = (char*)scratch(0, ctl_bytes + units * per + 64 + n * 4, island_ws);
+        bioik_problem::Scratch* sc = nullptr;
+        {
+            auto it = p->scratch.find(std::make_pair(stream, 0));
+            if (it != p->scratch.end() && it->second.base == (void*)w) sc = &it->second;
+        }
+        if (fused) {
+            size_t have = sc && sc->ctl_base == (void*)w ? sc->ctl_n : 0;
+            if (have < n) {  // a new buffer, a larger call, or a call of the other kind in between: set the words up (the kernels keep them from then on)
+                be_fill_ff_async(w, ctl_n * 4, stream);
+                be_zero_async(w + ctl_n * 4, ctl_n * 4, stream);
+                have = ctl_n;
+                if (sc) sc->ctl_base = (void*)w, sc->ctl_n = ctl_n;
+            }
+            if (sp.island_sync) args.first_success = (unsigned int*)w;
+            args.island_done = (unsigned int*)(w + have * 4);
+            args.final_solutions = d_solutions, args.final_fitness = d_fitness, args.final_success = d_success, args.final_steps = d_steps;
+            w += (2 * have * 4 + 63) / 64 * 64;
+            fused_select = true;
+        } else if (sc) {
+            sc->ctl_base = nullptr, sc->ctl_n = 0;  // (this call lays the buffer out its own way)
+        }
         args.solutions = (double*)w, w += units * dp.V * 8;
         args.fitness = (double*)w, w += units * 8;
         args.success = (int32_t*)w, w += units * 4;
         args.steps = (int32_t*)w, w += units * 4;
-        if (sp.island_sync) {  // "any island succeeds => all stop": the least step count of a passing island, per query (0xffffffff: none yet)
+        if (!fused && sp.island_sync) {  // "any island succeeds => all stop": the least step count of a passing island, per query (0xffffffff: none yet)
             args.first_success = (unsigned int*)w;
             be_fill_ff_async(args.first_success, n * 4, stream);
         }
     };
     auto select_islands = [&](const SolveArgs& args) {  // ik_parallel.h:220-269: the best island of every query
-        if (sp.islands == 1) return;
+        if (sp.islands == 1 || fused_select) return;
         SelectArgs s;
         s.islands = sp.islands, s.V = dp.V, s.n = n;
         s.sync = sp.island_sync, s.pad = 0;
@@ -658,7 +698,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         if (lds_point > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem too large for the gd / jac kernels (more than 64 KiB of LDS per query)");
         SolveArgs pa;
         pa.pb = p->pb(), pa.sp = sp, pa.seeds = d_seeds, pa.params = d_params;
-        result_arrays(pa);
+        result_arrays(pa, false);
         pa.phase_cycles = nullptr;
         set_deadline(p, sp, stream, pa);
         LAUNCH(k_solve_point, point_body(pa, b_, l_), units, 64, lds_point, stream, pa);
@@ -827,7 +867,6 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     const char* phase_path = sw.phase_dump.empty() ? nullptr : sw.phase_dump.c_str();
     if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
 #endif
-    result_arrays(a);
     auto launch = [&](const SolveArgs& args, int lanes, size_t lds_b) {
         // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
@@ -916,6 +955,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) handovers.clear();
 #endif
+    // (a solve in ONE launch reduces its islands itself, SolveArgs::island_done; BIOIK_SOLVE_FUSED_SELECT=0: by k_select as before)
+    result_arrays(a, handovers.empty() && sw.fused_select != 0);
     // the mapping with both species of a query on the halves of ONE wavefront, children computed where they are read and walked in pairs: the
     // first launch of a solve in several launches, and the whole of a throughput solve
     auto halves = [&](SolveArgs& aj, int& lanes, size_t& lds_j) {
@@ -1200,12 +1241,14 @@ static void io_finish(bioik_problem* p, bioik_problem::IoSlot& sl) {
         // stay untouched, and the slot is free again
         sl.failed_ticket = sl.ticket, sl.failed_code = e.code, sl.failed_message = e.what();
         sl.pending = false;
+        for (auto& kv : p->scratch) kv.second.ctl_base = nullptr;  // (a solve that broke off may have left its control words anywhere: set up again)
         return;
     }
     sl.pending = false;
     unsigned int& err = p->h_error[&sl - p->io];
     if (err != 0u) {  // (SolveArgs::error: a wavefront of this solve gave up waiting for its partner and went on unsynchronised)
         err = 0u;
+        for (auto& kv : p->scratch) kv.second.ctl_base = nullptr;
         sl.failed_ticket = sl.ticket, sl.failed_code = BIOIK_ERR_HIP;
         sl.failed_message = "a rendezvous between the wavefronts of a workgroup timed out (k_solve_lean_cl4h): the results of this solve are not valid";
         return;
@@ -1243,13 +1286,17 @@ static void io_begin(bioik_problem* p, bioik_problem::IoSlot& sl, uint64_t ticke
     const stream_t st = sl.stream;
     std::memcpy(hd + o_seeds, seeds, n * V * 8);
     if (P) std::memcpy(hd + o_par, goal_params, n * P * 8);
-    be_h2d(dd, hd, in_bytes, st);
+    // (a call of a few queries -- MoveIt's one pose per call -- reads its inputs where they lie: the page-locked arena is mapped into the device's address space, and a
+    // few hundred bytes per workgroup over the bus cost less than a DMA transfer in front of the launch)
+    const bool direct_inputs = n <= 16;
+    if (!direct_inputs) be_h2d(dd, hd, in_bytes, st);
+    const char* in_base = direct_inputs ? hd : dd;
     DevSolveParams sp = bioik::normalize_params(params, first_query, n, 8 * (size_t)p->model->dev.cus);
     // The results go from the kernels straight into the page-locked arena (it is mapped into the device's address space; 1.5 MB per 4096 queries,
     // written once per query).  A transfer out enqueued behind the solve would sit at the head of a DMA queue until the solve is over -- 12 ms
     // for a one-launch solve -- with the transfers in of the handle's next solves behind it: nothing would overlap
     // (profiles/r03_inflight_and_schedule.log, host pipeline).
-    solve_dispatch(p, sp, n, (const double*)(dd + o_seeds), (const double*)(dd + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
+    solve_dispatch(p, sp, n, (const double*)(in_base + o_seeds), (const double*)(in_base + o_par), (double*)(hd + o_sol), (double*)(hd + o_fit), (int32_t*)(hd + o_suc),
                    (int32_t*)(hd + o_steps), st, true, p->h_error + (&sl - p->io));
     sl.pending = true, sl.ticket = ticket, sl.n = n;
     sl.o_sol = o_sol, sl.o_fit = o_fit, sl.o_suc = o_suc, sl.o_steps = o_steps;

@@ -385,6 +385,48 @@ BIOIK_NOINLINE void build_approximator(PB pb, XV x, double* slots, double* s_fra
     group_sync(G);
 }
 
+// best island per query (ik_parallel.h:220-269); one lane per query
+struct SelectArgs {
+    int islands, V;
+    int sync, pad;  // sync: only the islands that passed after the LEAST number of steps are candidates (bioik_solve_params::island_sync)
+    uint64_t n;
+    const double* isl_solutions;
+    const double* isl_fitness;
+    const int32_t* isl_success;
+    const int32_t* isl_steps;
+    double* solutions;
+    double* fitness;
+    int32_t* success;
+    int32_t* steps;
+};
+// (the islands' results were written by the launches in front of this one: device-scope loads, p_load_device)
+BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
+    if (q >= a.n) return;
+    int best = 0;
+    double best_fit = BIOIK_DBL_MAX;
+    int least_steps = 0x7fffffff;
+    if (a.sync)
+        for (int i = 0; i < a.islands; i++) {
+            uint64_t u = q * (uint64_t)a.islands + i;
+            if (p_load_device(a.isl_success + u) && p_load_device(a.isl_steps + u) < least_steps) least_steps = p_load_device(a.isl_steps + u);
+        }
+    for (int i = 0; i < a.islands; i++) {
+        uint64_t u = q * (uint64_t)a.islands + i;
+        if (p_load_device(a.isl_success + u) && (!a.sync || p_load_device(a.isl_steps + u) == least_steps) && p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
+    }
+    if (best_fit == BIOIK_DBL_MAX) {
+        for (int i = 0; i < a.islands; i++) {
+            uint64_t u = q * (uint64_t)a.islands + i;
+            if (p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
+        }
+    }
+    uint64_t u = q * (uint64_t)a.islands + best;
+    for (int v = 0; v < a.V; v++) a.solutions[q * a.V + v] = p_load_device(a.isl_solutions + u * a.V + v);
+    a.fitness[q] = best_fit;
+    a.success[q] = p_load_device(a.isl_success + u);
+    a.steps[q] = p_load_device(a.isl_steps + u);
+}
+
 struct SolveArgs {
     ProbPtr pb;
     DevSolveParams sp;
@@ -411,6 +453,15 @@ struct SolveArgs {
     // an island of the query has passed the success test (the host fills it with 0xffffffff).  An island that passes files its step count (atomic
     // minimum); an island that finds a count <= its own leaves, because k_select only considers the islands that passed at the least count.
     unsigned int* first_success = nullptr;    // [n]
+    // One launch for a call with islands (round 6; calls that cannot fill the chip: MoveIt's one pose per call): an island that has written its result counts itself
+    // in a word of its query, and the island that completes the count picks the query's best island itself (select_body: what k_select does in a launch of its own)
+    // and puts the query's two words back -- the count to 0, first_success to 0xffffffff --, so that the next call finds them as it needs them and no launch has
+    // to set them up.  Null: the islands' results are reduced by k_select (solves in several launches, the gradient family).
+    unsigned int* island_done = nullptr;      // [n]
+    double* final_solutions = nullptr;        // the caller's arrays: [n][V], [n], [n], [n]
+    double* final_fitness = nullptr;
+    int32_t* final_success = nullptr;
+    int32_t* final_steps = nullptr;
     // Hand-over when the chip runs empty (the throughput schedule's straggler tail): the workgroups of every launch that carries this word count
     // their wavefronts in it while they run (the launches that take the stragglers over too: their work keeps the chip busy just as well).  New workgroups start as fast as old ones leave while any launch has work queued, so a count below `drain_below`
     // means the queue is empty and the chip is emptying: a unit that has run `drain_min_steps` steps then leaves for the next launch (the mapping with
@@ -1828,49 +1879,24 @@ BIOIK_DEV void solve_body(const SolveArgs& a, uint64_t unit_in, double* lds) {
         a.steps[unit] = steps;
     }
     if constexpr (HELPED) p_flag_store((unsigned int*)(lds + L.help) + 2 + p_wave_index(), 0xffffffffu);  // this wavefront's helper may leave
+    if (a.island_done && !handed_over) {  // (SolveArgs::island_done: the query's last island to file its result reduces the islands)
+        p_fence_device();  // this lane's part of the result is visible to the whole device ...
+        wg_barrier();      // ... and so is every other lane's
+        if (tid == 0) {
+            const unsigned int filed = p_atomic_inc(a.island_done + q);
+            if (filed + 1u == (unsigned int)sp.islands) {
+                p_fence_device();
+                SelectArgs sa;
+                sa.islands = sp.islands, sa.V = V, sa.sync = sp.island_sync, sa.pad = 0, sa.n = q + 1;
+                sa.isl_solutions = a.solutions, sa.isl_fitness = a.fitness, sa.isl_success = a.success, sa.isl_steps = a.steps;
+                sa.solutions = a.final_solutions, sa.fitness = a.final_fitness, sa.success = a.final_success, sa.steps = a.final_steps;
+                select_body(sa, q);
+                p_store_device(a.island_done + q, 0u);
+                if (a.first_success) p_store_device(a.first_success + q, 0xffffffffu);
+            }
+        }
+    }
     BIOIK_EPILOGUE_SCOPE_END
-}
-
-// best island per query (ik_parallel.h:220-269); one lane per query
-struct SelectArgs {
-    int islands, V;
-    int sync, pad;  // sync: only the islands that passed after the LEAST number of steps are candidates (bioik_solve_params::island_sync)
-    uint64_t n;
-    const double* isl_solutions;
-    const double* isl_fitness;
-    const int32_t* isl_success;
-    const int32_t* isl_steps;
-    double* solutions;
-    double* fitness;
-    int32_t* success;
-    int32_t* steps;
-};
-// (the islands' results were written by the launches in front of this one: device-scope loads, p_load_device)
-BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
-    if (q >= a.n) return;
-    int best = 0;
-    double best_fit = BIOIK_DBL_MAX;
-    int least_steps = 0x7fffffff;
-    if (a.sync)
-        for (int i = 0; i < a.islands; i++) {
-            uint64_t u = q * (uint64_t)a.islands + i;
-            if (p_load_device(a.isl_success + u) && p_load_device(a.isl_steps + u) < least_steps) least_steps = p_load_device(a.isl_steps + u);
-        }
-    for (int i = 0; i < a.islands; i++) {
-        uint64_t u = q * (uint64_t)a.islands + i;
-        if (p_load_device(a.isl_success + u) && (!a.sync || p_load_device(a.isl_steps + u) == least_steps) && p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
-    }
-    if (best_fit == BIOIK_DBL_MAX) {
-        for (int i = 0; i < a.islands; i++) {
-            uint64_t u = q * (uint64_t)a.islands + i;
-            if (p_load_device(a.isl_fitness + u) < best_fit) best_fit = p_load_device(a.isl_fitness + u), best = i;
-        }
-    }
-    uint64_t u = q * (uint64_t)a.islands + best;
-    for (int v = 0; v < a.V; v++) a.solutions[q * a.V + v] = p_load_device(a.isl_solutions + u * a.V + v);
-    a.fitness[q] = best_fit;
-    a.success[q] = p_load_device(a.isl_success + u);
-    a.steps[q] = p_load_device(a.isl_steps + u);
 }
 
 // ---------------------------------------------------------------------------------------------------------

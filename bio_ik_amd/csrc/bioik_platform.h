@@ -132,6 +132,8 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
     return old ? old : value;
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return atomicAdd(counter, 1u); }  // returns the value before
+// what this lane has written is visible to every workgroup of the device / what they have written is visible to this lane (agent scope: the chip's eight L2s)
+BIOIK_DEV void p_fence_device() { __threadfence(); }
 BIOIK_DEV int p_xcc_id() { return (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u); }  // the XCD this wavefront runs on (hardware register XCC_ID)
 // One 32-bit word from device memory straight into LDS (global_load_lds_dword: no register receives it, so nothing waits for it until p_prefetched_word
 // does).  Called by ONE lane (the instruction writes lane l's word at the LDS address + 4 l).  The compiler does not know of the load: its own waits on the

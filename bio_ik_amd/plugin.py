@@ -67,6 +67,7 @@ def load_shim(path=None):
     L.bioik_plugin_group_variables.restype = None
     L.bioik_plugin_submit.argtypes = [vp, u64, dp, dp, dp, dp, u32, C.POINTER(_WireGoal), i32, u32, strs, C.c_double, i32, C.POINTER(u64)]
     L.bioik_plugin_wait.argtypes = [vp, u64, dp, C.POINTER(C.c_uint8), dp]
+    L.bioik_plugin_search_each.argtypes = [vp, u64, dp, dp, dp, dp, u32, C.POINTER(_WireGoal), i32, u32, strs, C.c_double, i32, dp, C.POINTER(C.c_uint8), dp, dp]
     L.bioik_plugin_postprocess.argtypes = [vp, u64, dp, dp, u32, C.POINTER(i32)]
     _shims[path] = L
     return L
@@ -240,6 +241,47 @@ class BioIKKinematicsPlugin:
         if bio is not None and n:
             bio.solution_fitness = float(fit[-1])  # :632-634
         return solutions, ok, fit, codes
+
+    def searchPositionIKEach(self, ik_poses, ik_seed_states, options=None, context_state=None, timeout=0.0):
+        """n poses the way MoveIt asks for them: ONE searchPositionIK call per pose, each with `timeout`, the next when the last has returned -- looped inside
+        the plugin library (bioik_plugin_search_each), so that the wall time of every call is the plugin core's, not this face's marshalling.
+        -> (solutions [n][group variables], ok [n] bool, fitness [n], seconds [n])"""
+        self._push_params()
+        options = options or KinematicsQueryOptions()
+        m = self.robot_model
+        G = len(self._group_vars)
+        seeds = np.ascontiguousarray(np.asarray(ik_seed_states, dtype=np.float64).reshape(-1, G))
+        n = seeds.shape[0]
+        bio = options if isinstance(options, BioIKKinematicsQueryOptions) else None
+        replace = bool(bio and bio.replace)
+        caller = list(bio.goals) if bio else []
+        fixed = list(bio.fixed_joints) if bio else []
+        wire = (_WireGoal * max(len(caller), 1))()
+        keep = []
+        for w, g in zip(wire, caller):
+            if g.opcode is None:
+                raise NotImplementedError("%s has no device implementation (host-callback goal)" % type(g).__name__)
+            numbers = np.zeros(abi.GOAL_PARAM_COUNT[g.opcode])
+            pnum = np.asarray(g.params(), dtype=np.float64)
+            numbers[:len(pnum)] = pnum
+            keep.append(numbers)
+            w.opcode, w.secondary, w.n_numbers, w.weight = g.opcode, int(g.isSecondary()), len(numbers), g.getWeight()
+            w.link = (g.link_name() or "").encode()
+            w.variable = (g.variable_name() or "").encode()
+            w.numbers = abi.dptr(numbers)
+        if context_state is None:
+            context, base = m.default_positions(), self._base_default
+        else:
+            context = np.ascontiguousarray(np.asarray(context_state, dtype=np.float64).reshape(m.n_variables))
+            base = link_transform(m, self._base_link, context)
+        base = np.ascontiguousarray(base, dtype=np.float64)
+        poses = np.zeros(0) if replace else np.ascontiguousarray(np.asarray(ik_poses, dtype=np.float64).reshape(n, len(self.tip_frames), 7))
+        solutions, ok, fit, seconds = np.zeros((n, G)), np.zeros(n, dtype=np.uint8), np.zeros(n), np.zeros(n)
+        self._chk(self._L.bioik_plugin_search_each(self._h, n, abi.dptr(seeds), abi.dptr(poses) if poses.size else None, abi.dptr(base), abi.dptr(context), len(caller), wire,
+                                                   int(replace), len(fixed), _strs(fixed), float(timeout) if timeout and timeout > 0.0 else 0.0,
+                                                   int(bool(getattr(options, "return_approximate_solution", False))), abi.dptr(solutions), abi.u8ptr(ok), abi.dptr(fit),
+                                                   abi.dptr(seconds)))
+        return solutions, ok != 0, fit, seconds
 
     def searchPositionIKBatch(self, ik_poses, ik_seed_states, options=None, context_state=None, timeout=0.0):
         return self.searchPositionIKBatchWait(self.searchPositionIKBatchAsync(ik_poses, ik_seed_states, options, context_state, timeout))

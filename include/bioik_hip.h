@@ -120,7 +120,9 @@ enum {
  *   with three in flight, 0.94e6 with six; an isolated call stays as fast as it can be). */
 enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1, BIOIK_SCHEDULE_AUTO = 2 };
 /* bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): as many islands per query as the part of the chip the call leaves idle can carry,
- * min(16, 2048 / n) but at least four for a call of n <= 1024 queries (per device), one beyond that, stopping each other (island_sync is then taken as 1) -- the reference's
+ * min(16, 2048 / n) but at least four for a call of n <= 1024 queries (per device), one beyond that -- and, since round 6, 64 for calls of up to eight queries and 32 up to
+ * sixteen (MoveIt's one pose per call: 64 against 16 islands is 0.80 -> 0.75 ms for a PoseGoal on a 7-joint arm, 3.9 -> 3.6 ms with a secondary MinimalDisplacementGoal) --,
+ * stopping each other (island_sync is then taken as 1) -- the reference's
  * four island threads with "any thread succeeds => all stop" (ik_parallel.h:102, 141-178), sized to the hardware.  A call that cannot fill the
  * chip is bound by its slowest query's number of steps, and islands cut exactly that: MI355X, PoseGoal on a 7-joint arm, pop 128: 16 queries
  * 3.3 -> 1.25 ms per call, 256 queries 6.2 -> 3.3 ms, 896 queries 6.1 -> 5.1 ms, one query 0.93 -> 0.79 ms (profiles/r05_small_batches.log; with the helped kernel

@@ -70,6 +70,8 @@ def _declare(L):
     L.ref_solver_step.argtypes = [C.c_void_p]
     L.ref_solver_result.argtypes = [C.c_void_p, _pd, _pd, _pi]
     L.ref_solve_batch.argtypes = [C.c_void_p, C.c_size_t, _pd, _pd, C.c_int, _pd, _pd, _pi, _pi]
+    if hasattr(L, "ref_solve_batch_timeout"):
+        L.ref_solve_batch_timeout.argtypes = [C.c_void_p, C.c_size_t, _pd, _pd, C.c_double, _pd, _pd, _pi, _pi, _pd]
     return L
 
 
@@ -177,6 +179,17 @@ class Reference:
         suc, steps = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
         self._chk(self.L.ref_solve_batch(self._h, C.c_size_t(n), _d(s), _d(gp), C.c_int(max_steps), _d(sol), _d(fit), _i(suc), _i(steps)))
         return sol, fit, suc, steps
+
+    def solve_batch_timeout(self, seeds, goal_params, timeout):
+        """n queries, one after the other, each under the reference's wall-clock loop with `timeout` [s] (src/ik_parallel.h:160-184, one solver thread)
+        -> (solutions, fitness, success, steps, seconds per query)"""
+        s = _f64(seeds).reshape(-1, self.V)
+        n = s.shape[0]
+        gp = _f64(goal_params).reshape(n, self.P) if self.P else np.zeros((n, 1))
+        sol, fit, sec = np.zeros((n, self.V)), np.zeros(n), np.zeros(n)
+        suc, steps = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._chk(self.L.ref_solve_batch_timeout(self._h, C.c_size_t(n), _d(s), _d(gp), C.c_double(timeout), _d(sol), _d(fit), _i(suc), _i(steps), _d(sec)))
+        return sol, fit, suc, steps, sec
 
     def solve_steps(self, seed, goal_params, n_steps):
         """IKEvolution2 through the reference's IKFactory: solution / exact fitness / success after every step()."""

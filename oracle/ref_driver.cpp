@@ -11,6 +11,7 @@
 
 #include "ik_base.h"
 
+#include <chrono>
 #include <bio_ik/goal_types.h>
 
 #include "../include/bioik_hip.h"
@@ -485,6 +486,48 @@ int ref_solve_batch(void* h, size_t n, const double* seeds, const double* params
             fit = ik->computeFitness(sol, ik->model.getTipFrames());
             if (ok) break;
         }
+        for (size_t v = 0; v < V; v++) solutions[q * V + v] = sol[v];
+        fitness[q] = fit, success[q] = ok ? 1 : 0, steps[q] = st;
+    }
+    return 0;
+    CATCH(-1)
+}
+
+// The same n queries under the reference's WALL-CLOCK loop (src/ik_parallel.h:160-184, one solver thread): steps in groups of four while the clock is below the
+// call's timeout, the success test behind every group, at least one group -- what searchPositionIK does with its `timeout` argument (kinematics_plugin.cpp:504,
+// 566-578).  seconds [n]: the wall time of every query from the moment its goals are set (the plugin's t0) to the end of its loop.  bench.py's `one_pose_timeouts`.
+int ref_solve_batch_timeout(void* h, size_t n, const double* seeds, const double* params, double timeout, double* solutions, double* fitness, int32_t* success,
+                            int32_t* steps, double* seconds) {
+    TRY
+    Ref& r = *(Ref*)h;
+    size_t V = r.model->getVariableCount(), P = (size_t)r.P;
+    if (!r.batch_solver) r.batch_solver.reset(IKFactory::create(r.ikparams.solver_class_name, r.ikparams));  // once, like the plugin
+    IKSolver* ik = r.batch_solver.get();
+    ik->thread_index = 0;
+    std::vector<double> zero(1, 0.0);
+    typedef std::chrono::steady_clock clock;
+    for (size_t q = 0; q < n; q++) {
+        const clock::time_point t0 = clock::now();
+        const clock::time_point deadline = t0 + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(timeout));
+        r.set_query(seeds + q * V, P ? params + q * P : zero.data());
+        ik->canceled = false;
+        ik->initialize(r.problem);
+        int st = 0;
+        bool ok = false;
+        double fit = DBL_MAX;
+        std::vector<double> sol(seeds + q * V, seeds + (q + 1) * V);
+        for (size_t iteration = 0; clock::now() < deadline || iteration == 0; iteration++) {
+            ik->step();
+            st++;
+            for (int it2 = 1; it2 < 4; it2++)
+                if (clock::now() < deadline) ik->step(), st++;
+            sol = ik->getSolution();
+            ik->model.applyConfiguration(sol);
+            ok = ik->checkSolution(sol, ik->model.getTipFrames());
+            fit = ik->computeFitness(sol, ik->model.getTipFrames());
+            if (ok) break;
+        }
+        seconds[q] = std::chrono::duration<double>(clock::now() - t0).count();
         for (size_t v = 0; v < V; v++) solutions[q * V + v] = sol[v];
         fitness[q] = fit, success[q] = ok ? 1 : 0, steps[q] = st;
     }

@@ -109,6 +109,7 @@ BIOIK_DEV unsigned long long p_stamp_once(unsigned long long* word, unsigned lon
 }
 BIOIK_DEV unsigned int p_atomic_inc(unsigned int* counter) { return __atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL); }
 BIOIK_DEV int p_xcc_id() { return 0; }
+BIOIK_DEV void p_fence_device() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 BIOIK_DEV void p_prefetch_word_to_lds(const unsigned int* src, double* lds_slot) { *(unsigned int*)lds_slot = __atomic_load_n(src, __ATOMIC_RELAXED); }
 BIOIK_DEV unsigned int p_prefetched_word(const double* lds_slot) { return *(const unsigned int*)lds_slot; }
 BIOIK_DEV void p_atomic_add(unsigned int* counter, unsigned int v) { (void)__atomic_fetch_add(counter, v, __ATOMIC_ACQ_REL); }

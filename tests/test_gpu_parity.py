@@ -802,7 +802,8 @@ def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.all(b[3] <= a[3]) and b[3].mean() < a[3].mean()
     assert all(np.array_equal(x, y) for x, y in zip(b, c))
     # islands = BIOIK_ISLANDS_AUTO: sized to the part of the chip the call leaves idle (min(16, 2048 / n), at least four up to 1024 queries, one beyond), stopping each other
-    for n, want in ((1, 16), (200, 10), (700, 4), (1024, 4), (1025, 1), (2048, 1)):
+    # (round 6: 64 islands up to eight queries, 32 up to sixteen -- MoveIt's one pose per call)
+    for n, want in ((1, 64), (16, 32), (200, 10), (700, 4), (1024, 4), (1025, 1), (2048, 1)):
         d = h.solve_batch(abi.default_solve_params(population=128, max_steps=48, random_seed=2, islands=abi.ISLANDS_AUTO), seeds[:n], params[:n])
         e = h.solve_batch(abi.default_solve_params(population=128, max_steps=48, random_seed=2, islands=want, island_sync=1), seeds[:n], params[:n])
         assert all(np.array_equal(x, y) for x, y in zip(d, e)), n

@@ -677,14 +677,23 @@ def test_islands_that_stop_each_other(sims, oracles, templates, monkeypatch):
 
 
 def test_islands_sized_to_the_idle_chip(sims, templates):
-    """bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): min(16, 2048 / n) islands per query (at least four up to 1024 queries, one beyond) that stop each other -- the same solve as that count
+    """bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): min(16, 2048 / n) islands per query (at least four up to 1024 queries, one beyond; 64 up to eight queries and 32 up to sixteen since round 6) that stop each other -- the same solve as that count
     given explicitly with island_sync = 1; the gradient family keeps one island (an island count there names another solver)"""
     h, t = sims["c2"], templates["c2"]
     seeds, params, _ = make_queries(t, h.active_variables, h.fk_genes, 3, seed=21)
     a = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=abi.ISLANDS_AUTO, fk_mode=abi.FK_LINEAR), seeds, params)
-    b = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=16, island_sync=1, fk_mode=abi.FK_LINEAR), seeds, params)
+    b = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=64, island_sync=1, fk_mode=abi.FK_LINEAR), seeds, params)
     c = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=1, fk_mode=abi.FK_LINEAR), seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[0], c[0])
+    # bioik_resolve_islands: what a caller that shards a request itself asks once per request (the plugin over several devices)
+    import ctypes
+    isl, sync = ctypes.c_int32(), ctypes.c_int32()
+    for n, want in ((1, 64), (8, 64), (16, 32), (32, 16), (200, 10), (700, 4), (1024, 4), (1025, 1)):
+        p = abi.default_solve_params(islands=abi.ISLANDS_AUTO)
+        assert h.L.bioik_resolve_islands(h.problem, ctypes.byref(p), ctypes.c_size_t(n), ctypes.byref(isl), ctypes.byref(sync)) == 0
+        assert (isl.value, sync.value) == (want, 1 if want > 1 else 0), (n, isl.value, sync.value)
+    p = abi.default_solve_params(islands=3)
+    assert h.L.bioik_resolve_islands(h.problem, ctypes.byref(p), ctypes.c_size_t(5), ctypes.byref(isl), ctypes.byref(sync)) == 0 and (isl.value, sync.value) == (3, 0)
     g0 = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=abi.ISLANDS_AUTO, mode="gd_c"), seeds, params)
     g1 = h.solve_batch(abi.default_solve_params(population=16, max_steps=6, random_seed=3, islands=1, mode="gd_c"), seeds, params)
     assert all(np.array_equal(x, y) for x, y in zip(g0, g1))
