@@ -232,13 +232,6 @@ __global__ void __launch_bounds__(64, BIOIK_DENSE_WAVES) k_solve_lean_cl64w4(Sol
     extern __shared__ double lds[];
     solve_body<true, true, false, true, 1>(a, blockIdx.x, lds);
 }
-// Computed children with both species of a query on the halves of one wavefront AND secondary goals: the children of the two species are walked
-// as one list over the 64 lanes (solve_body<.., JOINT>), so that the wavefront does not wait for the longer of two random prefixes (C3: +7 %,
-// profiles/r03_ab_joint_walk.log)
-__global__ void __launch_bounds__(64, BIOIK_SOLVE_WAVES_PER_SIMD) k_solve_lean_clj(SolveArgs a) {
-    extern __shared__ double lds[];
-    solve_body<true, true, true>(a, blockIdx.x, lds);
-}
 // Populations of up to 32 children per species with LINEARISED phenotypes (the reference's own parameters: 16 children, RobotFK_Mutator): both species on
 // the halves of one wavefront, children computed where they are read, under the register budget of four wavefronts per SIMD (solve_body<.., FIXED = 3>).
 // Such solves are bound by the latency of their single-individual phases (linearisation, line search, ranking), not by arithmetic: sixteen queries
@@ -247,8 +240,10 @@ __global__ void __launch_bounds__(64, 4) k_solve_lean_lin(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, false, true, 3>(a, blockIdx.x, lds);
 }
-// The joint walk under the register budget of four wavefronts per SIMD (solve_body<.., FIXED = 4>: fitness values parked in LDS, accessors rebuilt behind
-// the walks): picked where a CU's LDS holds more than the twelve queries k_solve_lean_clj's 135 ... 168 registers allow
+// Computed children with both species of a query on the halves of one wavefront AND secondary goals: the children of the two species are walked as one list over
+// the 64 lanes (solve_body<.., JOINT>), so that the wavefront does not wait for the longer of two random prefixes (C3: +7 %, profiles/r03_ab_joint_walk.log) -- under
+// the register budget of four wavefronts per SIMD (FIXED = 4: fitness values parked in LDS, accessors rebuilt behind the walks).  (Its 168-register sibling
+// k_solve_lean_clj of rounds 3 - 5 served the one LDS band in which a CU holds exactly twelve queries; retired in round 6: this build runs there too.)
 __global__ void __launch_bounds__(64, 4) k_solve_lean_clj4(SolveArgs a) {
     extern __shared__ double lds[];
     solve_body<true, true, true, true, 4>(a, blockIdx.x, lds);
@@ -297,7 +292,6 @@ static void be_allow_lds(size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_cl64w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_lin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_solve_lean_clj4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -622,6 +616,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                     sc.pinned = true;  // (the graph being captured keeps this address: see bioik_problem::Scratch)
                     return sc.base;
                 }
+                // (a stream-ordered allocation inside the capture would replay once and abort at the second replay on this ROCm: refuse, and say what to do)
+                throw Error(BIOIK_ERR_UNSUPPORTED, "a solve captured into a hipGraph needs scratch memory this handle does not hold yet for the stream: run ONE eager call of the same size "
+                                                   "(queries, islands) on the stream before capturing");
             } else {
                 if (sc.pinned) p->retired_scratch.push_back(sc.base), sc = bioik_problem::Scratch{};
                 if (sc.capacity >= bytes) return sc.base;
@@ -880,7 +877,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         // profiles/r03_ab_joint_walk.log)
         const bool joint = lanes == 64 && args.sp.species_parallel && args.sp.child_pairs && dp.n_secondary > 0 && args.sp.fk_mode == BIOIK_FK_EXACT &&
                            !sw.no_joint;
-        const bool joint4 = joint && !sw.three_waves && (kLds / lds_b) > 12;  // (more queries per CU than the three-wavefront kernel can hold)
+        const bool joint4 = joint;  // (k_solve_lean_clj4 wherever the joint walk applies)
         const bool dense_launch = lanes == 64 && dense && args.sp.species_parallel && args.sp.child_pairs && args.sp.columnless;  // (what solve_body<.., FIXED = 1> is compiled for)
         const bool lin_launch = small_linear && lanes == 64 && args.sp.species_parallel && args.sp.columnless && !args.sp.child_pairs && args.sp.fk_mode == BIOIK_FK_LINEAR;
         // k_solve_lean_cl4's helped build: launches that leave most of the chip idle (every unit gets four wavefronts instead of two), and the stragglers of a
@@ -900,14 +897,12 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         }
         if (sw.report)
             std::fprintf(stderr, "[bioik] launch: %s, %d lanes, %zu B of LDS, steps [%d, %d)\n",
-                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? (joint4 ? "k_solve_lean_clj4" : "k_solve_lean_clj") : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
+                         !lean ? "k_solve" : lin_launch ? "k_solve_lean_lin" : !args.sp.columnless ? "k_solve_lean" : joint ? "k_solve_lean_clj4" : dense_launch ? "k_solve_lean_cl64w4" : four_waves ? "k_solve_lean_cl4" : "k_solve_lean_cl",
                          lanes, lds_b, (int)args.step_begin, (int)(args.step_end < args.sp.max_steps ? args.step_end : args.sp.max_steps));
         if (lean && lin_launch)
             LAUNCH(k_solve_lean_lin, (solve_body<true, true, false, true, 3>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && joint && joint4)
             LAUNCH(k_solve_lean_clj4, (solve_body<true, true, true, true, 4>(args, b_, l_)), units, lanes, lds_b, stream, args);
-        else if (lean && args.sp.columnless && joint)
-            LAUNCH(k_solve_lean_clj, (solve_body<true, true, true>(args, b_, l_)), units, lanes, lds_b, stream, args);
         else if (lean && args.sp.columnless && dense_launch)
             // the whole solve of a stream of batches under the dense mapping: sixteen queries per CU instead of twelve (+11 % with six solves in flight;
             // 30 values -- the lane's best two across the chain walk, a few kernel-lifetime ones -- then live in scratch memory;
