@@ -8,7 +8,8 @@
 // (its per-query numbers) — because on the MI355X the costs of a whole population are evaluated inside the solver kernels, not by a
 // virtual call per individual.  `evaluate()` remains the definition of the cost (the parity tests hold the kernels against it) and is
 // what runs for goals on the host (bio_ik/goal_eval.h).  A goal without a device opcode (a user subclass, JointFunctionGoal,
-// LinkFunctionGoal) cannot steer the device search: the plugin refuses it with a message.
+// LinkFunctionGoal) cannot steer the device search: it takes part through the hybrid path of plugin_core.h -- the device searches over the goals it can
+// evaluate and returns several candidates per query, the host scores them with ALL goals and picks.
 #pragma once
 #include <sys/types.h>
 

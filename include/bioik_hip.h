@@ -1,7 +1,7 @@
 /*
  * bioik_hip.h — C-ABI boundary of the MI355X-native bio2_memetic IK solver.
  *
- * This header is the drop-in boundary described in DESIGN.md §2.  It replaces, for the hot path
+ * This header is the drop-in boundary described in DESIGN.md §1.  It replaces, for the hot path
  * only, the pair of calls
  *
  *     ik->initialize(problem);   ik->solve();           (reference src/kinematics_plugin.cpp:566-578)
@@ -54,8 +54,9 @@ enum {
     BIOIK_JOINT_FIXED = 0,
     BIOIK_JOINT_REVOLUTE = 1,  /* also URDF "continuous" (unbounded revolute) */
     BIOIK_JOINT_PRISMATIC = 2,
-    BIOIK_JOINT_FLOATING = 3,  /* 7 variables x y z qx qy qz qw; device: one such joint, attached to the model root through fixed joints only */
-    BIOIK_JOINT_PLANAR = 4     /* 3 variables x y theta;          device: as FLOATING (the virtual joint of a mobile base)             */
+    BIOIK_JOINT_FLOATING = 3,  /* 7 variables x y z qx qy qz qw; device: anywhere on the goal chains (general flavour of the solver kernel); refused: such
+                                  a joint as a mimic of another, its variables off the goal chains, more than four with an active orientation              */
+    BIOIK_JOINT_PLANAR = 4     /* 3 variables x y theta;          device: as FLOATING                                                     */
 };
 
 /* ---- goal opcodes: one per closed-form class of reference include/bio_ik/goal_types.h.
@@ -105,29 +106,28 @@ enum {
                                        before the next step (:165-170, :233-237); the best configuration seen is returned          */
 };
 
-/* What the launcher optimises a solve for.
- * LATENCY (default): the time of THIS call.  A query gets the lanes that make its steps short (128: 95 us per step of the 7-joint arm; one query 0.93 ms), and a
- *   batch beyond what the chip holds of such workgroups (3072 queries and more) starts under the denser mapping below -- every query resident from the first
- *   moment -- and hands its stragglers to the short-step mapping when the chip runs empty (8.6 ms for 4096 queries).  Three such solves in flight keep an
- *   MI355X busy.
+/* What the launcher optimises a solve for (the measured figures of the current round: DESIGN.md section 6).
+ * LATENCY (default): the time of THIS call.  A query gets the lanes that make its steps short (128 and two helper wavefronts: ~90 us per step of the 7-joint
+ *   arm), and a batch beyond what the chip holds of such workgroups (3072 queries and more) starts under the denser mapping below -- every query resident from
+ *   the first moment -- and hands its stragglers to the short-step mapping when the chip runs empty.  Three such solves in flight keep an MI355X busy.
  * THROUGHPUT: solves per second of a STREAM of batches.  Both species of a query share one wavefront and the children are computed where they
  *   are read, sixteen queries per CU: a third more steps per ms on a full chip, but a step takes 2.5 x as long, so the stragglers of a batch run for
  *   up to 12 ms.  It pays with six to ten batches in flight on as many streams -- and hardware queues: the HIP runtime maps streams onto four unless
- *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call a fifth more time (10.5 against 8.6 ms for 4096 queries).  Problems the denser mapping does not exist for (secondary
- *   goals with more than 256 children, 32 or more genes, linearised phenotypes, floating joints) run as under LATENCY.                      
+ *   GPU_MAX_HW_QUEUES says otherwise -- and costs an isolated call about a fifth more time.  Problems the denser mapping does not exist for (secondary
+ *   goals with more than 256 children, 32 or more genes, floating joints) run as under LATENCY.
  * AUTO: LATENCY, except in bioik_solve_batch_submit when two or more solves of the handle are already in flight: THROUGHPUT then (a caller
- *   that streams batches through the asynchronous entry gets the dense mapping once its pipeline is three deep: 8.4e5 against 8.0e5 solves/s
- *   with three in flight, 0.94e6 with six; an isolated call stays as fast as it can be). */
+ *   that streams batches through the asynchronous entry gets the dense mapping once its pipeline is three deep; an isolated call stays as fast as it
+ *   can be). */
 enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1, BIOIK_SCHEDULE_AUTO = 2 };
-/* bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): as many islands per query as the part of the chip the call leaves idle can carry,
- * min(16, 2048 / n) but at least four for a call of n <= 1024 queries (per device), one beyond that -- and, since round 6, 64 for calls of up to eight queries and 32 up to
- * sixteen (MoveIt's one pose per call: 64 against 16 islands is 0.80 -> 0.75 ms for a PoseGoal on a 7-joint arm, 3.9 -> 3.6 ms with a secondary MinimalDisplacementGoal) --,
- * stopping each other (island_sync is then taken as 1) -- the reference's
- * four island threads with "any thread succeeds => all stop" (ik_parallel.h:102, 141-178), sized to the hardware.  A call that cannot fill the
- * chip is bound by its slowest query's number of steps, and islands cut exactly that: MI355X, PoseGoal on a 7-joint arm, pop 128: 16 queries
- * 3.3 -> 1.25 ms per call, 256 queries 6.2 -> 3.3 ms, 896 queries 6.1 -> 5.1 ms, one query 0.93 -> 0.79 ms (profiles/r05_small_batches.log; with the helped kernel
- * of small launches); calls of more than 1024 queries run one island as before.  The answer of a query then depends on the size of the call it came in (the island count is a function of
- * n); give an explicit count where that matters.  The bio2 family only: for gd / jac an island count names another solver ("gd_8"). */
+/* bioik_solve_params::islands = BIOIK_ISLANDS_AUTO (0): as many islands per query as the part of the chip the call leaves idle can carry --
+ * for a call of n queries (per device) max(min(16, 2048 / n), min(64, 512 / n)), at least four up to n = 1024, one beyond that: 64 for up to eight queries
+ * (MoveIt's one pose per call), 32 for sixteen, 16 up to 128 ... -- stopping each other (island_sync is then taken as 1): the reference's four island
+ * threads with "any thread succeeds => all stop" (ik_parallel.h:102, 141-178), sized to the hardware.  A call that cannot fill the chip is bound by its
+ * slowest query's number of steps, and islands cut exactly that (MI355X, PoseGoal on a 7-joint arm, pop 128: 16 queries 3.5 -> 1.25 ms per call, 256 queries
+ * 6.2 -> 2.9 ms, one query 1.2 -> 0.76 ms: bench.py's small_batches).  bioik_resolve_islands() returns the count a call of n queries would get.
+ * THE ANSWER OF A QUERY THEN DEPENDS ON THE SIZE OF THE CALL IT CAME IN (the island count is a function of n, and the islands' streams of random numbers are
+ * part of the answer): give an explicit count where answers must not depend on batching.  The bio2 family only: for gd / jac an island count names another
+ * solver ("gd_8"). */
 enum { BIOIK_ISLANDS_AUTO = 0 };
 
 /* how a child's phenotype (tip frames) is obtained inside the evolution loop */
@@ -325,7 +325,7 @@ int bioik_solve_batch_multi(bioik_problem* const* problems, int n_problems, cons
  * kernel); nothing in it waits for the host, so it may be captured into a hipGraph and replayed any number of times, on new contents of the
  * captured arrays too: make one eager call of the same size on the stream first (it sizes the scratch).  The words a solve resets per
  * call (hand-over counters, the timeout's clock, the islands' first-success words) are written by a kernel of this library, NOT by
- * hipMemsetAsync: on ROCm 7.2 a graph with a memset node in front of these kernels faults on its second replay.
+ * hipMemsetAsync: on ROCm 7.2 a graph with a memset node in front of these kernels faults on its second replay (HISTORY.md).
  * Lifetime of the scratch under capture: a buffer a captured call has used is PINNED -- the graph holds its address -- and stays alive until
  * bioik_problem_destroy; the next eager call on that stream moves on to a buffer of its own, whatever its size.  Graphs captured from ONE
  * stream of one handle share that stream's pinned buffer: launch them on one stream (or capture from different streams).  Destroy the
