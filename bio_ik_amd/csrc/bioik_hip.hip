@@ -593,19 +593,58 @@ static void set_deadline(bioik_problem* p, const DevSolveParams& sp, stream_t st
     a.deadline = p->clock_dev0 + (unsigned long long)(since * 1e8) + sp.timeout_ticks;
 }
 
-static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
-                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream, const SolveSwitches& sw, unsigned int* error_word) {
-    if (n == 0) return;
-    DevSolveParams sp = sp_in;
-    const DevProblem& dp = p->host.dev;
-    const size_t kLds = p->model->dev.lds_cu;  // LDS of a CU (160 KiB on MI355X)
-    const uint64_t kCus = (uint64_t)p->model->dev.cus;
-    if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
-    const uint64_t units = (uint64_t)n * sp.islands;
-    if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
+// ------------------------------------------------------------------------------------------------------------
+// One solve = SolveLauncher: what the call was given, where its results go (scratch, result_arrays, select_islands), the lane mapping the rules below pick
+// for it (choose_mapping), the kernel that mapping is compiled as (launch), and the launches it is cut into (plan_handovers, run).  launch_solve at the end
+// puts them in order.
+// ------------------------------------------------------------------------------------------------------------
+struct SolveLauncher {
+    bioik_problem* p;
+    DevSolveParams sp;
+    const size_t n;
+    const double* d_seeds;
+    const double* d_params;
+    double* d_solutions;
+    double* d_fitness;
+    int32_t* d_success;
+    int32_t* d_steps;
+    stream_t stream;
+    const SolveSwitches& sw;
+    unsigned int* error_word;
+    const DevProblem& dp;
+    const size_t kLds;    // LDS of a CU (160 KiB on MI355X)
+    const uint64_t kCus;
+    uint64_t units = 0;
+    void* island_ws = nullptr;  // (a stream-ordered fallback allocation of the per-island results, if any)
+    bool fused_select = false;
+    // the mapping (choose_mapping)
+    int nth = 0, groups = 1;
+    size_t lds = 0;
+    bool exact = false, quat = false, manual = false, can_columnless = false, prefer_cl4 = false, small_sec_cl4 = false, small_linear = false, throughput = false, dense_ok = false,
+         capturing = false, latency_drain = false, dense = false, lean = false, halves_ok = false;
+    // the launches (plan_handovers)
+    std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
+    bool when_draining = false;  // ... or: whenever the chip runs empty (SolveArgs::resident), every unit from the step it is at
+
+    SolveLauncher(bioik_problem* p_, const DevSolveParams& sp_in, size_t n_, const double* seeds, const double* params, double* solutions, double* fitness, int32_t* success,
+                  int32_t* steps, stream_t s, const SolveSwitches& w, unsigned int* err)
+        : p(p_), sp(sp_in), n(n_), d_seeds(seeds), d_params(params), d_solutions(solutions), d_fitness(fitness), d_success(success), d_steps(steps), stream(s), sw(w),
+          error_word(err), dp(p_->host.dev), kLds(p_->model->dev.lds_cu), kCus((uint64_t)p_->model->dev.cus) {
+        if (dp.n_secondary > 0 && sp.lambda < 2) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "population must be >= 2 when secondary goals are present");
+        units = (uint64_t)n * sp.islands;
+        if (units > 0x7fffffffull) throw Error(BIOIK_ERR_INVALID_ARGUMENT, "too many (query, island) units for one launch: split the batch");
+    }
+    ~SolveLauncher() { be_free_async(island_ws, stream); }
+    SolveLauncher(const SolveLauncher&) = delete;
+    struct AsyncFree {
+        void*& p;
+        stream_t s;
+        ~AsyncFree() { be_free_async(p, s); }
+    };
+
     // scratch of this solve: the handle's persistent buffer for (stream, purpose), or -- while the stream is being captured and the buffer would have to
     // grow, or for the sixty-fifth stream of a handle -- a stream-ordered allocation released on every path out (null: nothing to release)
-    auto scratch = [&](int purpose, size_t bytes, void*& async_owned) -> void* {
+    void* scratch(int purpose, size_t bytes, void*& async_owned) {
         const auto key = std::make_pair(stream, purpose);
         auto it = p->scratch.find(key);
         if (it == p->scratch.end() && p->scratch.size() < 128) it = p->scratch.emplace(key, bioik_problem::Scratch{}).first;
@@ -632,17 +671,10 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         }
         async_owned = be_alloc_async(bytes, stream);
         return async_owned;
-    };
-    void* island_ws = nullptr;  // (a stream-ordered fallback allocation of the per-island results, if any)
-    struct AsyncFree {
-        void*& p;
-        stream_t s;
-        ~AsyncFree() { be_free_async(p, s); }
-    } island_ws_guard{island_ws, stream};
+    }
     // where the launch writes its results: the caller's arrays, or (islands > 1) per-island arrays that are then reduced to them -- by the query's last island
     // itself (`fused`: SolveArgs::island_done; one launch in all) or by k_select behind the solve's launches (select_islands)
-    bool fused_select = false;
-    auto result_arrays = [&](SolveArgs& args, bool fused) {
+    void result_arrays(SolveArgs& args, bool fused) {
         if (sp.islands == 1) {
             args.solutions = d_solutions, args.fitness = d_fitness, args.success = d_success, args.steps = d_steps;
             return;
@@ -680,8 +712,8 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             args.first_success = (unsigned int*)w;
             be_fill_ff_async(args.first_success, n * 4, stream);
         }
-    };
-    auto select_islands = [&](const SolveArgs& args) {  // ik_parallel.h:220-269: the best island of every query
+    }
+    void select_islands(const SolveArgs& args) {  // ik_parallel.h:220-269: the best island of every query
         if (sp.islands == 1 || fused_select) return;
         SelectArgs s;
         s.islands = sp.islands, s.V = dp.V, s.n = n;
@@ -689,8 +721,9 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         s.isl_solutions = args.solutions, s.isl_fitness = args.fitness, s.isl_success = args.success, s.isl_steps = args.steps;
         s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
         LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
-    };
-    if (sp.solver != 0) {  // gd / gd_r / gd_c / jac: one wavefront per (query, island), its own (small) LDS layout
+    }
+    // gd / gd_r / gd_c / jac: one wavefront per (query, island), its own (small) LDS layout
+    void solve_point() {
         const size_t lds_point = (size_t)make_point_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, dp.D, 64).total * 8;
         if (lds_point > 64 * 1024) throw Error(BIOIK_ERR_UNSUPPORTED, "problem too large for the gd / jac kernels (more than 64 KiB of LDS per query)");
         SolveArgs pa;
@@ -700,133 +733,137 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         set_deadline(p, sp, stream, pa);
         LAUNCH(k_solve_point, point_body(pa, b_, l_), units, 64, lds_point, stream, pa);
         select_islands(pa);
-        return;
     }
-    // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
-    // and evaluated in pairs / kept / re-derived from the RNG, or 64 lanes (one wavefront, the species one after the other).  A CU
-    // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
-    // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
-    // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
-    int nth = solve_threads(sp, units, sw, kCus);
-    const bool exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
-    if (sw.threads <= 0 && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
-    const bool quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
-    const bool manual = sw.manual();
-    // children computed where they are read (no genotype columns in LDS): the lean flavour can, whenever it is chosen below
-    const bool can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !sw.general_set;
-    sp.columnless = 0;
-    // k_solve_lean_cl4's mapping first -- 128 lanes, a wavefront per species, children computed where they are read and walked in pairs, the kernel compiled
-    // for exactly that under the budget of four wavefronts per SIMD (no register spills since round 4): for problems without a secondary goal whose
-    // lanes get at least one pair of children per generation and whose LDS footprint lets sixteen wavefronts share a CU it beats the kernel with the
-    // children kept in columns on every count (C2: lone step 94 -> 91 us, fixed work at 4096 queries +30 %, three solves in flight +26 %, an isolated
-    // call +16 %: profiles/r04_ab_latency_schedule_kernel.log)
-    const bool cl4_eligible = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
-                              sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
-    // (... also for the launches that cannot fill the chip, where solve_threads asks for a lane per child: one query 0.928 against 0.942 ms, 256 queries 5.49 against
-    // 5.74 ms, profiles/r04_small_batches.log)
-    if (cl4_eligible && nth == 256) nth = 128;
-    const bool prefer_cl4 = cl4_eligible && nth == 128;
-    // ... and, for launches small enough for its helped build (k_solve_lean_cl4h), the same mapping for serial chains WITH secondary goals (a 7-joint arm with a
-    // MinimalDisplacementGoal, the 31-joint chain with AvoidJointLimitsGoal: the usual MoveIt configurations of bio_ik): the kernel pre-selects, the helper takes
-    // half of the survivors' walks.  Chip-filling batches of such problems keep the mappings chosen below (the joint walk, the 128-register build by residency).
-    const bool small_sec_cl4 = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary > 0 && sp.lambda >= 128 &&
-                               sw.helped > 0 && units <= (uint64_t)sw.helped && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
-    if (small_sec_cl4) nth = 128;
-    if (prefer_cl4 || small_sec_cl4) {
-        sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
-    } else if (!manual && nth == 128) {
-        struct Cand {
-            int nth, store, pairs, columnless;
-        };
-        // richest first: children kept in LDS and scored in pairs / kept / computed where they are read / one reusable column per lane
-        const Cand cands[] = {{128, 1, 1, 0}, {128, 1, 0, 0}, {128, 0, 1, 1}, {128, 0, 0, 1}, {128, 0, 0, 0}, {64, 0, 1, 1}, {64, 0, 0, 1}, {64, 0, 0, 0}};
-        const int kCuWaves = 4 * BIOIK_SOLVE_WAVES_PER_SIMD;  // wavefronts a CU holds at this kernel's register budget
-        int best = -1, best_waves = -1;
-        for (int i = 0; i < 8; i++) {
-            const Cand& c = cands[i];
-            if ((c.store || c.pairs) && quat) continue;
-            if (c.columnless && !can_columnless) continue;
-            if (c.pairs && sp.fk_mode != BIOIK_FK_EXACT) continue;
-            const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
-            const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : (c.columnless ? 0 : 1);
-            if (c.pairs && !c.columnless && cols < 2) continue;
-            // (computed children in pairs: measured +1.5 % with eight children per lane and generation (C4), -4 % with two (C3))
-            if (c.pairs && c.columnless && sp.lambda < 4 * G_c) continue;
-            const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact, c.columnless && exact);
-            if (bytes > kLds) continue;
-            int waves = (int)(kLds / bytes) * (c.nth / 64);
-            if (waves > kCuWaves) waves = kCuWaves;
-            // full CU: first (richest) candidate wins; LDS-limited: a later (leaner) candidate wins ties
-            if (waves > best_waves || (waves == best_waves && waves < kCuWaves)) best = i, best_waves = waves;
+    void choose_mapping() {
+        // Mapping of a (query, island) onto lanes.  Candidates: 128 lanes (one wavefront per species) with every child kept in LDS
+        // and evaluated in pairs / kept / re-derived from the RNG, or 64 lanes (one wavefront, the species one after the other).  A CU
+        // holds 160 KiB of LDS and, at this kernel's register budget, 12 wavefronts: the candidate that puts most wavefronts on a CU
+        // wins; among equals the richer mapping wins when the CU is full (C2: 20 KiB per workgroup) and the leaner one when LDS is
+        // what limits residency (C3, C4: measured +7 % and +26 % for 64 lanes, tools/mapping_sweep.py).
+        nth = solve_threads(sp, units, sw, kCus);
+        exact = sp.fk_mode == BIOIK_FK_EXACT;  // (the LDS layout of exact-FK solves is smaller, make_layout)
+        if (sw.threads <= 0 && nth == 256 && lds_bytes(p, 256, sp.lambda, 1, 2, 1, exact) > 48 * 1024) nth = 128;  // LDS-heavy problem
+        quat = dp.n_quat > 0;  // winners re-derived: their momentum is taken before the quaternion genes are renormalised
+        manual = sw.manual();
+        // children computed where they are read (no genotype columns in LDS): the lean flavour can, whenever it is chosen below
+        can_columnless = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && !sw.general_set;
+        sp.columnless = 0;
+        // k_solve_lean_cl4's mapping first -- 128 lanes, a wavefront per species, children computed where they are read and walked in pairs, the kernel compiled
+        // for exactly that under the budget of four wavefronts per SIMD (no register spills since round 4): for problems without a secondary goal whose
+        // lanes get at least one pair of children per generation and whose LDS footprint lets sixteen wavefronts share a CU it beats the kernel with the
+        // children kept in columns on every count (C2: lone step 94 -> 91 us, fixed work at 4096 queries +30 %, three solves in flight +26 %, an isolated
+        // call +16 %: profiles/r04_ab_latency_schedule_kernel.log)
+        const bool cl4_eligible = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary == 0 &&
+                                  sp.lambda >= 128 && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
+        // (... also for the launches that cannot fill the chip, where solve_threads asks for a lane per child: one query 0.928 against 0.942 ms, 256 queries 5.49 against
+        // 5.74 ms, profiles/r04_small_batches.log)
+        if (cl4_eligible && nth == 256) nth = 128;
+        prefer_cl4 = cl4_eligible && nth == 128;
+        // ... and, for launches small enough for its helped build (k_solve_lean_cl4h), the same mapping for serial chains WITH secondary goals (a 7-joint arm with a
+        // MinimalDisplacementGoal, the 31-joint chain with AvoidJointLimitsGoal: the usual MoveIt configurations of bio_ik): the kernel pre-selects, the helper takes
+        // half of the survivors' walks.  Chip-filling batches of such problems keep the mappings chosen below (the joint walk, the 128-register build by residency).
+        small_sec_cl4 = !manual && !sw.three_waves && can_columnless && exact && dp.serial_chain != 0 && !(dp.n_quat > 0) && dp.n_secondary > 0 && sp.lambda >= 128 &&
+                                   sw.helped > 0 && units <= (uint64_t)sw.helped && lds_bytes(p, 128, sp.lambda, 0, 2, 2, exact, exact) * 8 <= kLds;
+        if (small_sec_cl4) nth = 128;
+        if (prefer_cl4 || small_sec_cl4) {
+            sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1, sp.columnless = 1;
+        } else if (!manual && nth == 128) {
+            struct Cand {
+                int nth, store, pairs, columnless;
+            };
+            // richest first: children kept in LDS and scored in pairs / kept / computed where they are read / one reusable column per lane
+            const Cand cands[] = {{128, 1, 1, 0}, {128, 1, 0, 0}, {128, 0, 1, 1}, {128, 0, 0, 1}, {128, 0, 0, 0}, {64, 0, 1, 1}, {64, 0, 0, 1}, {64, 0, 0, 0}};
+            const int kCuWaves = 4 * BIOIK_SOLVE_WAVES_PER_SIMD;  // wavefronts a CU holds at this kernel's register budget
+            int best = -1, best_waves = -1;
+            for (int i = 0; i < 8; i++) {
+                const Cand& c = cands[i];
+                if ((c.store || c.pairs) && quat) continue;
+                if (c.columnless && !can_columnless) continue;
+                if (c.pairs && sp.fk_mode != BIOIK_FK_EXACT) continue;
+                const int groups_c = c.nth % 128 == 0 ? 2 : 1, G_c = c.nth / groups_c;
+                const int cols = c.store ? (sp.lambda + G_c - 1) / G_c : (c.columnless ? 0 : 1);
+                if (c.pairs && !c.columnless && cols < 2) continue;
+                // (computed children in pairs: measured +1.5 % with eight children per lane and generation (C4), -4 % with two (C3))
+                if (c.pairs && c.columnless && sp.lambda < 4 * G_c) continue;
+                const size_t bytes = lds_bytes(p, c.nth, sp.lambda, cols, groups_c, c.pairs ? 2 : 1, exact, c.columnless && exact);
+                if (bytes > kLds) continue;
+                int waves = (int)(kLds / bytes) * (c.nth / 64);
+                if (waves > kCuWaves) waves = kCuWaves;
+                // full CU: first (richest) candidate wins; LDS-limited: a later (leaner) candidate wins ties
+                if (waves > best_waves || (waves == best_waves && waves < kCuWaves)) best = i, best_waves = waves;
+            }
+            if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
+            nth = cands[best].nth;
+            sp.species_parallel = nth % 128 == 0 ? 1 : 0;
+            const int G_b = nth / (sp.species_parallel ? 2 : 1);
+            sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
+            sp.child_pairs = cands[best].pairs;
+            sp.columnless = cands[best].columnless;
+            // Problems with secondary goals score only a random prefix of the pre-selected children, so the phases besides the chain walk (the
+            // pre-selection itself, selection, the memetic phase) weigh more; with both species of a query on the halves of ONE wavefront those
+            // run once for the two.  Measured: C3 (128 children per species) +14 %, C4 (512: sixteen children per lane) -22 % (tools/c34_mapping_probe.sh).
+            if (sp.columnless && dp.n_secondary > 0 && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
+                lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact) * kCuWaves <= kLds) {
+                nth = 64, sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1;
+            }
+        } else {
+            while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2, 1, exact) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
+            // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
+            // (small populations, <= 32 children per species: +65..80 % measured, tools/halfwave_sweep.sh; at 64 and more children
+            // per species the sequential single wavefront or the two-wavefront mapping is as good or better)
+            sp.species_parallel = (nth % 128 == 0 || (nth == 64 && sp.lambda <= 32 && dp.D < 32)) ? 1 : 0;  // (the memetic phase wants lane D of a group)
+            if (sw.species_parallel >= 0) sp.species_parallel = (sw.species_parallel != 0 && (nth % 128 == 0 || (nth == 64 && dp.D < 32))) ? 1 : 0;
+            const int groups_m = sp.species_parallel ? 2 : 1, G_m = nth / groups_m;
+            sp.child_cols = (sp.lambda + G_m - 1) / G_m;
+            if (quat) {
+                sp.child_cols = 1;
+            } else if (sw.store_children >= 0) {
+                if (sw.store_children == 0) sp.child_cols = 1;
+            } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 1, exact) > 48 * 1024) {
+                sp.child_cols = 1;
+            }
+            // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
+            // trees, a second set of parked frames
+            sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2, exact) <= 64 * 1024) ? 1 : 0;
+            if (sw.child_pairs == 0) sp.child_pairs = 0;
         }
-        if (best < 0) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
-        nth = cands[best].nth;
-        sp.species_parallel = nth % 128 == 0 ? 1 : 0;
-        const int G_b = nth / (sp.species_parallel ? 2 : 1);
-        sp.child_cols = cands[best].store ? (sp.lambda + G_b - 1) / G_b : 1;
-        sp.child_pairs = cands[best].pairs;
-        sp.columnless = cands[best].columnless;
-        // Problems with secondary goals score only a random prefix of the pre-selected children, so the phases besides the chain walk (the
-        // pre-selection itself, selection, the memetic phase) weigh more; with both species of a query on the halves of ONE wavefront those
-        // run once for the two.  Measured: C3 (128 children per species) +14 %, C4 (512: sixteen children per lane) -22 % (tools/c34_mapping_probe.sh).
-        if (sp.columnless && dp.n_secondary > 0 && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
-            lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact) * kCuWaves <= kLds) {
-            nth = 64, sp.species_parallel = 1, sp.child_cols = 1, sp.child_pairs = 1;
+        // small populations, linearised phenotypes (the reference's own parameters), both species on the halves of one wavefront: children computed where
+        // they are read, and the kernel compiled for exactly that (k_solve_lean_lin: sixteen queries per CU)
+        small_linear = !manual && !sw.three_waves && can_columnless && !exact && nth == 64 && sp.species_parallel && sp.lambda <= 32 && sp.solver == 0;
+        if (small_linear) sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 0;
+        // BIOIK_SCHEDULE_THROUGHPUT: the whole solve under the mapping that retires most steps per ms on a full chip -- both species of a query on the
+        // halves of one wavefront, children computed where they are read and scored in pairs (the first launch's mapping of the two-launch solve
+        // below) -- for callers that keep six or more batches in flight (include/bioik_hip.h; profiles/r03_inflight_and_schedule.log)
+        throughput = sp.schedule == BIOIK_SCHEDULE_THROUGHPUT && !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
+                                dp.n_secondary == 0;
+        // (nth / sp keep the LATENCY mapping: a throughput solve may hand its stragglers over to it, sw.dense_handover; its own launch takes the
+        // dense mapping where it is made, `halves` below)
+        // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
+        // BIOIK_SCHEDULE_LATENCY, a batch beyond what the chip holds of k_solve_lean_cl4's workgroups (2048; 2048 queries: 7.27 ms alone, 7.51 ms this way) under its mapping: the dense kernel first -- every query of up to 4096
+        // resident from the start, most steps retired per ms while the chip is full -- and, when the chip runs empty, the stragglers on to k_solve_lean_cl4 whose lone
+        // step is a third shorter (SolveArgs::resident).  An isolated 4096-query call: 9.2 -> 8.5 ms (profiles/r04_drain_handover.log).  Streams of solves keep the
+        // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
+        dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
+                              dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
+        // (BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: round 4's rule -- a call on a stream that is being captured gets a one-launch mapping.  The replay defect it worked around
+        // was the runtime's memset NODE in front of the kernels, not the hand-over; the library fills its words with a kernel of its own now
+        // and captured calls take the same mapping as eager ones)
+        capturing = sw.capture_one_launch && be_stream_capturing(stream);
+        latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= (uint64_t)(sp.islands <= 2 ? sw.drain_min_units : 3072) * kCus / 256 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
+                                   !sw.two_phase_set && !capturing;
+        dense = (throughput || latency_drain) && dense_ok;
+        if (sw.columnless > 0 && can_columnless) {
+            sp.columnless = 1, sp.child_cols = 1;
+            sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
         }
-    } else {
-        while (nth > 64 && lds_bytes(p, nth, sp.lambda, 1, 2, 1, exact) > 64 * 1024) nth -= 64;  // genotype columns scale with the lane count
-        // two lane groups, one species each: whole wavefronts (128 / 256 lanes), or the two halves of one wavefront (64 lanes)
-        // (small populations, <= 32 children per species: +65..80 % measured, tools/halfwave_sweep.sh; at 64 and more children
-        // per species the sequential single wavefront or the two-wavefront mapping is as good or better)
-        sp.species_parallel = (nth % 128 == 0 || (nth == 64 && sp.lambda <= 32 && dp.D < 32)) ? 1 : 0;  // (the memetic phase wants lane D of a group)
-        if (sw.species_parallel >= 0) sp.species_parallel = (sw.species_parallel != 0 && (nth % 128 == 0 || (nth == 64 && dp.D < 32))) ? 1 : 0;
-        const int groups_m = sp.species_parallel ? 2 : 1, G_m = nth / groups_m;
-        sp.child_cols = (sp.lambda + G_m - 1) / G_m;
-        if (quat) {
-            sp.child_cols = 1;
-        } else if (sw.store_children >= 0) {
-            if (sw.store_children == 0) sp.child_cols = 1;
-        } else if (lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 1, exact) > 48 * 1024) {
-            sp.child_cols = 1;
-        }
-        // children two at a time per lane (two independent dependency chains): needs both columns of the pair and, for branching
-        // trees, a second set of parked frames
-        sp.child_pairs = (sp.child_cols >= 2 && sp.fk_mode == BIOIK_FK_EXACT && lds_bytes(p, nth, sp.lambda, sp.child_cols, groups_m, 2, exact) <= 64 * 1024) ? 1 : 0;
-        if (sw.child_pairs == 0) sp.child_pairs = 0;
+        groups = sp.species_parallel ? 2 : 1;
+        lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
+        if (lds > kLds) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
+        lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
+        if (sw.general_set && sw.general) lean = false;
+        halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
     }
-    // small populations, linearised phenotypes (the reference's own parameters), both species on the halves of one wavefront: children computed where
-    // they are read, and the kernel compiled for exactly that (k_solve_lean_lin: sixteen queries per CU)
-    const bool small_linear = !manual && !sw.three_waves && can_columnless && !exact && nth == 64 && sp.species_parallel && sp.lambda <= 32 && sp.solver == 0;
-    if (small_linear) sp.columnless = 1, sp.child_cols = 1, sp.child_pairs = 0;
-    // BIOIK_SCHEDULE_THROUGHPUT: the whole solve under the mapping that retires most steps per ms on a full chip -- both species of a query on the
-    // halves of one wavefront, children computed where they are read and scored in pairs (the first launch's mapping of the two-launch solve
-    // below) -- for callers that keep six or more batches in flight (include/bioik_hip.h; profiles/r03_inflight_and_schedule.log)
-    const bool throughput = sp.schedule == BIOIK_SCHEDULE_THROUGHPUT && !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 &&
-                            dp.n_secondary == 0;
-    // (nth / sp keep the LATENCY mapping: a throughput solve may hand its stragglers over to it, sw.dense_handover; its own launch takes the
-    // dense mapping where it is made, `halves` below)
-    // k_solve_lean_cl64w4 (solve_body<.., DENSE>): the 128-register build of that mapping, four wavefronts per SIMD
-    // BIOIK_SCHEDULE_LATENCY, a batch beyond what the chip holds of k_solve_lean_cl4's workgroups (2048; 2048 queries: 7.27 ms alone, 7.51 ms this way) under its mapping: the dense kernel first -- every query of up to 4096
-    // resident from the start, most steps retired per ms while the chip is full -- and, when the chip runs empty, the stragglers on to k_solve_lean_cl4 whose lone
-    // step is a third shorter (SolveArgs::resident).  An isolated 4096-query call: 9.2 -> 8.5 ms (profiles/r04_drain_handover.log).  Streams of solves keep the
-    // chip full, never see the hand-over and pay for its bookkeeping: the throughput schedule does without (BIOIK_SOLVE_DRAIN_THROUGHPUT=1: with).
-    const bool dense_ok = !manual && can_columnless && exact && sp.lambda >= 128 && sp.lambda <= 256 && dp.D < 32 && dp.n_secondary == 0 && !sw.three_waves && dp.multi_op < 0 &&
-                          dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0 && dp.serial_chain != 0;
-    // (BIOIK_SOLVE_CAPTURE_ONE_LAUNCH=1: round 4's rule -- a call on a stream that is being captured gets a one-launch mapping.  The replay defect it worked around
-    // was the runtime's memset NODE in front of the kernels, not the hand-over; the library fills its words with a kernel of its own now
-    // and captured calls take the same mapping as eager ones)
-    const bool capturing = sw.capture_one_launch && be_stream_capturing(stream);
-    const bool latency_drain = sp.schedule != BIOIK_SCHEDULE_THROUGHPUT && prefer_cl4 && dense_ok && units >= (uint64_t)(sp.islands <= 2 ? sw.drain_min_units : 3072) * kCus / 256 && sw.drain_below > 0 && sp.max_steps > sw.drain_min_steps + 1 &&
-                               !sw.two_phase_set && !capturing;
-    const bool dense = (throughput || latency_drain) && dense_ok;
-    if (sw.columnless > 0 && can_columnless) {
-        sp.columnless = 1, sp.child_cols = 1;
-        sp.child_pairs = (sw.columnless == 2 && sp.fk_mode == BIOIK_FK_EXACT) ? 1 : 0;  // 2: children scored two at a time
-    }
-    const int groups = sp.species_parallel ? 2 : 1;
-    const size_t lds = lds_bytes(p, nth, sp.lambda, sp.columnless ? 0 : sp.child_cols, groups, sp.child_pairs ? 2 : 1, exact, sp.columnless && exact);
-    if (lds > kLds) throw Error(BIOIK_ERR_UNSUPPORTED, "problem needs more LDS per workgroup than a CU has");
-    if (sw.report) {  // diagnostics: the lane mapping and the residency it gives
+    void report_mapping() const {  // diagnostics: the lane mapping and the residency it gives
         const LdsLayout L = make_layout(dp.n_ops, dp.V, dp.P, dp.T, dp.n_slots, nth, sp.lambda, dp.n_secondary > 0 ? (exact ? 2 : 1) : 0, sp.columnless ? 0 : sp.child_cols,
                                         groups, sp.child_pairs ? 2 : 1, (sp.columnless && exact) ? 1 : 0, 1);
         int n_rev = 0, n_pos = 0, n_rot = 0;  // revolute ops and how many of them the walk takes through a sparse form
@@ -845,26 +882,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
                      dp.n_ops, dp.D, dp.T, dp.n_slots, nth, sp.species_parallel, sp.child_cols, sp.child_pairs, sp.columnless, lds, (L.slots - L.xcol) * 8,
                      (L.g_first - L.slots) * 8, L.g_stride * 8, groups, (int)(kLds / lds), (int)(kLds / lds) * (nth / 64));
     }
-    if (lds > 64 * 1024) be_allow_lds(lds);
-    bool lean = dp.multi_op < 0 && dp.n_quat == 0 && dp.genes_follow_ops != 0 && dp.n_balance == 0;
-    if (sw.general_set && sw.general) lean = false;
-    SolveArgs a;
-    a.pb = p->pb();
-    a.sp = sp;
-    a.seeds = d_seeds;
-    a.params = d_params;
-    a.phase_cycles = nullptr;
-    a.sort_key_drop = sw.sort_key_drop;
-    a.preselect = sw.preselect | (sw.tie_test_bits << 8);
-    a.error = error_word;
-    a.debug_flags = sw.debug_flags;
-    set_deadline(p, sp, stream, a);
-#if defined(BIOIK_PHASE_TIMING)
-    DevBuf phase_buf(units * PHASE_SLOTS * sizeof(unsigned long long));
-    const char* phase_path = sw.phase_dump.empty() ? nullptr : sw.phase_dump.c_str();
-    if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
-#endif
-    auto launch = [&](const SolveArgs& args, int lanes, size_t lds_b) {
+    void launch(const SolveArgs& args, int lanes, size_t lds_b) {
         // computed children: the 128-register build when a CU's LDS holds at least the 16 wavefronts it makes room for and a lane walks
         // at least eight children per generation (the generation loops, which fit the smaller budget, are then most of a step)
         const int group_lanes = lanes / (args.sp.species_parallel ? 2 : 1);
@@ -916,7 +934,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
             LAUNCH(k_solve_lean, solve_body<true>(args, b_, l_), units, lanes, lds_b, stream, args);
         else
             LAUNCH(k_solve, solve_body<false>(args, b_, l_), units, lanes, lds_b, stream, args);
-    };
+    }
     // One launch, or two (SolveArgs::step_begin ...).  Measured on streams of distinct 4096-query PoseGoal batches (profiles/r02_two_launch_sweep.log):
     // split after the first step(), the state of the unsolved queries handed over through HBM, the first launch with both species of a query on
     // the halves of ONE wavefront and the children computed where they are read, a stream of batches runs 2.6 % faster and an isolated call 3.5 %
@@ -925,94 +943,124 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     // coincide (the same batch solved again on another stream) do not lose the 8 % such a coincidence costs.
     // BIOIK_SOLVE_TWO_PHASE=K (or K1,K2,... / init) forces hand-overs after those steps for any problem (0: never) -- the parity suites run every
     // mapping through it.
-    std::vector<int> handovers;  // the steps after which the unsolved units pass to the next launch (ascending)
-    bool when_draining = false;  // ... or: whenever the chip runs empty (SolveArgs::resident), every unit from the step it is at
-    const bool halves_ok = lean && can_columnless && exact && sp.lambda >= 128 && dp.D < 32;  // the first launch's mapping exists for this problem
-    if (sw.drain_test > 0 && sp.max_steps > 1 && sp.solver == 0) {
-        when_draining = true;
-        handovers.push_back(sp.max_steps);
-    } else if (sw.two_phase_set) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
-        if (sw.two_phase_init) handovers.push_back(0);  // (experiment: the first launch only initialises)
-        for (const long k : sw.two_phase)
-            if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
-    } else if (throughput) {
-        // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
-        if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
-        else if (dense && prefer_cl4 && units >= 8 * kCus && sw.drain_throughput && sw.drain_below > 0 && sw.drain_below_throughput > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing)
+    void plan_handovers() {
+        if (sw.drain_test > 0 && sp.max_steps > 1 && sp.solver == 0) {
+            when_draining = true;
+            handovers.push_back(sp.max_steps);
+        } else if (sw.two_phase_set) {  // "K" or "K1,K2,..." (experiments: more than one hand-over)
+            if (sw.two_phase_init) handovers.push_back(0);  // (experiment: the first launch only initialises)
+            for (const long k : sw.two_phase)
+                if (k > (handovers.empty() ? 0 : handovers.back()) && k < sp.max_steps) handovers.push_back((int)k);
+        } else if (throughput) {
+            // the dense mapping retires most steps per ms but its steps are 2.5 x as long: the stragglers of a batch may pass to the latency mapping
+            if (sw.dense_handover > 0 && sw.dense_handover < sp.max_steps) handovers.push_back(sw.dense_handover);
+            else if (dense && prefer_cl4 && units >= 8 * kCus && sw.drain_throughput && sw.drain_below > 0 && sw.drain_below_throughput > 0 && sp.max_steps > sw.drain_min_steps + 1 && !capturing)
+                when_draining = true, handovers.push_back(sp.max_steps);
+        } else if (latency_drain) {
             when_draining = true, handovers.push_back(sp.max_steps);
-    } else if (latency_drain) {
-        when_draining = true, handovers.push_back(sp.max_steps);
-    } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 8 * kCus && sp.max_steps >= 24 && !capturing) {
-        // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
-        // profiles/r04_ab_latency_schedule_kernel.log)
-        handovers.push_back(1);
+        } else if (halves_ok && !manual && !prefer_cl4 && sp.lambda <= 256 && dp.n_secondary == 0 && units >= 8 * kCus && sp.max_steps >= 24 && !capturing) {
+            // (not under k_solve_lean_cl4's mapping: there one launch is faster -- three in flight 9.9e5 against 9.3e5, an isolated call 8.9 against 9.3 ms,
+            // profiles/r04_ab_latency_schedule_kernel.log)
+            handovers.push_back(1);
+        }
     }
-#if defined(BIOIK_PHASE_TIMING)
-    if (phase_path) handovers.clear();
-#endif
-    // (a solve in ONE launch reduces its islands itself, SolveArgs::island_done; BIOIK_SOLVE_FUSED_SELECT=0: by k_select as before)
-    result_arrays(a, handovers.empty() && sw.fused_select != 0);
     // the mapping with both species of a query on the halves of ONE wavefront, children computed where they are read and walked in pairs: the
     // first launch of a solve in several launches, and the whole of a throughput solve
-    auto halves = [&](SolveArgs& aj, int& lanes, size_t& lds_j) {
+    void halves(SolveArgs& aj, int& lanes, size_t& lds_j) {
         lanes = 64;
         aj.sp.species_parallel = 1, aj.sp.columnless = 1, aj.sp.child_cols = 1, aj.sp.child_pairs = 1;
         lds_j = lds_bytes(p, 64, sp.lambda, 0, 2, 2, exact, exact);
         if (lds_j > 64 * 1024) be_allow_lds(lds_j);
-    };
-    if (handovers.empty() && throughput) {
-        SolveArgs a0 = a;
-        int lanes = nth;
-        size_t lds_0 = lds;
-        halves(a0, lanes, lds_0);
-        launch(a0, lanes, lds_0);
-    } else if (handovers.empty()) {
-        launch(a, nth, lds);
-    } else {
-        const size_t nh = handovers.size();
-        const size_t carry_n = 9 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;  // (solve_body: carry_n)
-        const size_t list_bytes = (units * 4 + 63) / 64 * 64;
-        const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + nh * list_bytes;
-        void* ws_async = nullptr;
-        AsyncFree ws_guard{ws_async, stream};
-        void* ws = scratch(1, count_off + nh * 64, ws_async);
-        be_zero_async((char*)ws + count_off, nh * 64, stream);
-        if (!sw.handover_dump.empty())
-            if (FILE* f = std::fopen(sw.handover_dump.c_str(), "a")) {
-                std::fprintf(f, "%llu %zu %zu %llu %zu\n", (unsigned long long)(size_t)ws, list_off, count_off, (unsigned long long)units, carry_n);
-                std::fclose(f);
-            }
-        for (size_t j = 0; j <= nh; j++) {  // launch j runs the steps [handovers[j-1], handovers[j])
-            SolveArgs aj = a;
+    }
+    // the launch(es) of a solve whose arguments `a` are complete
+    void run(const SolveArgs& a) {
+        if (handovers.empty() && throughput) {
+            SolveArgs a0 = a;
             int lanes = nth;
-            size_t lds_j = lds;
-            if (j == 0 && halves_ok && !manual) halves(aj, lanes, lds_j);
-            aj.carry = (double*)ws;
-            if (when_draining) {  // (the last launch counts its wavefronts too; it has no list to leave for)
-                aj.resident = p->d_resident;
-                {  // (per XCD -- eight on MI355X --, the threshold itself scaled to the chip's CUs: BIOIK_SOLVE_DRAIN_BELOW names it for 256 of them)
-                    const int xcds = p->model->dev.xcds > 0 ? p->model->dev.xcds : 1;
-                    const long long below = (long long)(throughput ? sw.drain_below_throughput : sw.drain_below) * (long long)kCus / 256;
-                    aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (int32_t)((below + xcds - 1) / xcds);
+            size_t lds_0 = lds;
+            halves(a0, lanes, lds_0);
+            launch(a0, lanes, lds_0);
+        } else if (handovers.empty()) {
+            launch(a, nth, lds);
+        } else {
+            const size_t nh = handovers.size();
+            const size_t carry_n = 9 * (size_t)(dp.n_ops > 0 ? dp.n_ops : 1) + 24;  // (solve_body: carry_n)
+            const size_t list_bytes = (units * 4 + 63) / 64 * 64;
+            const size_t list_off = (units * carry_n * 8 + 63) / 64 * 64, count_off = list_off + nh * list_bytes;
+            void* ws_async = nullptr;
+            AsyncFree ws_guard{ws_async, stream};
+            void* ws = scratch(1, count_off + nh * 64, ws_async);
+            be_zero_async((char*)ws + count_off, nh * 64, stream);
+            if (!sw.handover_dump.empty())
+                if (FILE* f = std::fopen(sw.handover_dump.c_str(), "a")) {
+                    std::fprintf(f, "%llu %zu %zu %llu %zu\n", (unsigned long long)(size_t)ws, list_off, count_off, (unsigned long long)units, carry_n);
+                    std::fclose(f);
                 }
-                aj.drain_min_steps = sw.drain_min_steps;
+            for (size_t j = 0; j <= nh; j++) {  // launch j runs the steps [handovers[j-1], handovers[j])
+                SolveArgs aj = a;
+                int lanes = nth;
+                size_t lds_j = lds;
+                if (j == 0 && halves_ok && !manual) halves(aj, lanes, lds_j);
+                aj.carry = (double*)ws;
+                if (when_draining) {  // (the last launch counts its wavefronts too; it has no list to leave for)
+                    aj.resident = p->d_resident;
+                    {  // (per XCD -- eight on MI355X --, the threshold itself scaled to the chip's CUs: BIOIK_SOLVE_DRAIN_BELOW names it for 256 of them)
+                        const int xcds = p->model->dev.xcds > 0 ? p->model->dev.xcds : 1;
+                        const long long below = (long long)(throughput ? sw.drain_below_throughput : sw.drain_below) * (long long)kCus / 256;
+                        aj.drain_below = sw.drain_test > 0 ? -sw.drain_test : (int32_t)((below + xcds - 1) / xcds);
+                    }
+                    aj.drain_min_steps = sw.drain_min_steps;
+                }
+                if (j > 0) {
+                    aj.step_begin = when_draining ? -1 : handovers[j - 1];
+                    aj.unit_list = (const int32_t*)((char*)ws + list_off + (j - 1) * list_bytes);
+                    aj.unit_count = (const unsigned int*)((char*)ws + count_off + (j - 1) * 64);
+                }
+                if (j < nh) {
+                    aj.step_end = handovers[j];
+                    aj.carry_list = (int32_t*)((char*)ws + list_off + j * list_bytes);
+                    aj.carry_count = (unsigned int*)((char*)ws + count_off + j * 64);
+                }
+                launch(aj, lanes, lds_j);  // (always a grid of `units` workgroups: those beyond the list's length leave at once)
             }
-            if (j > 0) {
-                aj.step_begin = when_draining ? -1 : handovers[j - 1];
-                aj.unit_list = (const int32_t*)((char*)ws + list_off + (j - 1) * list_bytes);
-                aj.unit_count = (const unsigned int*)((char*)ws + count_off + (j - 1) * 64);
-            }
-            if (j < nh) {
-                aj.step_end = handovers[j];
-                aj.carry_list = (int32_t*)((char*)ws + list_off + j * list_bytes);
-                aj.carry_count = (unsigned int*)((char*)ws + count_off + j * 64);
-            }
-            launch(aj, lanes, lds_j);  // (always a grid of `units` workgroups: those beyond the list's length leave at once)
         }
     }
+};
+
+static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n, const double* d_seeds, const double* d_params, double* d_solutions,
+                         double* d_fitness, int32_t* d_success, int32_t* d_steps, stream_t stream, const SolveSwitches& sw, unsigned int* error_word) {
+    if (n == 0) return;
+    SolveLauncher s(p, sp_in, n, d_seeds, d_params, d_solutions, d_fitness, d_success, d_steps, stream, sw, error_word);
+    if (s.sp.solver != 0) return s.solve_point();
+    s.choose_mapping();
+    if (sw.report) s.report_mapping();
+    if (s.lds > 64 * 1024) be_allow_lds(s.lds);
+    SolveArgs a;
+    a.pb = p->pb();
+    a.sp = s.sp;
+    a.seeds = d_seeds;
+    a.params = d_params;
+    a.phase_cycles = nullptr;
+    a.sort_key_drop = sw.sort_key_drop;
+    a.preselect = sw.preselect | (sw.tie_test_bits << 8);
+    a.error = error_word;
+    a.debug_flags = sw.debug_flags;
+    set_deadline(p, s.sp, stream, a);
+#if defined(BIOIK_PHASE_TIMING)
+    DevBuf phase_buf(s.units * PHASE_SLOTS * sizeof(unsigned long long));
+    const char* phase_path = sw.phase_dump.empty() ? nullptr : sw.phase_dump.c_str();
+    if (phase_path) a.phase_cycles = phase_buf.as<unsigned long long>();
+#endif
+    s.plan_handovers();
+#if defined(BIOIK_PHASE_TIMING)
+    if (phase_path) s.handovers.clear();
+#endif
+    // (a solve in ONE launch reduces its islands itself, SolveArgs::island_done; BIOIK_SOLVE_FUSED_SELECT=0: by k_select as before)
+    s.result_arrays(a, s.handovers.empty() && sw.fused_select != 0);
+    s.run(a);
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters
-        std::vector<unsigned long long> h(units * PHASE_SLOTS);
+        std::vector<unsigned long long> h(s.units * PHASE_SLOTS);
         be_d2h(h.data(), phase_buf.p, h.size() * sizeof(unsigned long long), stream);
         be_sync(stream);
         if (FILE* f = std::fopen(phase_path, "wb")) {
@@ -1021,7 +1069,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
         }
     }
 #endif
-    select_islands(a);
+    s.select_islands(a);
 }
 
 // ------------------------------------------------------------------------------------------------------------

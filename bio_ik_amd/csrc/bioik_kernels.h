@@ -709,6 +709,7 @@ struct SolveFrame {
     auto species_load = [&](int r_) { return (F).species_load(r_); };                                                                                                 \
     auto species_store = [&](int r_, const SpeciesState& S_) { (F).species_store(r_, S_); };                                                                          \
     auto my_resident = [&]() { return (F).my_resident(); };                                                                                                           \
+    (void)wg_barrier, (void)species_load, (void)species_store, (void)my_resident; /* (not every phase uses every one) */                                              \
     BIOIK_FRAME_PHASE_NAMES(F)
 // the launch's constants, the lane mapping and the unit's LDS block; seed and goal parameters staged (the workgroup's first barrier).  false: nothing to do for this
 // workgroup (a launch that continues handed-over units has a grid as large as the list can get)
