@@ -373,8 +373,17 @@ struct bioik_problem {
         int preset = -1;
         double ms[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     };
-    std::map<std::tuple<int, int, int>, Tuned> tuned;
-    std::vector<void*> retired_scratch;  // pinned buffers that eager solves have moved away from: captured graphs may still replay into them
+    std::map<std::tuple<int, int, int, int>, Tuned> tuned;  // (..., floor(log2(units)): a choice holds for calls of about the size it was measured on)
+    // pinned buffers that eager solves have moved away from: captured graphs may still replay into them -- and LATER captures on the same stream take them again
+    // (graphs captured from one stream share that stream's pinned buffer anyway), so that a caller who alternates eager calls and captures holds two buffers
+    // per stream, not one more per alternation
+    struct Retired {
+        void* base;
+        size_t capacity;
+        stream_t stream;
+        int purpose;
+    };
+    std::vector<Retired> retired_scratch;
     std::mutex mtx;
     bioik_problem(bioik_model* m, const bioik_problem_desc& d) : model(m), host(&m->host, d) {}
     ProbPtr pb() const { return (ProbPtr)d_pb; }
@@ -651,6 +660,8 @@ struct SolveLauncher {
         if (it != p->scratch.end()) {
             bioik_problem::Scratch& sc = it->second;
             if (be_stream_capturing(stream)) {
+                for (const auto& r : p->retired_scratch)
+                    if (r.stream == stream && r.purpose == purpose && r.capacity >= bytes) return r.base;  // (pinned by an earlier capture on this stream)
                 if (sc.capacity >= bytes) {
                     sc.pinned = true;  // (the graph being captured keeps this address: see bioik_problem::Scratch)
                     return sc.base;
@@ -659,7 +670,7 @@ struct SolveLauncher {
                 throw Error(BIOIK_ERR_UNSUPPORTED, "a solve captured into a hipGraph needs scratch memory this handle does not hold yet for the stream: run ONE eager call of the same size "
                                                    "(queries, islands) on the stream before capturing");
             } else {
-                if (sc.pinned) p->retired_scratch.push_back(sc.base), sc = bioik_problem::Scratch{};
+                if (sc.pinned) p->retired_scratch.push_back(bioik_problem::Retired{sc.base, sc.capacity, stream, purpose}), sc = bioik_problem::Scratch{};
                 if (sc.capacity >= bytes) return sc.base;
                 // (stream-ordered on THIS stream, kept until it has to grow or the handle goes: no call here waits for the device -- hipMalloc / hipFree do, which
                 // cost the first solves of a pipeline over the handle's six streams a factor of three)
@@ -1105,13 +1116,18 @@ static void solve_dispatch(bioik_problem* p, const DevSolveParams& sp, size_t n,
         run(sw);
         return;
     }
-    const auto key = std::make_tuple((int)sp.lambda, (int)sp.fk_mode, sp.islands > 1 ? 1 : 0);
+    int bucket = 0;  // floor(log2(units)): a mapping measured on 2048 units says little about 65536 (whether the hand-over to the helped kernel pays, ...)
+    for (uint64_t u = units; u > 1; u >>= 1) bucket++;
+    const auto key = std::make_tuple((int)sp.lambda, (int)sp.fk_mode, sp.islands > 1 ? 1 : 0, bucket);
     auto it = p->tuned.find(key);
     if (it != p->tuned.end() && it->second.preset >= 0) {
         run(preset_switches(sw, it->second.preset));
         return;
     }
-    if (!(may_wait || sw.autotune >= 2) || !be_can_time()) {
+    // (not while other solves of the handle are in flight on its other slots: their work would be in the timings, and a submit would block for five solves)
+    bool others_pending = false;
+    for (const auto& sl : p->io) others_pending = others_pending || sl.pending;
+    if (!(may_wait || sw.autotune >= 2) || !be_can_time() || others_pending) {
         run(sw);
         return;
     }
@@ -1212,7 +1228,7 @@ void bioik_problem_destroy(bioik_problem* p) {
     be_free(p->d_resident);
     be_free_pinned(p->h_error);
     for (auto& kv : p->scratch) be_free(kv.second.base);
-    for (void* q : p->retired_scratch) be_free(q);
+    for (const auto& r : p->retired_scratch) be_free(r.base);
     for (auto& sl : p->io) {
         if (sl.pending) {  // (a submitted solve nobody waited for: let it finish before its buffers go)
             try {

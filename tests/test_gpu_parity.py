@@ -780,6 +780,17 @@ def test_hipgraph_replay_with_islands_timeout_and_eager_solves_between(gpus, tem
         assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3]), i
         if i < 3:
             eager_big()  # (needs more scratch than the graph's solve: grows on a buffer of its own)
+    # round 6: a SECOND capture on the same stream, after eager calls have moved to a buffer of their own, takes the first capture's pinned buffer again
+    # (the eager one stays free to grow): both graphs replay to the eager answer, with eager solves in between
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        enqueue()
+    for gg in (g2, g, g2):
+        o[0].zero_(), o[2].zero_(), o[3].zero_()
+        gg.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(o[0].cpu().numpy(), ref[0]) and np.array_equal(o[2].cpu().numpy(), ref[2]) and np.array_equal(o[3].cpu().numpy(), ref[3])
+        eager_big()
 
 
 def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
