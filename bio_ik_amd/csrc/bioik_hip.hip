@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(64) k_solve_point(SolveArgs a) {
     point_body(a, blockIdx.x, lds);
 }
 __global__ void k_select(SelectArgs a) { select_body(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ void __launch_bounds__(64) k_select_wave(SelectArgs a) { select_coop(a, (uint64_t)blockIdx.x, (int)threadIdx.x); }  // a wavefront per query: calls of few queries with many islands
 __global__ void __launch_bounds__(256) k_eval_fk(EvalArgs a) {
     extern __shared__ double lds[];
     eval_fk_body(a, blockIdx.x, lds);
@@ -435,7 +436,7 @@ struct SolveSwitches {
     int helped = 1024;  // BIOIK_SOLVE_HELPED=N: launches of up to N (query, island) units of a problem k_solve_lean_cl4 covers without a secondary goal run its helped
                         // build (k_solve_lean_cl4h: four wavefronts per unit), as do the stragglers a chip-filling call hands over; 0: never
     int debug_flags = 0;  // BIOIK_SOLVE_DEBUG_FLAGS (tests): SolveArgs::debug_flags
-    int fused_select = 1;  // BIOIK_SOLVE_FUSED_SELECT=0: the islands of a one-launch solve are reduced by k_select in a launch of its own (and the first_success words set up by a fill kernel), as until round 5
+    int fused_select = 1;  // BIOIK_SOLVE_FUSED_SELECT=0: the islands of a one-launch solve are reduced by a kernel of their own (and the first_success words set up by a fill kernel), as until round 5; -1: ... by k_select's lane per query whatever the island count (tests)
     int autotune = 1;  // BIOIK_SOLVE_AUTOTUNE: 1 (default) = the host-pointer entries time the eligible lane mappings on a handle's first chip-filling call of a kind and keep
                        // the fastest (solve_dispatch); 2 = the device-pointer entry does so too (it then waits for its stream once); 0 = the rules alone
     bool memset_nodes = false;  // BIOIK_SOLVE_MEMSET_NODES=1 (probe of the runtime's graph-replay defect): hipMemsetAsync instead of the library's own fill kernel
@@ -731,7 +732,8 @@ struct SolveLauncher {
         s.sync = sp.island_sync, s.pad = 0;
         s.isl_solutions = args.solutions, s.isl_fitness = args.fitness, s.isl_success = args.success, s.isl_steps = args.steps;
         s.solutions = d_solutions, s.fitness = d_fitness, s.success = d_success, s.steps = d_steps;
-        LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
+        if (sp.islands >= 8 && n <= 4096 && sw.fused_select >= 0) LAUNCH(k_select_wave, select_coop(s, b_, p_tid()), n, 64, 0, stream, s);
+        else LAUNCH(k_select, select_body(s, b_ * 256 + (uint64_t)p_tid()), (n + 255) / 256, 256, 0, stream, s);
     }
     // gd / gd_r / gd_c / jac: one wavefront per (query, island), its own (small) LDS layout
     void solve_point() {
@@ -1067,7 +1069,7 @@ static void launch_solve(bioik_problem* p, const DevSolveParams& sp_in, size_t n
     if (phase_path) s.handovers.clear();
 #endif
     // (a solve in ONE launch reduces its islands itself, SolveArgs::island_done; BIOIK_SOLVE_FUSED_SELECT=0: by k_select as before)
-    s.result_arrays(a, s.handovers.empty() && sw.fused_select != 0);
+    s.result_arrays(a, s.handovers.empty() && sw.fused_select > 0);
     s.run(a);
 #if defined(BIOIK_PHASE_TIMING)
     if (phase_path) {  // profiling build only: synchronous dump of the per-phase cycle counters

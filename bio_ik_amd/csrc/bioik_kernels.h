@@ -427,6 +427,51 @@ BIOIK_DEV void select_body(const SelectArgs& a, uint64_t q) {
     a.steps[q] = p_load_device(a.isl_steps + u);
 }
 
+// select_body by ONE WAVEFRONT for one query (all 64 lanes call it): lane i reads the islands i, i + 64, ... and three butterflies pick what the loop above
+// picks -- the least step count of a passing island, then the least fitness among the islands that count, the LOWEST island among equal values (the loop's
+// strict comparison keeps the first), else the least fitness of all -- and the lanes copy the winner's solution.  A single lane walks 64 islands in ~22 us
+// (dependent device-scope loads: k_select on one query with 64 islands, profiles/r06_select_by_wavefront.log), the wavefront in ~3: what MoveIt's one pose per call
+// pays once per call.
+BIOIK_DEV void select_coop(const SelectArgs& a, uint64_t q, int lane) {
+    const uint64_t u0 = q * (uint64_t)a.islands;
+    int least = 0x7fffffff;
+    if (a.sync) {
+        for (int i = lane; i < a.islands; i += 64) {
+            const int st = p_load_device(a.isl_steps + u0 + i);
+            if (p_load_device(a.isl_success + u0 + i) && st < least) least = st;
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = p_shfl_xor(least, m);
+            least = o < least ? o : least;
+        }
+    }
+    double bf = BIOIK_DBL_MAX, af = BIOIK_DBL_MAX;  // the least fitness among the islands that count / among all, of this lane's islands
+    int bi = 0x7fffffff, ai = 0x7fffffff;
+    for (int i = lane; i < a.islands; i += 64) {
+        const double f = p_load_device(a.isl_fitness + u0 + i);
+        const bool counts = p_load_device(a.isl_success + u0 + i) && (!a.sync || p_load_device(a.isl_steps + u0 + i) == least);
+        if (counts && f < bf) bf = f, bi = i;
+        if (f < af) af = f, ai = i;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double obf = p_shfl_xor(bf, m), oaf = p_shfl_xor(af, m);
+        const int obi = p_shfl_xor(bi, m), oai = p_shfl_xor(ai, m);
+        if (obf < bf || (obf == bf && obi < bi)) bf = obf, bi = obi;
+        if (oaf < af || (oaf == af && oai < ai)) af = oaf, ai = oai;
+    }
+    double best_fit = bf;
+    int best = bi;
+    if (!(bf < BIOIK_DBL_MAX)) best_fit = af, best = ai;               // no island counts (or none with a fitness below DBL_MAX): the least fitness of all
+    if (!(best_fit < BIOIK_DBL_MAX)) best_fit = BIOIK_DBL_MAX, best = 0;  // ... and if there is none either, the first island
+    const uint64_t u = u0 + (uint64_t)best;
+    for (int v = lane; v < a.V; v += 64) a.solutions[q * a.V + v] = p_load_device(a.isl_solutions + u * a.V + v);
+    if (lane == 0) {
+        a.fitness[q] = best_fit;
+        a.success[q] = p_load_device(a.isl_success + u);
+        a.steps[q] = p_load_device(a.isl_steps + u);
+    }
+}
+
 struct SolveArgs {
     ProbPtr pb;
     DevSolveParams sp;
@@ -2039,18 +2084,19 @@ BIOIK_DEV void solve_epilogue(Frame& F) {
         a.steps[unit] = steps;
     }
     if constexpr (HELPED) p_flag_store((unsigned int*)(lds + L.help) + 2 + p_wave_index(), 0xffffffffu);  // this wavefront's helper may leave
-    if (a.island_done && !handed_over) {  // (SolveArgs::island_done: the query's last island to file its result reduces the islands)
+    if (a.island_done) {  // (SolveArgs::island_done: the query's last island to file its result reduces the islands; set for solves in ONE launch: nothing is handed over)
         p_fence_device();  // this lane's part of the result is visible to the whole device ...
         wg_barrier();      // ... and so is every other lane's
-        if (tid == 0) {
-            const unsigned int filed = p_atomic_inc(a.island_done + q);
-            if (filed + 1u == (unsigned int)sp.islands) {
-                p_fence_device();
-                SelectArgs sa;
-                sa.islands = sp.islands, sa.V = V, sa.sync = sp.island_sync, sa.pad = 0, sa.n = q + 1;
-                sa.isl_solutions = a.solutions, sa.isl_fitness = a.fitness, sa.isl_success = a.success, sa.isl_steps = a.steps;
-                sa.solutions = a.final_solutions, sa.fitness = a.final_fitness, sa.success = a.final_success, sa.steps = a.final_steps;
-                select_body(sa, q);
+        if (tid == 0) s_wbc[0] = p_atomic_inc(a.island_done + q) + 1u == (unsigned int)sp.islands ? 1.0 : 0.0;
+        wg_barrier();
+        if (tid < 64 && s_wbc[0] != 0.0) {  // the workgroup's first wavefront, all of its lanes (select_coop)
+            p_fence_device();
+            SelectArgs sa;
+            sa.islands = sp.islands, sa.V = V, sa.sync = sp.island_sync, sa.pad = 0, sa.n = q + 1;
+            sa.isl_solutions = a.solutions, sa.isl_fitness = a.fitness, sa.isl_success = a.success, sa.isl_steps = a.steps;
+            sa.solutions = a.final_solutions, sa.fitness = a.final_fitness, sa.success = a.final_success, sa.steps = a.final_steps;
+            select_coop(sa, q, tid);
+            if (tid == 0) {
                 p_store_device(a.island_done + q, 0u);
                 if (a.first_success) p_store_device(a.first_success + q, 0xffffffffu);
             }

@@ -793,6 +793,12 @@ def test_hipgraph_replay_with_islands_timeout_and_eager_solves_between(gpus, tem
         eager_big()
 
 
+def test_best_island_three_ways(gpus, templates, monkeypatch):
+    """round 6: the islands' reduction by a wavefront (inside the solve's launch, or a launch of its own) against the lane that walks the islands"""
+    pc.island_selection_three_ways(gpus["c2"], templates["c2"], monkeypatch, n=5, pop=128, steps=12)
+    pc.island_selection_three_ways(gpus["c2"], templates["c2"], monkeypatch, n=3, pop=16, steps=20, fk_mode=abi.FK_LINEAR)
+
+
 def test_islands_that_stop_each_other(gpus, oracles, templates, monkeypatch):
     """bioik_solve_params::island_sync = 1 on the device: islands of a query that run in different workgroups at different times, the answer still the
     oracle's lock-step answer bit for bit (an island leaves early only when its result can no longer be chosen)"""

@@ -699,6 +699,11 @@ def test_islands_sized_to_the_idle_chip(sims, templates):
     assert all(np.array_equal(x, y) for x, y in zip(g0, g1))
 
 
+def test_best_island_three_ways(sims, templates, monkeypatch):
+    """round 6: the islands' reduction by a wavefront (inside the solve's launch, or a launch of its own) against the lane that walks the islands"""
+    pc.island_selection_three_ways(sims["c2"], templates["c2"], monkeypatch, n=3, pop=16, steps=5, fk_mode=abi.FK_LINEAR)
+
+
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):
     """joints without any range: every child of a generation is the same genotype, so every fitness of a generation is the same number and
     the elitist selection is decided by position alone (ik_evolution_2.cpp:410-431) -- the tie path of the wavefront-minimum top-2
