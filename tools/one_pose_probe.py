@@ -1,5 +1,5 @@
 """round 6: the latency of ONE pose per plugin call (bioik_plugin_search_each), call by call: mean, percentiles, and where the slow calls are -- their indices and times.
-usage: python tools/one_pose_probe.py [timeout_ms] [calls] [arm|arm_md|all|snake] [gpu_islands] [gpu_population] [gpu_max_steps]"""
+usage: python tools/one_pose_probe.py [timeout_ms] [calls] [arm|arm_md|all|snake] [gpu_islands] [gpu_population] [gpu_max_steps] [exact|linear]"""
 import os
 import sys
 
@@ -21,6 +21,7 @@ def main():
     islands = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     pop = int(sys.argv[5]) if len(sys.argv) > 5 else 128
     max_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 4096
+    fk = sys.argv[7] if len(sys.argv) > 7 else "exact"
     model, group, tips, extra = {"arm": (pr2_like(), "right_arm", ["r_wrist_roll_link"], []),
                                  "arm_md": (pr2_like(), "right_arm", ["r_wrist_roll_link"], [MinimalDisplacementGoal()]),
                                  "all": (pr2_like(), "all", ["r_wrist_roll_link", "l_wrist_roll_link"], [MinimalDisplacementGoal()]),
@@ -29,13 +30,13 @@ def main():
     h = HipSolver(template, device=0)
     seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=0x0E905E)
     plug = BioIKKinematicsPlugin()
-    plug.initialize(model, group, model.link_names[0], tips, params={"random_seed": 1, "gpu_max_steps": max_steps, "gpu_islands": islands, "gpu_population": pop})
+    plug.initialize(model, group, model.link_names[0], tips, params={"random_seed": 1, "gpu_max_steps": max_steps, "gpu_islands": islands, "gpu_population": pop, "gpu_fk": fk})
     gv = plug._group_vars
     poses = np.stack([params[:, 8 * t:8 * t + 7] for t in range(len(tips))], axis=1)
     opts = BioIKKinematicsQueryOptions()
     opts.goals = list(extra)
     plug.searchPositionIKEach(poses[:8], seeds[:8, gv], opts, timeout=0.02)
-    print("%s, gpu_islands %d, gpu_population %d, gpu_max_steps %d" % (which, islands, pop, max_steps))
+    print("%s, gpu_islands %d, gpu_population %d, gpu_max_steps %d, gpu_fk %s" % (which, islands, pop, max_steps, fk))
     for rep in range(2):
         _, ok, _, sec = plug.searchPositionIKEach(poses, seeds[:, gv], opts, timeout=timeout)
         order = np.argsort(sec)[::-1][:8]
