@@ -355,18 +355,19 @@ def line_search_step_without_bound(make_solver):
         assert np.isfinite(sol).all() and np.abs(sol).max() < 1e300
 
 
-def island_selection_three_ways(h, template, monkeypatch, n=3, pop=16, steps=5, fk_mode=None):
+def island_selection_three_ways(h, template, monkeypatch, n=3, pop=16, steps=5, fk_mode=None, kind="global", noise=0.1, configs=((9, 1, False), (64, 1, False), (100, 0, False), (100, 1, True), (70, 1, False))):
     """The best island of every query (ik_parallel.h:220-269) three ways -- by the query's last island inside the solve's launch (a wavefront: select_coop), by a
     wavefront per query in a launch of its own (k_select_wave), by a lane per query walking the islands (k_select: the loop that restates the reference) -- on solves
     whose islands pass at different steps, pass not at all (the fallback: least fitness of all), and number more than a wavefront has lanes: the same answer."""
     from bio_ik_amd import abi
     from bio_ik_amd.workload import make_queries
     import numpy as np
-    seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=77)
+    seeds, params, _ = make_queries(template, h.active_variables, h.fk_genes, n, seed=77, kind=kind, noise=noise)
     far = params.copy()
     far[:, 0:3] += 10.0  # out of reach: no island ever passes
     kw = {} if fk_mode is None else {"fk_mode": fk_mode}
-    for islands, sync, par in ((9, 1, params), (64, 1, params), (100, 0, params), (100, 1, far), (70, 1, params)):
+    for islands, sync, unreachable in configs:
+        par = far if unreachable else params
         res = []
         for mode in ("1", "0", "-1"):
             monkeypatch.setenv("BIOIK_SOLVE_FUSED_SELECT", mode)
@@ -374,3 +375,4 @@ def island_selection_three_ways(h, template, monkeypatch, n=3, pop=16, steps=5, 
         monkeypatch.delenv("BIOIK_SOLVE_FUSED_SELECT")
         for r in res[1:]:
             assert all(np.array_equal(x, y) for x, y in zip(res[0], r)), (islands, sync)
+        assert not res[0][2].any() if unreachable else res[0][2].any(), (islands, sync, res[0][2])  # (the rule for passing islands / the fallback is what ran)

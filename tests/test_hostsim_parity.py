@@ -701,7 +701,7 @@ def test_islands_sized_to_the_idle_chip(sims, templates):
 
 def test_best_island_three_ways(sims, templates, monkeypatch):
     """round 6: the islands' reduction by a wavefront (inside the solve's launch, or a launch of its own) against the lane that walks the islands"""
-    pc.island_selection_three_ways(sims["c2"], templates["c2"], monkeypatch, n=3, pop=16, steps=5, fk_mode=abi.FK_LINEAR)
+    pc.island_selection_three_ways(sims["c2"], templates["c2"], monkeypatch, n=2, pop=8, steps=4, fk_mode=abi.FK_LINEAR, kind="tracking", noise=0.02, configs=((9, 1, False), (70, 1, True), (66, 0, False)))
 
 
 def test_selection_ties_are_decided_by_position(hostsim_lib, monkeypatch):
