@@ -530,6 +530,17 @@ def main():
                              streams[1].cuda_stream)
         torch.cuda.synchronize(dev)
         identical = bool(torch.equal(chk[0], d_sol)) and bool(torch.equal(chk[2], d_suc)) and bool(torch.equal(chk[3], d_steps))
+    # The same protocol over three times as many steps, right behind the timed region: a run of K steps is K batches at the steady rate plus a fixed piece -- the
+    # chip filling up at the start and, mostly, the stragglers of the last batches finishing on a nearly empty chip at the end (up to 64 sequential steps each).
+    # Two run lengths separate the two: what the kernels do on a full chip, and what the protocol's ends cost.
+    longer = None
+    if world == 1 and not args.timed_only and args.steps >= nfl and os.environ.get("BIOIK_BENCH_LONGER", "1") != "0":
+        k3 = 3 * args.steps
+        el3, _ = timed(k3, 0)
+        sh3 = [len(range(k, k3, nfl)) for k in range(nfl)]
+        suc3 = float(sum(int(o[2].sum().item()) * sh3[k] for k, o in enumerate(bufs)))
+        longer = {"steps": k3, "value": suc3 / el3, "ms_per_step": 1e3 * el3 / k3,
+                  "steady_ms_per_step": 1e3 * (el3 - elapsed) / (k3 - args.steps), "fixed_ms_per_run": 1e3 * (elapsed - (el3 - elapsed) / (k3 - args.steps) * args.steps)}
     sequential = latency3 = None
     if nfl > 1 and not args.timed_only:
         # the same steps strictly one after the other, and three in flight, under BIOIK_SCHEDULE_LATENCY: what an isolated call takes, and the
@@ -650,6 +661,13 @@ def main():
                                      "LDS-resident and the measured traffic is `roofline.traffic`"}},
         "results_identical_across_streams": identical,
     }
+    if longer is not None:
+        longer["frac"] = alg_flops * longer["steps"] / (longer["ms_per_step"] * 1e-3 * longer["steps"]) / FP64_PEAK
+        longer["steady_frac"] = alg_flops / (longer["steady_ms_per_step"] * 1e-3) / FP64_PEAK if longer["steady_ms_per_step"] > 0 else None
+        longer["note"] = ("the timed protocol once more over three times the steps, behind the timed region: `steady_ms_per_step` = the extra steps' extra time (the kernels on "
+                          "a full chip), `fixed_ms_per_run` = what the K-step region takes beyond K steady steps (the chip filling up, and the last batches' stragglers -- up "
+                          "to 64 sequential steps each -- finishing on an empty chip); never `value`")
+        out["longer_run"] = longer
     if latency3 is not None and world == 1:
         out["latency_schedule_three_in_flight"] = {"value": latency3[0], "unit": "solves/s", "ms_per_step": latency3[1] * 1e3, "batches_in_flight": 3,
                                                    "note": "BIOIK_SCHEDULE_LATENCY, three solves in flight: the protocol of `value` up to round 3's first profile"}
@@ -883,6 +901,7 @@ def main():
             return None if x is None else float("%.3g" % x)
         out["summary"] = {
             "value": r3(out["value"]), "chip_frac": r3(out["roofline"]["chip_level_frac"]),
+            "steady_frac": r3(out.get("longer_run", {}).get("steady_frac")), "fixed_ms_per_run": r3(out.get("longer_run", {}).get("fixed_ms_per_run")),
             "lat3": r3(out.get("latency_schedule_three_in_flight", {}).get("value")),
             "one_at_a_time": r3(out.get("one_batch_at_a_time", {}).get("value")),
             "host_pipelined": r3(out.get("host_pointer_pipelined", {}).get("value")),
