@@ -677,6 +677,11 @@ BIOIK_DEV F7 multi_joint_fetch(const F7& f, const double* slots_of_child, int mu
     return f7_concat(f, F7{{s[0], s[(size_t)nth], s[(size_t)2 * nth]}, {s[(size_t)3 * nth], s[(size_t)4 * nth], s[(size_t)5 * nth], s[(size_t)6 * nth]}});
 }
 
+// accessors whose entry is COMPUTED from numbers of the op (ChildX, ChildT: `at`) say so
+template <class XA, class = void>
+struct accessor_takes_op_numbers : std::false_type {};
+template <class XA>
+struct accessor_takes_op_numbers<XA, std::enable_if_t<XA::takes_op_numbers>> : std::true_type {};
 // value of the joint of op k in the individual x: its own entry, or for a mimic joint factor * (entry of the joint it
 // follows) + offset (RobotFK_Fast_Base::updateMimic, forward_kinematics.h:230-246; a plain multiply and add)
 template <class XA>
@@ -867,8 +872,16 @@ BIOIK_DEV void fk_walk_n(PB pb, const XA (&x)[N], double* slots, int slot_set_st
         const double cb0 = pb->ops[k].cb[0], cb1 = pb->ops[k].cb[1], cb2 = pb->ops[k].cb[2], cb3 = pb->ops[k].cb[3];
         const double cp0 = pb->ops[k].cpos[0], cp1 = pb->ops[k].cpos[1], cp2 = pb->ops[k].cpos[2];
         double xv[N];
+        if constexpr (SERIAL && accessor_takes_op_numbers<XA>::value) {
+            // (children computed where they are read: what their accessor reads of the op comes with the burst above)
+            const int gene = pb->ops[k].gene;
+            const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
 #pragma unroll
-        for (int j = 0; j < N; j++) xv[j] = joint_value(x[j], k, msrc, mf, mo);
+            for (int j = 0; j < N; j++) xv[j] = x[j].at(k, gene, span, cmin, cmax);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; j++) xv[j] = joint_value(x[j], k, msrc, mf, mo);
+        }
         if (ls >= 0) {
             const int tid = p_tid_fresh();
 #pragma unroll
@@ -1313,12 +1326,17 @@ struct ChildX {
     // (p_clamp_uniform); false where lane k asks for op k (the winners' re-derivation): the same two instructions on vector operands
     template <bool UNIFORM = true>
     BIOIK_DEV double value(int k) const {
+        return at<UNIFORM>(k, pb->ops[k].gene, pb->ops[k].span, pb->ops[k].clip_min, pb->ops[k].clip_max);
+    }
+    // the same with the op's numbers handed in: the chain walk asks for them in ONE burst of scalar loads with the joint's constants (fk_walk_n), and the
+    // parents' entries are read from LDS before anything waits -- a lone wavefront (one pose per call, the stragglers of a batch) otherwise waits four times per joint
+    static constexpr bool takes_op_numbers = true;
+    template <bool UNIFORM = true>
+    BIOIK_DEV double at(int k, int g, double span, double cmin, double cmax) const {
         BIOIK_FP_STRICT
-        const int g = pb->ops[k].gene;
         const double parent_gene = p0g[k];
-        if (g < 0) return parent_gene;  // inactive op: the seed's value, carried by every elite
-        const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
         const double d0 = p0d[k], d1 = p1d[k];
+        if (g < 0) return parent_gene;  // inactive op: the seed's value, carried by every elite
         const uint32_t word = rng_child_word(base, (uint32_t)(g + 1));
         double r = rng_gauss32(word);
         double f = mutation_rate * span;
@@ -1362,18 +1380,19 @@ struct ChildT {
     const double *p0g, *pgrow;  // LDS, op-indexed: genes of parent 0; the row of the table for this child's parity
     uint32_t base;
     double mutation_rate, gradient_factor;
-    BIOIK_DEV double operator()(int k) const {
+    BIOIK_DEV double operator()(int k) const { return at(k, pb->ops[k].gene, pb->ops[k].span, pb->ops[k].clip_min, pb->ops[k].clip_max); }
+    static constexpr bool takes_op_numbers = true;  // (ChildX::at)
+    BIOIK_DEV double at(int k, int g, double span, double cmin, double cmax) const {
         BIOIK_FP_STRICT
-        const int g = pb->ops[k].gene;
         const double parent_gene = p0g[k];
+        const double pg = pgrow[k];
         if (g < 0) return parent_gene;
-        const double span = pb->ops[k].span, cmin = pb->ops[k].clip_min, cmax = pb->ops[k].clip_max;
         const uint32_t word = rng_child_word(base, (uint32_t)(g + 1));
         double r = rng_gauss32(word);
         double f = mutation_rate * span;
         double gn = parent_gene;
         gn += r * f;
-        double g2 = pgrow[k] * gradient_factor;
+        double g2 = pg * gradient_factor;
         gn += g2;
         gn = p_clamp_uniform(gn, cmin, cmax);
         return gn;

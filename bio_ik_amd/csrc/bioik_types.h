@@ -27,28 +27,33 @@ enum { BIOIK_ROT_GENERAL = 0, BIOIK_ROT_X = 1, BIOIK_ROT_Y = 2, BIOIK_ROT_Z = 3 
 // with  revolute : C o J = ( C.pos , cos(x/2) * A + sin(x/2) * B ),  A = C.rot, B = C.rot (x) (axis, 0)
 //       prismatic: C o J = ( C.pos + x * Pv , A ),                  Pv = C.rot * axis   (stored in cb[0..2])
 struct DevOp {
+    // What a joint of the chain walk reads comes first and lies together -- 14 doubles and 6 ints = 34 dwords, three scalar loads in one burst (fk_walk_n) --;
+    // scattered over the record the same numbers took eight loads in three bursts, each waited for on its own: nothing for a full chip, a fifth of the
+    // lone step of a call that cannot fill it (round 6)
     double cpos[3];
     double ca[4];
     double cb[4];
-    double axis[3];                  // joint axis in the joint frame (analytic Jacobian, forward_kinematics.h:639-693)
     double clip_min, clip_max, span; // RobotInfo (include/bio_ik/robot_info.h:70-106) of the variable
-    double vmin, vmax;               // variable bounds (random re-initialisation, ik_evolution_2.cpp:626-631)
-    double vw;                       // minimal_displacement_factors (src/problem.cpp:207-225)
-    double mimic_factor, mimic_offset;  // mimic joint: value = x(mimic_src) * factor + offset (forward_kinematics.h:230-246)
     int32_t type;                    // BIOIK_OP_*
     int32_t pos_kind;                // BIOIK_POS_*: which components of cpos are non-zero (revolute ops; the walk skips the exact no-ops)
     int32_t rot_kind;                // BIOIK_ROT_*: revolute op behind an unrotated constant frame turning about a coordinate axis
-    int32_t var;                     // robot variable index
     int32_t gene;                    // index into Problem::active_variables, or -1 (inactive: value comes from the seed)
+    int32_t tip_first, tip_count;    // device tips whose frame is F_out o E (evaluated right after this op)
+    // ... and what the other phases read
+    double axis[3];                  // joint axis in the joint frame (analytic Jacobian, forward_kinematics.h:639-693)
+    double vmin, vmax;               // variable bounds (random re-initialisation, ik_evolution_2.cpp:626-631)
+    double vw;                       // minimal_displacement_factors (src/problem.cpp:207-225)
+    double mimic_factor, mimic_offset;  // mimic joint: value = x(mimic_src) * factor + offset (forward_kinematics.h:230-246)
+    int32_t var;                     // robot variable index
     int32_t src;                     // op whose output frame is the parent frame, -1 = model root (identity)
     int32_t load_slot;               // >=0: parent frame must be fetched from this LDS slot (branching trees)
     int32_t save_slot;               // >=0: output frame is parked in this LDS slot for a later branch
-    int32_t tip_first, tip_count;    // device tips whose frame is F_out o E (evaluated right after this op)
     int32_t unbounded;               // clip_max == DBL_MAX (goal_types.h:394,419)
     int32_t mimic_src;               // op whose value this joint mimics, -1: the joint has its own value x(k)
     int32_t val_first;               // FLOATING / PLANAR chain op: first of its 7 / 3 consecutive value ops (type NONE), else -1
     int32_t joint_op;                // value op of a FLOATING / PLANAR joint: the chain op it belongs to, else -1
     int32_t multi_slot;              // FLOATING / PLANAR chain op: the LDS slot its joint frame J(values) is parked in before a walk (multi_joint_prologue); else -1
+    int32_t pad_;
 };
 
 struct DevTip {
