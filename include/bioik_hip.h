@@ -124,7 +124,7 @@ enum { BIOIK_SCHEDULE_LATENCY = 0, BIOIK_SCHEDULE_THROUGHPUT = 1, BIOIK_SCHEDULE
  * (MoveIt's one pose per call), 32 for sixteen, 16 up to 128 ... -- stopping each other (island_sync is then taken as 1): the reference's four island
  * threads with "any thread succeeds => all stop" (ik_parallel.h:102, 141-178), sized to the hardware.  A call that cannot fill the chip is bound by its
  * slowest query's number of steps, and islands cut exactly that (MI355X, PoseGoal on a 7-joint arm, pop 128: 16 queries 3.5 -> 1.25 ms per call, 256 queries
- * 6.2 -> 2.85 ms, one query 1.2 -> 0.73 ms: bench.py's small_batches).  bioik_resolve_islands() returns the count a call of n queries would get.
+ * 6.2 -> 2.8 ms, one query 1.2 -> 0.71 ms: bench.py's small_batches).  bioik_resolve_islands() returns the count a call of n queries would get.
  * THE ANSWER OF A QUERY THEN DEPENDS ON THE SIZE OF THE CALL IT CAME IN (the island count is a function of n, and the islands' streams of random numbers are
  * part of the answer): give an explicit count where answers must not depend on batching.  The bio2 family only: for gd / jac an island count names another
  * solver ("gd_8"). */
