@@ -461,7 +461,10 @@ def main():
     # reproduced with idle torch streams, gone with four hardware queues or fewer streams).  A MoveIt process has the plugin's streams and no others.
     one_pose = None
     if rank == 0 and world == 1 and not args.timed_only and os.environ.get("BIOIK_BENCH_ONE_POSE", "1") != "0":
-        one_pose = one_pose_timeouts(dev, cpu=not args.no_cpu_baseline)
+        try:
+            one_pose = one_pose_timeouts(dev, cpu=not args.no_cpu_baseline)
+        except Exception as e:  # (a secondary leg must not take the headline with it)
+            one_pose = {"error": repr(e), "rows": []}
     streams = [torch.cuda.Stream(dev) for _ in range(nfl)]
     bufs = [(torch.empty((BATCH, V), dtype=torch.float64, device=dev), torch.empty(BATCH, dtype=torch.float64, device=dev),
              torch.empty(BATCH, dtype=torch.int32, device=dev), torch.empty(BATCH, dtype=torch.int32, device=dev)) for _ in range(nfl)]
