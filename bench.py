@@ -32,6 +32,11 @@ Extra objects on the JSON line:
   tracking_seeds  the same template and parameters on seeds near the target (SURVEY.md section 8(d)'s second workload).
   reference_parameters  the GPU on the same queries at the reference's own parameters (its population, its linearised
                phenotypes): the like-for-like figure next to cpu_baseline.value.
+  longer_run   the timed protocol once more over 3 K steps, behind the timed region: the steady rate of a batch on a full chip and what a run costs at its ends
+               (the last batches' stragglers finishing on an empty chip); never `value`.
+  small_batches, small_batches_secondary_goals, one_pose_timeouts   calls that cannot fill the chip: ms per call for 1 ... 1024 queries; ONE pose per plugin call under the
+               reference's timeouts (1 / 5 / 20 ms) with the reference's own wall-clock loop beside every cell.  The one-pose leg runs first (see main()).
+  summary      the figures a reader looks for first, last on the line.
 """
 import argparse
 import json
